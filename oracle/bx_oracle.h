@@ -1,0 +1,96 @@
+/*
+ * bx_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY) for the segment-prove hot path.
+ *
+ * This is a plain-C restatement of the algorithms that the reference reaches through
+ *   agent.prover.prove_segment(...)            bento/crates/workflow/src/tasks/prove.rs:41-49
+ *   get_prover_server(&ProverOpts::default())  bento/crates/workflow/src/lib.rs:246-249
+ * i.e. the `risc0_zkp::hal::Hal` CPU implementation.  That arithmetic is NOT in /root/reference:
+ * it lives in the un-vendored crates pinned by the reference's lockfile
+ *   risc0-zkp 3.0.3 (Cargo.lock:9155), risc0-core 3.0.0 (Cargo.lock:9012).
+ * The restatement therefore follows their *published* algorithms (BabyBear Montgomery field,
+ * recursive DIF/DIT NTT, Poseidon2 t=24 sponge, FRI fold-by-16), as summarised in SURVEY.md
+ * Appendix A.
+ *
+ * PARITY STATUS
+ *   - Poseidon2 permutation: PINNED to the published BabyBear t=24 known-answer test
+ *     (input 0..23) — see tests/golden/poseidon2_kat.json and oracle/README.md.
+ *     Round constants are *derived* (Poseidon Grain-LFSR generator), not typed in.
+ *   - Field constants / roots of unity: pinned numerically (tests/golden/babybear_consts.json).
+ *   - NTT / FRI-fold / Merkle / seal bytes vs. the Rust CPU prover: PARITY UNPINNED — the
+ *     reference holds no vectors for them and cannot be built here.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ * The product (boundless_amd/) never links, imports or calls it.
+ *
+ * All field elements cross this API as u32 words in Montgomery form (R = 2^32), exactly the
+ * in-memory representation of risc0_core::field::baby_bear::Elem.
+ */
+#ifndef BX_ORACLE_H
+#define BX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BXO_P 2013265921u
+#define BXO_CELLS 24
+#define BXO_RATE 16
+#define BXO_DIGEST_WORDS 8
+#define BXO_EXT 4
+#define BXO_FRI_FOLD 16
+
+void bxo_init(void); /* idempotent; builds root tables + Poseidon2 constants */
+void bxo_set_threads(int n); /* OpenMP threads for batch ops (0 = all cores) */
+int bxo_get_threads(void);
+
+/* ---- field ---- */
+uint32_t bxo_fp_encode(uint32_t canonical);
+uint32_t bxo_fp_decode(uint32_t mont);
+uint32_t bxo_fp_add(uint32_t a, uint32_t b);
+uint32_t bxo_fp_sub(uint32_t a, uint32_t b);
+uint32_t bxo_fp_mul(uint32_t a, uint32_t b);
+uint32_t bxo_fp_pow(uint32_t a, uint64_t e);
+uint32_t bxo_fp_inv(uint32_t a);
+void bxo_fp4_mul(uint32_t out[4], const uint32_t a[4], const uint32_t b[4]);
+void bxo_fp4_inv(uint32_t out[4], const uint32_t a[4]);
+uint32_t bxo_rou_fwd(unsigned k); /* Montgomery form of ROU_FWD[k], order 2^k */
+uint32_t bxo_rou_rev(unsigned k);
+
+/* ---- NTT family (column-major: poly c occupies [c*size,(c+1)*size)) ---- */
+void bxo_batch_interpolate_ntt(uint32_t* io, size_t count, size_t size);
+void bxo_batch_evaluate_ntt(uint32_t* io, size_t count, size_t size, unsigned expand_bits);
+void bxo_batch_expand_into_evaluate_ntt(uint32_t* out, const uint32_t* in, size_t count,
+                                        size_t in_size, unsigned expand_bits);
+void bxo_batch_bit_reverse(uint32_t* io, size_t count, size_t size);
+void bxo_zk_shift(uint32_t* io, size_t count, size_t size);
+
+/* ---- Poseidon2 (BabyBear, t=24, rate 16, 8 full + 21 partial rounds, x^7) ---- */
+void bxo_poseidon2_get_params(uint32_t rc_canonical[213], uint32_t diag_canonical[24]);
+void bxo_poseidon2_set_params(const uint32_t rc_canonical[213], const uint32_t diag_canonical[24]);
+void bxo_poseidon2_mix(uint32_t cells[24]);
+void bxo_hash_elem_slice(uint32_t digest[8], const uint32_t* elems, size_t n, size_t stride);
+void bxo_hash_pair(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]);
+void bxo_hash_rows(uint32_t* out_digests, const uint32_t* matrix, size_t rows, size_t cols);
+void bxo_hash_fold(uint32_t* io_digests, size_t input_size, size_t output_size);
+
+/* ---- FRI / DEEP helpers ---- */
+void bxo_fri_fold(uint32_t* out, const uint32_t* in, const uint32_t mix[4], size_t out_count);
+void bxo_mix_poly_coeffs(uint32_t* out_ext, const uint32_t mix_start[4], const uint32_t mix[4],
+                         const uint32_t* in, const uint32_t* combos, size_t input_size,
+                         size_t count);
+void bxo_batch_evaluate_any(const uint32_t* coeffs, size_t poly_size, const uint32_t* which,
+                            const uint32_t* xs_ext, uint32_t* out_ext, size_t eval_count);
+void bxo_eltwise_add(uint32_t* out, const uint32_t* a, const uint32_t* b, size_t n);
+void bxo_eltwise_sum_extelem(uint32_t* out, const uint32_t* in_ext, size_t count, size_t to_add);
+void bxo_eltwise_zeroize(uint32_t* io, size_t n);
+void bxo_gather_sample(uint32_t* dst, const uint32_t* src, size_t idx, size_t size,
+                       size_t stride);
+/* DEEP quotient: combo (SoA ext planes? no: AoS ext, `size` elems) <- (combo - value)/(x - z),
+ * synthetic division, coefficients in natural order. Returns the remainder-is-zero flag. */
+int bxo_poly_divide(uint32_t* poly_ext, size_t size, const uint32_t z[4], uint32_t rem_out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""ctypes loader for oracle/libbx_oracle.so (the C restatement).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build(force=False, native=False, out=None):
+    """Compile the C oracle.  native=True builds a -march=native copy (for the cpu_baseline timing leg)."""
+    out = out or os.path.join(_HERE, "libbx_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("bx_oracle.c", "bx_oracle_prover.c")]
+    deps = srcs + [os.path.join(_HERE, "bx_oracle.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["gcc", "-O3", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", out] + srcs
+    if native:
+        cmd.insert(2, "-march=native")
+    subprocess.run(cmd, check=True, cwd=_HERE)
+    return out
+
+
+def lib(path=None):
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or os.path.join(_HERE, "libbx_oracle.so")
+    if not os.path.exists(p):
+        build()
+    L = C.CDLL(p)
+    sz = C.c_size_t
+    sig = {
+        "bxo_init": ([], None),
+        "bxo_set_threads": ([C.c_int], None),
+        "bxo_get_threads": ([], C.c_int),
+        "bxo_fp_encode": ([C.c_uint32], C.c_uint32),
+        "bxo_fp_decode": ([C.c_uint32], C.c_uint32),
+        "bxo_fp_add": ([C.c_uint32, C.c_uint32], C.c_uint32),
+        "bxo_fp_sub": ([C.c_uint32, C.c_uint32], C.c_uint32),
+        "bxo_fp_mul": ([C.c_uint32, C.c_uint32], C.c_uint32),
+        "bxo_fp_pow": ([C.c_uint32, C.c_uint64], C.c_uint32),
+        "bxo_fp_inv": ([C.c_uint32], C.c_uint32),
+        "bxo_fp4_mul": ([u32p, u32p, u32p], None),
+        "bxo_fp4_inv": ([u32p, u32p], None),
+        "bxo_rou_fwd": ([C.c_uint], C.c_uint32),
+        "bxo_rou_rev": ([C.c_uint], C.c_uint32),
+        "bxo_batch_interpolate_ntt": ([u32p, sz, sz], None),
+        "bxo_batch_evaluate_ntt": ([u32p, sz, sz, C.c_uint], None),
+        "bxo_batch_expand_into_evaluate_ntt": ([u32p, u32p, sz, sz, C.c_uint], None),
+        "bxo_batch_bit_reverse": ([u32p, sz, sz], None),
+        "bxo_zk_shift": ([u32p, sz, sz], None),
+        "bxo_poseidon2_get_params": ([u32p, u32p], None),
+        "bxo_poseidon2_set_params": ([u32p, u32p], None),
+        "bxo_poseidon2_mix": ([u32p], None),
+        "bxo_hash_elem_slice": ([u32p, u32p, sz, sz], None),
+        "bxo_hash_pair": ([u32p, u32p, u32p], None),
+        "bxo_hash_rows": ([u32p, u32p, sz, sz], None),
+        "bxo_hash_fold": ([u32p, sz, sz], None),
+        "bxo_fri_fold": ([u32p, u32p, u32p, sz], None),
+        "bxo_mix_poly_coeffs": ([u32p, u32p, u32p, u32p, u32p, sz, sz], None),
+        "bxo_batch_evaluate_any": ([u32p, sz, u32p, u32p, u32p, sz], None),
+        "bxo_eltwise_add": ([u32p, u32p, u32p, sz], None),
+        "bxo_eltwise_sum_extelem": ([u32p, u32p, sz, sz], None),
+        "bxo_eltwise_zeroize": ([u32p, sz], None),
+        "bxo_gather_sample": ([u32p, u32p, sz, sz, sz], None),
+        "bxo_poly_divide": ([u32p, sz, u32p, u32p], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = res
+    L.bxo_init()
+    if path is None:
+        _LIB = L
+    return L
+
+
+P = 2013265921
+
+
+def encode(x):
+    """canonical ints (array-like) -> Montgomery u32 array"""
+    a = np.asarray(x, dtype=np.uint64) % np.uint64(P)
+    return ((a << np.uint64(32)) % np.uint64(P)).astype(np.uint32)
+
+
+def decode(m):
+    """Montgomery u32 array -> canonical (numpy uint32)."""
+    a = np.asarray(m, dtype=np.uint64)
+    rinv = np.uint64(pow(1 << 32, -1, P))
+    return ((a * rinv) % np.uint64(P)).astype(np.uint32)
+
+
+def random_elems(rng, shape):
+    """uniform field elements as Montgomery words (any word < P is a valid Montgomery element)"""
+    return rng.integers(0, P, size=shape, dtype=np.uint32)
