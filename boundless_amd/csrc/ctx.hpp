@@ -1,0 +1,129 @@
+// ctx.hpp — internal state behind the opaque bx_ctx of include/bx_hal.h (one per device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bx_hal.h"
+#include "fp.hpp"
+
+namespace bx {
+
+constexpr int TW_LOG = 13;  // stage-twiddle tables cover sub-transform sizes up to 2^13
+
+struct ProfRec {
+    const char* name;
+    double bytes;  // algorithmic bytes of this call
+    hipEvent_t e0, e1;
+};
+struct ProfAgg {
+    double ms = 0, bytes = 0;
+    long calls = 0;
+};
+
+struct TwistKey {
+    int m, m_hi, inverse;
+    bool operator<(const TwistKey& o) const {
+        if (m != o.m) return m < o.m;
+        if (m_hi != o.m_hi) return m_hi < o.m_hi;
+        return inverse < o.inverse;
+    }
+};
+struct ZkTab {
+    uint32_t* lo = nullptr;  // 3^(rev_LO(i_lo) << (n-LO))
+    uint32_t* hi = nullptr;  // 3^(rev_(n-LO)(i_hi))
+    int lo_bits = 0;
+};
+
+}  // namespace bx
+
+struct bx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    char err[512];
+    int cu_count = 256;
+
+    // NTT tables (device): stage table index 2^(s-1)+e -> w_{2^s}^{+-e} (Montgomery)
+    uint32_t* d_tw_fwd = nullptr;
+    uint32_t* d_tw_inv = nullptr;
+    std::map<bx::TwistKey, uint32_t*> twist;
+    std::map<int, bx::ZkTab> zk;
+
+    // Poseidon2 parameters: host canonical copy + device Montgomery copy [213 rc | 24 diag]
+    uint32_t h_rc[BX_POSEIDON2_RC_COUNT];
+    uint32_t h_diag[24];
+    uint32_t* d_p2 = nullptr;
+
+    // scratch (grown on demand)
+    uint32_t* d_scratch = nullptr;
+    size_t scratch_words = 0;
+
+    // tunables
+    long ntt_block_log = 12;   // log2 of the contiguous-pass sub-transform (13 when the size needs it)
+    long ntt_tile_log = 14;    // log2 of the strided-pass LDS tile (elements)
+    long hash_rows_block = 256;
+
+    // timing
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    std::vector<bx::ProfRec> prof_pending;
+    std::map<std::string, bx::ProfAgg> prof_agg;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace bx {
+
+inline const char* set_err(bx_ctx* c, const char* what, hipError_t e, const char* file, int line) {
+    snprintf(c->err, sizeof c->err, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return c->err;
+}
+inline const char* set_msg(bx_ctx* c, const char* msg) {
+    snprintf(c->err, sizeof c->err, "%s", msg);
+    return c->err;
+}
+
+#define BX_HIP(c, call)                                                        \
+    do {                                                                       \
+        hipError_t _e = (call);                                                \
+        if (_e != hipSuccess) return bx::set_err((c), #call, _e, __FILE__, __LINE__); \
+    } while (0)
+#define BX_LAUNCH_CHECK(c) BX_HIP(c, hipGetLastError())
+#define BX_REQUIRE(c, cond, msg)                  \
+    do {                                          \
+        if (!(cond)) return bx::set_msg((c), msg); \
+    } while (0)
+#define BX_TRY(expr)                      \
+    do {                                  \
+        const char* _m = (expr);          \
+        if (_m) return _m;                \
+    } while (0)
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline int ilog2(size_t n) {
+    int k = 0;
+    while (((size_t)1 << k) < n) k++;
+    return k;
+}
+
+// RAII bracket: records hipEvents around an entry point when profiling is on.
+struct OpScope {
+    bx_ctx* c;
+    const char* name;
+    double bytes;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    OpScope(bx_ctx* ctx, const char* n, double b);
+    ~OpScope();
+};
+
+// internal launchers shared between translation units (each returns NULL or an error string)
+const char* ensure_scratch(bx_ctx* c, size_t words);
+const char* ntt_init_tables(bx_ctx* c);
+void ntt_free_tables(bx_ctx* c);
+const char* poseidon2_upload_params(bx_ctx* c);
+
+}  // namespace bx

@@ -1,0 +1,132 @@
+// fp.hpp — BabyBear field (Montgomery u32) and its quartic extension, usable from host and gfx950 device code.
+//
+// Restates risc0_core::field::baby_bear::{Elem, ExtElem} (risc0-core 3.0.0, pinned by the reference's
+// Cargo.lock:9012; reached from bento/crates/workflow/src/tasks/prove.rs:41-49).  Every value that crosses the
+// HAL boundary is the Montgomery word itself, so results are bit-identical as long as each op returns the
+// canonical representative in [0, P).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BX_HD __host__ __device__ __forceinline__
+#else
+#define BX_HD inline
+#endif
+
+namespace bx {
+
+constexpr uint32_t P = 2013265921u;      // 15 * 2^27 + 1
+constexpr uint32_t P_INV = 0x88000001u;  // P^-1 mod 2^32  (= 2^31 + 2^27 + 1)
+constexpr uint32_t R2 = 1172168163u;     // 2^64 mod P
+constexpr uint32_t MONT_ONE = 268435454u;  // 2^32 mod P
+
+BX_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// a + b mod P for canonical inputs: s < 2P < 2^32; s - P wraps above s exactly when s < P.
+BX_HD uint32_t fp_add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    return umin(s, s - P);
+}
+// a - b mod P: d wraps above P exactly when a < b, and then d + P wraps back into [0, P).
+BX_HD uint32_t fp_sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return umin(d, d + P);
+}
+BX_HD uint32_t fp_neg(uint32_t a) { return fp_sub(0u, a); }
+BX_HD uint32_t fp_dbl(uint32_t a) { return fp_add(a, a); }
+
+// Montgomery product a*b*2^-32 mod P, canonical.  With t = lo(ab)*P^-1 mod 2^32 the low words of ab and t*P
+// agree, so (ab - tP)/2^32 = hi(ab) - hi(tP) exactly, in (-P, P).  lo*P_INV is two shift-adds on the VALU
+// (P_INV = 2^31 + 2^27 + 1) instead of a quarter-rate 32-bit multiply.
+BX_HD uint32_t fp_mul(uint32_t a, uint32_t b) {
+    uint64_t ab = (uint64_t)a * (uint64_t)b;
+    uint32_t lo = (uint32_t)ab, hi = (uint32_t)(ab >> 32);
+    uint32_t t = lo + (lo << 27) + (lo << 31);
+    uint32_t u = (uint32_t)(((uint64_t)t * (uint64_t)P) >> 32);
+    uint32_t d = hi - u;
+    return umin(d, d + P);
+}
+BX_HD uint32_t fp_sqr(uint32_t a) { return fp_mul(a, a); }
+BX_HD uint32_t fp_encode(uint32_t canonical) { return fp_mul(R2, canonical % P); }
+BX_HD uint32_t fp_decode(uint32_t mont) { return fp_mul(1u, mont); }
+BX_HD uint32_t fp_pow(uint32_t a, uint64_t e) {
+    uint32_t r = MONT_ONE;
+    while (e) {
+        if (e & 1) r = fp_mul(r, a);
+        a = fp_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+BX_HD uint32_t fp_inv(uint32_t a) { return fp_pow(a, (uint64_t)P - 2); }
+
+// Montgomery forms of a few small constants (checked against fp_encode at ctx init, hal.hip).
+constexpr uint32_t MONT_NBETA = 1073741848u;  // encode(P - 11)
+constexpr uint32_t MONT_BETA = 939524073u;    // encode(11)
+constexpr uint32_t MONT_THREE = 805306362u;   // encode(3)
+
+// Fp4 = Fp[X]/(X^4 + 11), AoS.
+struct Fp4 {
+    uint32_t c[4];
+};
+BX_HD Fp4 f4_zero() { return Fp4{{0u, 0u, 0u, 0u}}; }
+BX_HD Fp4 f4_one() { return Fp4{{MONT_ONE, 0u, 0u, 0u}}; }
+BX_HD Fp4 f4_add(const Fp4& a, const Fp4& b) {
+    return Fp4{{fp_add(a.c[0], b.c[0]), fp_add(a.c[1], b.c[1]), fp_add(a.c[2], b.c[2]), fp_add(a.c[3], b.c[3])}};
+}
+BX_HD Fp4 f4_sub(const Fp4& a, const Fp4& b) {
+    return Fp4{{fp_sub(a.c[0], b.c[0]), fp_sub(a.c[1], b.c[1]), fp_sub(a.c[2], b.c[2]), fp_sub(a.c[3], b.c[3])}};
+}
+BX_HD Fp4 f4_scale(const Fp4& a, uint32_t s) {
+    return Fp4{{fp_mul(a.c[0], s), fp_mul(a.c[1], s), fp_mul(a.c[2], s), fp_mul(a.c[3], s)}};
+}
+// [EXT] ExtElem::mul: X^4 = -11 (NBETA = P - 11 in Montgomery form passed as a constant).
+BX_HD Fp4 f4_mul(const Fp4& a, const Fp4& b) {
+    const uint32_t nb = MONT_NBETA;
+    Fp4 r;
+    r.c[0] = fp_add(fp_mul(a.c[0], b.c[0]),
+                    fp_mul(nb, fp_add(fp_add(fp_mul(a.c[1], b.c[3]), fp_mul(a.c[2], b.c[2])), fp_mul(a.c[3], b.c[1]))));
+    r.c[1] = fp_add(fp_add(fp_mul(a.c[0], b.c[1]), fp_mul(a.c[1], b.c[0])),
+                    fp_mul(nb, fp_add(fp_mul(a.c[2], b.c[3]), fp_mul(a.c[3], b.c[2]))));
+    r.c[2] = fp_add(fp_add(fp_add(fp_mul(a.c[0], b.c[2]), fp_mul(a.c[1], b.c[1])), fp_mul(a.c[2], b.c[0])),
+                    fp_mul(nb, fp_mul(a.c[3], b.c[3])));
+    r.c[3] = fp_add(fp_add(fp_add(fp_mul(a.c[0], b.c[3]), fp_mul(a.c[1], b.c[2])), fp_mul(a.c[2], b.c[1])),
+                    fp_mul(a.c[3], b.c[0]));
+    return r;
+}
+BX_HD Fp4 f4_pow(Fp4 a, uint64_t e) {
+    Fp4 r = f4_one();
+    while (e) {
+        if (e & 1) r = f4_mul(r, a);
+        a = f4_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+BX_HD bool f4_is_zero(const Fp4& a) { return (a.c[0] | a.c[1] | a.c[2] | a.c[3]) == 0u; }
+// inverse through the norm to Fp[X^2]/(X^4+11): a(X)a(-X) = b0 + b2 X^2, (b0 + b2 Y)(b0 - b2 Y) = b0^2 + 11 b2^2.
+BX_HD Fp4 f4_inv(const Fp4& a) {
+    const uint32_t beta = MONT_BETA;
+    uint32_t b0 = fp_add(fp_sqr(a.c[0]), fp_mul(beta, fp_sub(fp_mul(fp_dbl(a.c[1]), a.c[3]), fp_sqr(a.c[2]))));
+    uint32_t b2 = fp_add(fp_sub(fp_mul(fp_dbl(a.c[0]), a.c[2]), fp_sqr(a.c[1])), fp_mul(beta, fp_sqr(a.c[3])));
+    uint32_t ic = fp_inv(fp_add(fp_sqr(b0), fp_mul(beta, fp_sqr(b2))));
+    Fp4 an{{a.c[0], fp_neg(a.c[1]), a.c[2], fp_neg(a.c[3])}};
+    Fp4 d{{fp_mul(b0, ic), 0u, fp_neg(fp_mul(b2, ic)), 0u}};
+    return f4_mul(an, d);
+}
+
+BX_HD uint32_t bit_reverse32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+BX_HD uint32_t bit_reverse(uint32_t v, unsigned bits) { return bits ? bit_reverse32(v) >> (32u - bits) : 0u; }
+
+}  // namespace bx

@@ -1,0 +1,242 @@
+// hal.hip — context, memory, timing and profiling entry points of include/bx_hal.h.
+//
+// Counterpart of the device/buffer half of risc0_zkp::hal::Hal (alloc_*, copy_from_*, Buffer::view) that the
+// agent's prover object owns for the process lifetime (bento/crates/workflow/src/lib.rs:192,246-249: one
+// `Rc<dyn ProverServer>` per agent process = one per GPU, compose.yml:113).
+#include <string.h>
+
+#include <string>
+
+#include "ctx.hpp"
+#include "poseidon2_params.hpp"
+
+namespace bx {
+
+static hipEvent_t get_event(bx_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+OpScope::OpScope(bx_ctx* ctx, const char* n, double b) : c(ctx), name(n), bytes(b) {
+    if (!c->profile) return;
+    e0 = get_event(c);
+    e1 = get_event(c);
+    if (e0) (void)hipEventRecord(e0, c->stream);
+}
+OpScope::~OpScope() {
+    if (!c->profile || !e0 || !e1) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->prof_pending.push_back(ProfRec{name, bytes, e0, e1});
+}
+
+static void drain_profile(bx_ctx* c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            ProfAgg& a = c->prof_agg[r.name];
+            a.ms += ms;
+            a.bytes += r.bytes;
+            a.calls += 1;
+        }
+        c->event_pool.push_back(r.e0);
+        c->event_pool.push_back(r.e1);
+    }
+    c->prof_pending.clear();
+}
+
+}  // namespace bx
+
+using namespace bx;
+
+extern "C" const char* bx_init(int device, bx_ctx** out) {
+    if (!out) return "bx_init: null out pointer";
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return "bx_init: no HIP device visible (the HIP HAL has no CPU fallback)";
+    if (device < 0 || device >= n) return "bx_init: device index out of range";
+    if (hipSetDevice(device) != hipSuccess) return "bx_init: hipSetDevice failed";
+    bx_ctx* c = new (std::nothrow) bx_ctx();
+    if (!c) return "bx_init: out of host memory";
+    c->device = device;
+    c->err[0] = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return "bx_init: hipStreamCreate failed";
+    }
+    c->stream = c->own_stream;
+    if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+        delete c;
+        return "bx_init: hipEventCreate failed";
+    }
+    // constants sanity (fp.hpp literals vs. computed)
+    if (fp_encode(1u) != MONT_ONE || fp_encode(P - 11u) != MONT_NBETA || fp_encode(11u) != MONT_BETA ||
+        fp_encode(3u) != MONT_THREE) {
+        delete c;
+        return "bx_init: field constant self-check failed";
+    }
+    static char init_err[512];
+    const char* m = ntt_init_tables(c);
+    if (!m) {
+        for (int i = 0; i < 213; ++i) c->h_rc[i] = POSEIDON2_RC[i];
+        for (int i = 0; i < 24; ++i) c->h_diag[i] = POSEIDON2_DIAG[i];
+        m = poseidon2_upload_params(c);
+    }
+    if (m) {
+        snprintf(init_err, sizeof init_err, "bx_init: %s", m);
+        bx_free(c);
+        return init_err;
+    }
+    *out = c;
+    return nullptr;
+}
+
+extern "C" const char* bx_free(bx_ctx* c) {
+    if (!c) return nullptr;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_profile(c);
+    ntt_free_tables(c);
+    if (c->d_p2) (void)hipFree(c->d_p2);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+}
+
+extern "C" const char* bx_device_name(bx_ctx* c, char* out, size_t cap) {
+    if (!c) return "bx_device_name: null ctx";
+    hipDeviceProp_t prop;
+    BX_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    snprintf(out, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return nullptr;
+}
+
+extern "C" const char* bx_set_stream(bx_ctx* c, void* s) {
+    if (!c) return "bx_set_stream: null ctx";
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return nullptr;
+}
+extern "C" void* bx_get_stream(bx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) {
+    if (!c) return "bx_alloc: null ctx";
+    BX_REQUIRE(c, out != nullptr, "bx_alloc: null out");
+    BX_HIP(c, hipSetDevice(c->device));
+    void* p = nullptr;
+    BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
+    out->dptr = p;
+    out->len = words;
+    return nullptr;
+}
+extern "C" const char* bx_release(bx_ctx* c, bx_buf b) {
+    if (!c) return "bx_release: null ctx";
+    if (!b.dptr) return nullptr;
+    BX_HIP(c, hipSetDevice(c->device));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_HIP(c, hipFree(b.dptr));
+    return nullptr;
+}
+extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
+    if (!c) return "bx_h2d: null ctx";
+    BX_REQUIRE(c, words <= dst.len, "bx_h2d: copy larger than the buffer");
+    BX_HIP(c, hipSetDevice(c->device));
+    BX_HIP(c, hipMemcpyAsync(dst.dptr, src, words * 4, hipMemcpyHostToDevice, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));  // src may be pageable and freed by the caller right after
+    return nullptr;
+}
+extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words) {
+    if (!c) return "bx_d2h: null ctx";
+    BX_REQUIRE(c, words <= src.len, "bx_d2h: copy larger than the buffer");
+    BX_HIP(c, hipSetDevice(c->device));
+    BX_HIP(c, hipMemcpyAsync(dst, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) {
+    if (!c) return "bx_d2d: null ctx";
+    BX_REQUIRE(c, words <= src.len && words <= dst.len, "bx_d2d: copy larger than a buffer");
+    BX_HIP(c, hipSetDevice(c->device));
+    BX_HIP(c, hipMemcpyAsync(dst.dptr, src.dptr, words * 4, hipMemcpyDeviceToDevice, c->stream));
+    return nullptr;
+}
+extern "C" const char* bx_sync(bx_ctx* c) {
+    if (!c) return "bx_sync: null ctx";
+    BX_HIP(c, hipSetDevice(c->device));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+
+extern "C" const char* bx_timer_start(bx_ctx* c) {
+    if (!c) return "bx_timer_start: null ctx";
+    BX_HIP(c, hipEventRecord(c->t0, c->stream));
+    return nullptr;
+}
+extern "C" const char* bx_timer_stop(bx_ctx* c, float* ms) {
+    if (!c) return "bx_timer_stop: null ctx";
+    BX_HIP(c, hipEventRecord(c->t1, c->stream));
+    BX_HIP(c, hipEventSynchronize(c->t1));
+    BX_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return nullptr;
+}
+
+extern "C" const char* bx_profile_enable(bx_ctx* c, int on) {
+    if (!c) return "bx_profile_enable: null ctx";
+    if (!on) drain_profile(c);
+    c->profile = on != 0;
+    return nullptr;
+}
+extern "C" const char* bx_profile_reset(bx_ctx* c) {
+    if (!c) return "bx_profile_reset: null ctx";
+    drain_profile(c);
+    c->prof_agg.clear();
+    return nullptr;
+}
+extern "C" const char* bx_profile_report(bx_ctx* c, char* out, size_t cap) {
+    if (!c) return "bx_profile_report: null ctx";
+    drain_profile(c);
+    std::string s = "{";
+    bool first = true;
+    char line[256];
+    for (auto& kv : c->prof_agg) {
+        snprintf(line, sizeof line, "%s\"%s\":{\"calls\":%ld,\"ms\":%.6f,\"alg_bytes\":%.0f}", first ? "" : ",", kv.first.c_str(),
+                 kv.second.calls, kv.second.ms, kv.second.bytes);
+        s += line;
+        first = false;
+    }
+    s += "}";
+    BX_REQUIRE(c, s.size() + 1 <= cap, "bx_profile_report: output buffer too small");
+    memcpy(out, s.c_str(), s.size() + 1);
+    return nullptr;
+}
+
+extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
+    if (!c) return "bx_set_tunable: null ctx";
+    BX_REQUIRE(c, name != nullptr, "bx_set_tunable: null name");
+    if (!strcmp(name, "ntt_block_log")) {
+        BX_REQUIRE(c, value >= 1 && value <= TW_LOG, "ntt_block_log out of range [1,13]");
+        c->ntt_block_log = value;
+    } else if (!strcmp(name, "ntt_tile_log")) {
+        BX_REQUIRE(c, value >= 6 && value <= 15, "ntt_tile_log out of range [6,15]");
+        c->ntt_tile_log = value;
+    } else if (!strcmp(name, "hash_rows_block")) {
+        BX_REQUIRE(c, value == 64 || value == 128 || value == 256, "hash_rows_block must be 64, 128 or 256");
+        c->hash_rows_block = value;
+    } else {
+        return set_msg(c, "bx_set_tunable: unknown tunable");
+    }
+    return nullptr;
+}

@@ -1,0 +1,405 @@
+// ntt.hip — batched radix-2 NTT / LDE over BabyBear for gfx950 (column-major, one polynomial per column).
+//
+// Entry points restate risc0_zkp::hal::Hal::{batch_interpolate_ntt, batch_evaluate_ntt,
+// batch_expand_into_evaluate_ntt, batch_bit_reverse, zk_shift} (risc0-zkp 3.0.3, reference Cargo.lock:9155),
+// reached from bento/crates/workflow/src/tasks/prove.rs:41-49.  The upstream CPU code is a recursive
+// radix-2 DIF/DIT; the arithmetic is exact, so any factorisation of the same DFT gives identical words.
+//
+// MI355X design: a size-2^m transform is factored "four-step" as 2^m = 2^m_hi * 2^m_lo.
+//   pass A  (ntt_block_kernel)   : 2^m_lo contiguous blocks of 2^m_hi elements, each transformed entirely in LDS
+//                                  with perfectly coalesced loads/stores; the inter-pass twist w_M^(j_lo*k2)
+//                                  (and the 1/M scale for the inverse) comes from a precomputed table that is
+//                                  streamed in the same order as the data.
+//   pass B  (ntt_strided_kernel) : 2^m_lo-point transforms across the blocks (stride 2^m_hi), T adjacent
+//                                  positions per workgroup so every row access is a T*4-byte contiguous segment.
+// Forward (evaluate) = A then B, bit-reversed coefficients -> natural evaluations; the zero-padding "expand" is
+// folded into pass A's load (out[i] = in[i >> bits]; the first `bits` stages are skipped exactly like upstream).
+// Inverse (interpolate) = B then A.  Each pass moves every element HBM->LDS->HBM once: 2 reads + 2 writes per
+// element for m <= 26 instead of m reads/writes.  Sizes with m <= m_hi need pass A only.
+#include "ctx.hpp"
+
+namespace bx {
+
+// ---------------------------------------------------------------------------------------------------------
+// in-LDS radix-2 stages over `rows` = 2^lr points laid out with a unit of `T` = 2^lt adjacent lanes:
+// element (r, t) lives at s[r*T + t].  ltw is the stage table (ltw[half + e] = w_{2*half}^e).
+// ---------------------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void lds_stages(uint32_t* __restrict__ s, const uint32_t* __restrict__ ltw, int lr, int lt,
+                                           int first_stage, int tid, int nthreads) {
+    const uint32_t bfly = 1u << (lr - 1 + lt);
+    const uint32_t tmask = (1u << lt) - 1u;
+    if (!INV) {
+        for (int stage = first_stage; stage <= lr; ++stage) {
+            const uint32_t half = 1u << (stage - 1);
+            for (uint32_t x = tid; x < bfly; x += nthreads) {
+                uint32_t t = x & tmask, q = x >> lt;
+                uint32_t lo = q & (half - 1u);
+                uint32_t i = (((q - lo) << 1) | lo);
+                uint32_t ia = (i << lt) | t, ib = ((i + half) << lt) | t;
+                uint32_t a = s[ia];
+                uint32_t b = fp_mul(s[ib], ltw[half + lo]);
+                s[ia] = fp_add(a, b);
+                s[ib] = fp_sub(a, b);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int stage = lr; stage >= 1; --stage) {
+            const uint32_t half = 1u << (stage - 1);
+            for (uint32_t x = tid; x < bfly; x += nthreads) {
+                uint32_t t = x & tmask, q = x >> lt;
+                uint32_t lo = q & (half - 1u);
+                uint32_t i = (((q - lo) << 1) | lo);
+                uint32_t ia = (i << lt) | t, ib = ((i + half) << lt) | t;
+                uint32_t a = s[ia], b = s[ib];
+                s[ia] = fp_add(a, b);
+                s[ib] = fp_mul(fp_sub(a, b), ltw[half + lo]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// pass A: one workgroup per (block, column).  LDS = data[R] + stage table[R].
+template <bool INV>
+__global__ void ntt_block_kernel(uint32_t* out, const uint32_t* in,  // may alias (in-place): no __restrict__
+                                 const uint32_t* __restrict__ tw, const uint32_t* __restrict__ twist, uint32_t scale,
+                                 int lr, int expand_bits, int first_stage, size_t in_col_stride, size_t out_col_stride) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t R = 1u << lr;
+    uint32_t* s = lds;
+    uint32_t* ltw = lds + R;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t block = blockIdx.x, col = blockIdx.y;
+    const uint32_t* src = in + col * in_col_stride + ((block << lr) >> expand_bits);
+    uint32_t* dst = out + col * out_col_stride + (block << lr);
+    const uint32_t* twb = twist ? twist + (block << lr) : nullptr;
+
+    for (uint32_t i = tid; i < R; i += nt) ltw[i] = tw[i];
+    if (!INV) {
+        for (uint32_t i = tid; i < R; i += nt) s[i] = src[i >> expand_bits];
+        __syncthreads();
+        lds_stages<false>(s, ltw, lr, 0, first_stage, tid, nt);
+        if (twb) {
+            for (uint32_t i = tid; i < R; i += nt) dst[i] = fp_mul(s[i], twb[i]);
+        } else {
+            for (uint32_t i = tid; i < R; i += nt) dst[i] = s[i];
+        }
+    } else {
+        if (twb) {
+            for (uint32_t i = tid; i < R; i += nt) s[i] = fp_mul(src[i], twb[i]);
+        } else {
+            for (uint32_t i = tid; i < R; i += nt) s[i] = fp_mul(src[i], scale);
+        }
+        __syncthreads();
+        lds_stages<true>(s, ltw, lr, 0, 1, tid, nt);
+        for (uint32_t i = tid; i < R; i += nt) dst[i] = s[i];
+    }
+}
+
+// pass B: one workgroup per (tile of T adjacent positions, column); rows are 2^m_hi apart.  In place.
+// `tile_swz`: blockIdx.x -> tile remap so that tiles sharing a 128-byte line run on the same XCD (block b is
+// observed on XCD b % 8; a performance hint only).
+template <bool INV>
+__global__ void ntt_strided_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ tw, int lr, int lt, int m_hi,
+                                   size_t col_stride, uint32_t tiles) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t rows = 1u << lr, T = 1u << lt;
+    uint32_t* s = lds;
+    uint32_t* ltw = lds + (rows << lt);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    uint32_t b = blockIdx.x;
+    uint32_t tile = (tiles % 8u == 0u) ? (b % 8u) * (tiles / 8u) + b / 8u : b;
+    uint32_t* base = io + (size_t)blockIdx.y * col_stride + ((size_t)tile << lt);
+    const uint32_t total = rows << lt, tmask = T - 1u;
+
+    for (uint32_t i = tid; i < rows; i += nt) ltw[i] = tw[i];
+    for (uint32_t e = tid; e < total; e += nt) s[e] = base[((size_t)(e >> lt) << m_hi) + (e & tmask)];
+    __syncthreads();
+    lds_stages<INV>(s, ltw, lr, lt, 1, tid, nt);
+    for (uint32_t e = tid; e < total; e += nt) base[((size_t)(e >> lt) << m_hi) + (e & tmask)] = s[e];
+}
+
+// twist[b*2^m_hi + i] = w_M^(+-rev_{m_lo}(b) * i) (* 1/M for the inverse)
+__global__ void twist_build_kernel(uint32_t* __restrict__ out, uint32_t root, uint32_t scale, int m, int m_hi) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ((size_t)1 << m)) return;
+    uint32_t b = (uint32_t)(p >> m_hi), i = (uint32_t)(p & (((size_t)1 << m_hi) - 1));
+    uint64_t e = ((uint64_t)bit_reverse(b, m - m_hi) * i) & (((uint64_t)1 << m) - 1);
+    out[p] = fp_mul(fp_pow(root, e), scale);
+}
+
+__global__ void zk_tab_kernel(uint32_t* __restrict__ lo, uint32_t* __restrict__ hi, int n, int lo_bits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1u << lo_bits)) lo[i] = fp_pow(MONT_THREE, (uint64_t)bit_reverse(i, lo_bits) << (n - lo_bits));
+    if (i < (1u << (n - lo_bits))) hi[i] = fp_pow(MONT_THREE, bit_reverse(i, n - lo_bits));
+}
+__global__ void zk_shift_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                int n, int lo_bits, size_t total) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        uint32_t pos = (uint32_t)(i & (((size_t)1 << n) - 1));
+        uint32_t f = fp_mul(lo[pos & ((1u << lo_bits) - 1u)], hi[pos >> lo_bits]);
+        io[i] = fp_mul(io[i], f);
+    }
+}
+__global__ void bit_reverse_kernel(uint32_t* __restrict__ io, int n, size_t total) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        uint32_t i = (uint32_t)(g & (((size_t)1 << n) - 1));
+        uint32_t r = bit_reverse(i, n);
+        if (i < r) {
+            size_t base = g - i;
+            uint32_t a = io[base + i], b = io[base + r];
+            io[base + i] = b;
+            io[base + r] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+const char* ntt_init_tables(bx_ctx* c) {
+    const size_t n = (size_t)1 << TW_LOG;
+    std::vector<uint32_t> f(n, 0), r(n, 0);
+    uint32_t rou[28], rev[28];
+    rou[27] = fp_encode(137u);
+    for (int k = 26; k >= 0; --k) rou[k] = fp_mul(rou[k + 1], rou[k + 1]);
+    for (int k = 0; k < 28; ++k) rev[k] = fp_inv(rou[k]);
+    for (int s = 1; s <= TW_LOG; ++s) {
+        size_t half = (size_t)1 << (s - 1);
+        uint32_t cf = MONT_ONE, cr = MONT_ONE;
+        for (size_t e = 0; e < half; ++e) {
+            f[half + e] = cf;
+            r[half + e] = cr;
+            cf = fp_mul(cf, rou[s]);
+            cr = fp_mul(cr, rev[s]);
+        }
+    }
+    BX_HIP(c, hipMalloc(&c->d_tw_fwd, n * 4));
+    BX_HIP(c, hipMalloc(&c->d_tw_inv, n * 4));
+    BX_HIP(c, hipMemcpy(c->d_tw_fwd, f.data(), n * 4, hipMemcpyHostToDevice));
+    BX_HIP(c, hipMemcpy(c->d_tw_inv, r.data(), n * 4, hipMemcpyHostToDevice));
+    return nullptr;
+}
+void ntt_free_tables(bx_ctx* c) {
+    if (c->d_tw_fwd) (void)hipFree(c->d_tw_fwd);
+    if (c->d_tw_inv) (void)hipFree(c->d_tw_inv);
+    for (auto& kv : c->twist) (void)hipFree(kv.second);
+    for (auto& kv : c->zk) {
+        (void)hipFree(kv.second.lo);
+        (void)hipFree(kv.second.hi);
+    }
+    c->twist.clear();
+    c->zk.clear();
+}
+
+static const char* get_twist(bx_ctx* c, int m, int m_hi, bool inverse, uint32_t** out) {
+    TwistKey key{m, m_hi, inverse ? 1 : 0};
+    auto it = c->twist.find(key);
+    if (it != c->twist.end()) {
+        *out = it->second;
+        return nullptr;
+    }
+    uint32_t* d = nullptr;
+    size_t M = (size_t)1 << m;
+    BX_HIP(c, hipMalloc(&d, M * 4));
+    uint32_t root = fp_pow(fp_encode(137u), (uint64_t)1 << (27 - m));  // w_M
+    uint32_t scale = MONT_ONE;
+    if (inverse) {
+        root = fp_inv(root);
+        scale = fp_inv(fp_encode((uint32_t)M));
+    }
+    hipLaunchKernelGGL(twist_build_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, d, root, scale, m,
+                       m_hi);
+    BX_LAUNCH_CHECK(c);
+    c->twist[key] = d;
+    *out = d;
+    return nullptr;
+}
+
+struct Split {
+    int m_hi, m_lo, lt;
+};
+static Split choose_split(bx_ctx* c, int m) {
+    Split sp;
+    int blk = (int)c->ntt_block_log;
+    if (blk > TW_LOG) blk = TW_LOG;
+    if (m <= blk) {
+        sp.m_hi = m;
+        sp.m_lo = 0;
+        sp.lt = 0;
+        return sp;
+    }
+    sp.m_hi = blk;
+    sp.m_lo = m - blk;
+    if (sp.m_lo > TW_LOG) {  // > 2^26: not reachable for BabyBear segment sizes, guarded by the callers
+        sp.m_lo = TW_LOG;
+        sp.m_hi = m - TW_LOG;
+    }
+    int tile = (int)c->ntt_tile_log;
+    if (tile < sp.m_lo) tile = sp.m_lo;
+    sp.lt = tile - sp.m_lo;
+    if (sp.lt > sp.m_hi) sp.lt = sp.m_hi;
+    return sp;
+}
+
+template <typename K>
+static const char* allow_lds(bx_ctx* c, K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) BX_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return nullptr;
+}
+
+// forward transform of `count` columns: in (size M >> expand_bits per column) -> out (size M per column).
+// `expand_bits` = load shift (out[i] = in[i >> bits]); `skip_bits` = leading stages skipped (== expand_bits for the
+// expanding form, and for the in-place Hal::batch_evaluate_ntt(io, count, expand_bits) with no load shift).
+static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t count, int m, int expand_bits,
+                           int skip_bits) {
+    if (m == 0 || count == 0) {
+        if (out != in) BX_HIP(c, hipMemcpyAsync(out, in, count * 4, hipMemcpyDeviceToDevice, c->stream));
+        return nullptr;
+    }
+    Split sp = choose_split(c, m);
+    BX_REQUIRE(c, sp.m_hi <= TW_LOG && sp.m_lo <= TW_LOG, "ntt: size too large");
+    BX_REQUIRE(c, expand_bits <= sp.m_hi && skip_bits <= sp.m_hi, "ntt: expand_bits larger than the block pass");
+    size_t M = (size_t)1 << m;
+    uint32_t* twist = nullptr;
+    if (sp.m_lo) BX_TRY(get_twist(c, m, sp.m_hi, false, &twist));
+    {
+        unsigned R = 1u << sp.m_hi;
+        unsigned threads = R / 2 < 64 ? 64 : (R / 2 > 256 ? 256 : R / 2);
+        size_t lds = (size_t)R * 8;
+        BX_TRY(allow_lds(c, ntt_block_kernel<false>, lds));
+        hipLaunchKernelGGL(ntt_block_kernel<false>, dim3(1u << sp.m_lo, (unsigned)count), dim3(threads), lds, c->stream, out,
+                           in, c->d_tw_fwd, twist, MONT_ONE, sp.m_hi, expand_bits, skip_bits + 1, M >> expand_bits, M);
+        BX_LAUNCH_CHECK(c);
+    }
+    if (sp.m_lo) {
+        unsigned rows = 1u << sp.m_lo;
+        unsigned total = rows << sp.lt;
+        unsigned threads = total / 2 > 1024 ? 1024 : (total / 2 < 64 ? 64 : total / 2);
+        if (threads > 512 && total <= 8192) threads = 512;
+        size_t lds = (size_t)total * 4 + (size_t)rows * 4;
+        BX_TRY(allow_lds(c, ntt_strided_kernel<false>, lds));
+        unsigned tiles = 1u << (sp.m_hi - sp.lt);
+        hipLaunchKernelGGL(ntt_strided_kernel<false>, dim3(tiles, (unsigned)count), dim3(threads), lds, c->stream, out,
+                           c->d_tw_fwd, sp.m_lo, sp.lt, sp.m_hi, M, tiles);
+        BX_LAUNCH_CHECK(c);
+    }
+    return nullptr;
+}
+
+static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m) {
+    if (m == 0 || count == 0) return nullptr;
+    Split sp = choose_split(c, m);
+    BX_REQUIRE(c, sp.m_hi <= TW_LOG && sp.m_lo <= TW_LOG, "ntt: size too large");
+    size_t M = (size_t)1 << m;
+    uint32_t* twist = nullptr;
+    if (sp.m_lo) {
+        BX_TRY(get_twist(c, m, sp.m_hi, true, &twist));
+        unsigned rows = 1u << sp.m_lo;
+        unsigned total = rows << sp.lt;
+        unsigned threads = total / 2 > 1024 ? 1024 : (total / 2 < 64 ? 64 : total / 2);
+        if (threads > 512 && total <= 8192) threads = 512;
+        size_t lds = (size_t)total * 4 + (size_t)rows * 4;
+        BX_TRY(allow_lds(c, ntt_strided_kernel<true>, lds));
+        unsigned tiles = 1u << (sp.m_hi - sp.lt);
+        hipLaunchKernelGGL(ntt_strided_kernel<true>, dim3(tiles, (unsigned)count), dim3(threads), lds, c->stream, io,
+                           c->d_tw_inv, sp.m_lo, sp.lt, sp.m_hi, M, tiles);
+        BX_LAUNCH_CHECK(c);
+    }
+    {
+        unsigned R = 1u << sp.m_hi;
+        unsigned threads = R / 2 < 64 ? 64 : (R / 2 > 256 ? 256 : R / 2);
+        size_t lds = (size_t)R * 8;
+        uint32_t scale = fp_inv(fp_encode((uint32_t)M));
+        BX_TRY(allow_lds(c, ntt_block_kernel<true>, lds));
+        hipLaunchKernelGGL(ntt_block_kernel<true>, dim3(1u << sp.m_lo, (unsigned)count), dim3(threads), lds, c->stream, io,
+                           io, c->d_tw_inv, twist, scale, sp.m_hi, 0, 1, M, M);
+        BX_LAUNCH_CHECK(c);
+    }
+    return nullptr;
+}
+
+static const char* get_zk(bx_ctx* c, int n, ZkTab* out) {
+    auto it = c->zk.find(n);
+    if (it != c->zk.end()) {
+        *out = it->second;
+        return nullptr;
+    }
+    ZkTab t;
+    t.lo_bits = (n + 1) / 2;
+    size_t nlo = (size_t)1 << t.lo_bits, nhi = (size_t)1 << (n - t.lo_bits);
+    BX_HIP(c, hipMalloc(&t.lo, nlo * 4));
+    BX_HIP(c, hipMalloc(&t.hi, nhi * 4));
+    hipLaunchKernelGGL(zk_tab_kernel, dim3((unsigned)((nlo + 255) / 256)), dim3(256), 0, c->stream, t.lo, t.hi, n, t.lo_bits);
+    BX_LAUNCH_CHECK(c);
+    c->zk[n] = t;
+    *out = t;
+    return nullptr;
+}
+
+}  // namespace bx
+
+using namespace bx;
+
+extern "C" const char* bx_batch_interpolate_ntt(bx_ctx* c, bx_buf io, size_t count) {
+    if (!c) return "bx_batch_interpolate_ntt: null ctx";
+    BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_ntt: io.len/count must be a power of two");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_interpolate_ntt", 8.0 * (double)io.len);
+    return inverse(c, (uint32_t*)io.dptr, count, ilog2(io.len / count));
+}
+
+extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count, size_t expand_bits) {
+    if (!c) return "bx_batch_evaluate_ntt: null ctx";
+    BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_evaluate_ntt: io.len/count must be a power of two");
+    int m = ilog2(io.len / count);
+    BX_REQUIRE(c, (int)expand_bits <= m, "batch_evaluate_ntt: expand_bits > log2(size)");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_evaluate_ntt", 8.0 * (double)io.len);
+    return forward(c, (uint32_t*)io.dptr, (const uint32_t*)io.dptr, count, m, 0, (int)expand_bits);
+}
+
+extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, bx_buf in, size_t count, size_t expand_bits) {
+    if (!c) return "bx_batch_expand_into_evaluate_ntt: null ctx";
+    BX_REQUIRE(c, count > 0 && in.len % count == 0 && is_pow2(in.len / count), "batch_expand_into_evaluate_ntt: in.len/count must be a power of two");
+    BX_REQUIRE(c, out.len == (in.len << expand_bits), "batch_expand_into_evaluate_ntt: out.len != in.len << expand_bits");
+    BX_REQUIRE(c, out.dptr != in.dptr || expand_bits == 0, "batch_expand_into_evaluate_ntt: in-place expansion");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_expand_into_evaluate_ntt", 4.0 * (double)in.len + 4.0 * (double)out.len);
+    int m = ilog2(out.len / count);
+    return forward(c, (uint32_t*)out.dptr, (const uint32_t*)in.dptr, count, m, (int)expand_bits, (int)expand_bits);
+}
+
+extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) {
+    if (!c) return "bx_batch_bit_reverse: null ctx";
+    BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_bit_reverse: io.len/count must be a power of two");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_bit_reverse", 8.0 * (double)io.len);
+    int n = ilog2(io.len / count);
+    if (n == 0) return nullptr;
+    size_t blocks = (io.len + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bit_reverse_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n, io.len);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) {
+    if (!c) return "bx_zk_shift: null ctx";
+    BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "zk_shift: io.len/count must be a power of two");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "zk_shift", 8.0 * (double)io.len);
+    int n = ilog2(io.len / count);
+    ZkTab t;
+    BX_TRY(get_zk(c, n, &t));
+    size_t blocks = (io.len + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(zk_shift_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint32_t*)io.dptr, t.lo, t.hi, n,
+                       t.lo_bits, io.len);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}

@@ -1,0 +1,363 @@
+// poly.hip — FRI fold, DEEP mixing/evaluation/division and element-wise helpers for gfx950.
+//
+// Restates risc0_zkp::hal::Hal::{fri_fold, mix_poly_coeffs, batch_evaluate_any, eltwise_*, gather_sample} and
+// risc0_zkp::core::poly::poly_divide (risc0-zkp 3.0.3, reference Cargo.lock:9155), reached from
+// bento/crates/workflow/src/tasks/prove.rs:41-49 through Prover::finalize / fri_prove.
+// All of these stream each input word once; they are HBM-bound except batch_evaluate_any and
+// poly_divide, whose Fp4 products make them VALU-bound.
+#include "ctx.hpp"
+
+namespace bx {
+
+__device__ __forceinline__ Fp4 ld4(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return Fp4{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void st4(uint32_t* p, const Fp4& a) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(a.c[0], a.c[1], a.c[2], a.c[3]);
+}
+
+// ---- fri_fold: out[k*count + idx] = sum_i mix^i * in[(k*16 + rev4(i))*count + idx] ----
+__global__ __launch_bounds__(256) void fri_fold_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, Fp4 mix,
+                                                       size_t count) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    // Horner from the highest power keeps one running product: tot = (((f15*mix + f14)*mix + ...)*mix + f0
+    Fp4 tot = f4_zero();
+#pragma unroll
+    for (int i = BX_FRI_FOLD - 1; i >= 0; --i) {
+        size_t r = (size_t)bit_reverse((uint32_t)i, 4) * count + idx;
+        Fp4 f{{in[r], in[16 * count + r], in[32 * count + r], in[48 * count + r]}};
+        tot = f4_add(f4_mul(tot, mix), f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k * count + idx] = tot.c[k];
+}
+
+// ---- mix_poly_coeffs ----
+// prep (one workgroup): order[] = polynomial indices grouped by combo, starts[c] = first slot of combo c,
+// pows[i] = mix_start * mix^i.
+__global__ void mix_prep_kernel(const uint32_t* __restrict__ combos, uint32_t input_size, uint32_t n_combos,
+                                uint32_t* __restrict__ order, uint32_t* __restrict__ starts, uint32_t* __restrict__ pows,
+                                Fp4 mix_start, Fp4 mix) {
+    for (uint32_t i = threadIdx.x; i < input_size; i += blockDim.x) st4(pows + 4 * (size_t)i, f4_mul(mix_start, f4_pow(mix, i)));
+    if (threadIdx.x == 0) {
+        uint32_t pos = 0;
+        for (uint32_t c = 0; c < n_combos; ++c) {
+            starts[c] = pos;
+            for (uint32_t i = 0; i < input_size; ++i)
+                if (combos[i] == c) order[pos++] = i;
+        }
+        starts[n_combos] = pos;
+    }
+}
+__global__ __launch_bounds__(256) void mix_poly_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+                                                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ starts,
+                                                       const uint32_t* __restrict__ pows, size_t count) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    uint32_t combo = blockIdx.y;
+    uint32_t lo = starts[combo], hi = starts[combo + 1];
+    if (lo == hi) return;
+    uint32_t* o = out + 4 * ((size_t)combo * count + idx);
+    Fp4 acc = ld4(o);
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t i = order[k];
+        Fp4 w = ld4(pows + 4 * (size_t)i);  // wave-uniform
+        acc = f4_add(acc, f4_scale(w, in[(size_t)i * count + idx]));
+    }
+    st4(o, acc);
+}
+__global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sh[256];
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) m = v[i] > m ? v[i] : m;
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// ---- batch_evaluate_any ----
+// grid = (segments, evals).  A workgroup evaluates SEG = 256*K coefficients of polynomial which[e] at xs[e]:
+//   sum_{t<256} x^t * sum_{i<K} c[seg + t + 256 i] * (x^256)^i,  then scales by x^seg and writes a partial.
+constexpr int EV_K = 32, EV_T = 256;
+__global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __restrict__ coeffs, size_t poly_size,
+                                                            const uint32_t* __restrict__ which, const uint32_t* __restrict__ xs,
+                                                            uint32_t* __restrict__ partials, uint32_t segs) {
+    __shared__ uint32_t ypow[EV_K * 4];
+    __shared__ uint32_t red[EV_T * 4];
+    const uint32_t e = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const Fp4 x = ld4(xs + 4 * (size_t)e);
+    const size_t seg_elems = (size_t)EV_T * EV_K;
+    const size_t base = (size_t)seg * seg_elems;
+    const uint32_t* c = coeffs + (size_t)which[e] * poly_size + base;
+    const size_t remaining = poly_size - base;
+    if (tid < EV_K) st4(ypow + 4 * tid, f4_pow(f4_pow(x, EV_T), tid));
+    __syncthreads();
+    Fp4 acc = f4_zero();
+#pragma unroll 4
+    for (int i = 0; i < EV_K; ++i) {
+        size_t j = (size_t)tid + (size_t)EV_T * i;
+        if (j < remaining) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[j]));
+    }
+    acc = f4_mul(acc, f4_pow(x, tid));
+    st4(red + 4 * tid, acc);
+    __syncthreads();
+    for (int s = EV_T / 2; s > 0; s >>= 1) {
+        if ((int)tid < s) st4(red + 4 * tid, f4_add(ld4(red + 4 * tid), ld4(red + 4 * (tid + s))));
+        __syncthreads();
+    }
+    if (tid == 0) st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(red), f4_pow(x, base)));
+}
+__global__ void eval_final_kernel(const uint32_t* __restrict__ partials, uint32_t segs, uint32_t* __restrict__ out,
+                                  uint32_t evals) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= evals) return;
+    Fp4 acc = f4_zero();
+    for (uint32_t s = 0; s < segs; ++s) acc = f4_add(acc, ld4(partials + 4 * ((size_t)e * segs + s)));
+    st4(out + 4 * (size_t)e, acc);
+}
+
+// ---- element-wise ----
+__global__ void eltwise_add_kernel(uint32_t* __restrict__ out, const uint32_t* a, const uint32_t* b, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fp_add(a[i], b[i]);
+}
+__global__ void eltwise_zeroize_kernel(uint32_t* __restrict__ io, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (io[i] == 0xffffffffu) io[i] = 0u;
+}
+__global__ __launch_bounds__(256) void eltwise_sum_ext_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+                                                              size_t count, size_t to_add) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Fp4 tot = f4_zero();
+    for (size_t j = 0; j < to_add; ++j) tot = f4_add(tot, ld4(in + 4 * (j * count + idx)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k * count + idx] = tot.c[k];
+}
+__global__ void gather_sample_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t idx, size_t size,
+                                     size_t stride) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < size) dst[i] = src[idx + i * stride];
+}
+
+// ---- poly_divide: q_{i-1} = p_i + z q_i (top down), in place; remainder = p_0 + z q_0 ----
+// Three phases over chunks of DIV_L coefficients: (1) each chunk's carry-out assuming zero carry-in,
+// (2) sequential composition of the chunk maps carry -> local + z^L * carry (one workgroup), (3) replay.
+constexpr int DIV_L = 64;
+__global__ void div_local_kernel(const uint32_t* __restrict__ poly, size_t size, Fp4 z, uint32_t* __restrict__ local,
+                                 size_t chunks) {
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= chunks) return;
+    size_t lo = ch * DIV_L, hi = lo + DIV_L < size ? lo + DIV_L : size;
+    Fp4 cur = f4_zero();
+    for (size_t i = hi; i-- > lo;) cur = f4_add(f4_mul(z, cur), ld4(poly + 4 * i));
+    st4(local + 4 * ch, cur);
+}
+// carry_in[ch] = value of `cur` entering chunk ch from above; processed top chunk first.
+__global__ void div_scan_kernel(uint32_t* __restrict__ local_then_carry, size_t chunks, Fp4 zL, uint32_t* __restrict__ rem) {
+    // block-sequential two-level scan: thread t owns a contiguous run of chunks.
+    extern __shared__ uint32_t sh[];  // per-thread aggregate (a = zL^run, b) -> 8 words
+    const uint32_t nt = blockDim.x, tid = threadIdx.x;
+    size_t per = (chunks + nt - 1) / nt;
+    // runs are assigned from the top: thread 0 owns the highest chunks
+    size_t hi = chunks > (size_t)tid * per ? chunks - (size_t)tid * per : 0;
+    size_t lo = hi > per ? hi - per : 0;
+    // aggregate of my run with zero carry-in: b = carry-out below my run, a = zL^(len)
+    Fp4 a = f4_one(), b = f4_zero();
+    for (size_t ch = hi; ch-- > lo;) {
+        b = f4_add(f4_mul(zL, b), ld4(local_then_carry + 4 * ch));
+        a = f4_mul(a, zL);
+    }
+    st4(sh + 8 * tid, a);
+    st4(sh + 8 * tid + 4, b);
+    __syncthreads();
+    if (tid == 0) {
+        Fp4 carry = f4_zero();
+        for (uint32_t t = 0; t < nt; ++t) {
+            Fp4 ta = ld4(sh + 8 * t), tb = ld4(sh + 8 * t + 4);
+            st4(sh + 8 * t, carry);  // carry entering thread t's run
+            carry = f4_add(f4_mul(ta, carry), tb);
+        }
+        st4(rem, carry);  // after the lowest chunk: remainder
+    }
+    __syncthreads();
+    Fp4 carry = ld4(sh + 8 * tid);
+    for (size_t ch = hi; ch-- > lo;) {
+        Fp4 l = ld4(local_then_carry + 4 * ch);
+        st4(local_then_carry + 4 * ch, carry);
+        carry = f4_add(f4_mul(zL, carry), l);
+    }
+}
+__global__ void div_apply_kernel(uint32_t* __restrict__ poly, size_t size, Fp4 z, const uint32_t* __restrict__ carry_in,
+                                 size_t chunks) {
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= chunks) return;
+    size_t lo = ch * DIV_L, hi = lo + DIV_L < size ? lo + DIV_L : size;
+    Fp4 cur = ld4(carry_in + 4 * ch);
+    for (size_t i = hi; i-- > lo;) {
+        Fp4 next = f4_add(f4_mul(z, cur), ld4(poly + 4 * i));
+        st4(poly + 4 * i, cur);
+        cur = next;
+    }
+}
+
+const char* ensure_scratch(bx_ctx* c, size_t words) {
+    if (c->scratch_words >= words) return nullptr;
+    if (c->d_scratch) {
+        BX_HIP(c, hipStreamSynchronize(c->stream));
+        BX_HIP(c, hipFree(c->d_scratch));
+        c->d_scratch = nullptr;
+        c->scratch_words = 0;
+    }
+    size_t want = words < (1u << 20) ? (1u << 20) : words;
+    BX_HIP(c, hipMalloc(&c->d_scratch, want * 4));
+    c->scratch_words = want;
+    return nullptr;
+}
+
+}  // namespace bx
+
+using namespace bx;
+
+static inline Fp4 host4(const uint32_t* w) { return Fp4{{w[0], w[1], w[2], w[3]}}; }
+static inline unsigned grid1d(size_t n, unsigned bs = 256, size_t cap = 65536) {
+    size_t b = (n + bs - 1) / bs;
+    return (unsigned)(b > cap ? cap : (b ? b : 1));
+}
+
+extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint32_t mix[4]) {
+    if (!c) return "bx_fri_fold: null ctx";
+    BX_REQUIRE(c, out.len % 4 == 0 && in.len == out.len * BX_FRI_FOLD, "fri_fold: input.len must be 16 * output.len");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t count = out.len / 4;
+    OpScope op(c, "fri_fold", 4.0 * (double)(in.len + out.len));
+    if (!count) return nullptr;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
+                       (const uint32_t*)in.dptr, host4(mix), count);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t mix_start[4], const uint32_t mix[4], bx_buf in,
+                                          bx_buf combos, size_t input_size, size_t count) {
+    if (!c) return "bx_mix_poly_coeffs: null ctx";
+    BX_REQUIRE(c, in.len >= input_size * count && combos.len >= input_size, "mix_poly_coeffs: input/combos too small");
+    BX_REQUIRE(c, count > 0 && out.len % (4 * count) == 0, "mix_poly_coeffs: out.len not a multiple of 4*count");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!input_size) return nullptr;
+    size_t n_combos = out.len / (4 * count);
+    OpScope op(c, "mix_poly_coeffs", 4.0 * (double)(input_size * count) + 32.0 * (double)out.len / 4.0);
+    // scratch: order[input_size] | starts[n_combos+1] | pows[4*input_size] (16B aligned first)
+    size_t pows_off = 0, order_off = 4 * input_size, starts_off = order_off + input_size;
+    BX_TRY(ensure_scratch(c, starts_off + n_combos + 8));
+    uint32_t* s = c->d_scratch;
+    hipLaunchKernelGGL(mix_prep_kernel, dim3(1), dim3(256), 0, c->stream, (const uint32_t*)combos.dptr, (uint32_t)input_size,
+                       (uint32_t)n_combos, s + order_off, s + starts_off, s + pows_off, host4(mix_start), host4(mix));
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(mix_poly_kernel, dim3((unsigned)((count + 255) / 256), (unsigned)n_combos), dim3(256), 0, c->stream,
+                       (uint32_t*)out.dptr, (const uint32_t*)in.dptr, s + order_off, s + starts_off, s + pows_off, count);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
+    if (!c) return "bx_batch_evaluate_any: null ctx";
+    BX_REQUIRE(c, poly_count > 0 && coeffs.len % poly_count == 0, "batch_evaluate_any: coeffs.len not a multiple of poly_count");
+    size_t evals = which.len;
+    BX_REQUIRE(c, xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_any: xs/out must hold one ext elem per eval");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t poly_size = coeffs.len / poly_count;
+    OpScope op(c, "batch_evaluate_any", 4.0 * (double)(poly_size * evals));
+    if (!evals) return nullptr;
+    size_t seg_elems = (size_t)EV_T * EV_K;
+    size_t segs = (poly_size + seg_elems - 1) / seg_elems;
+    BX_REQUIRE(c, evals <= 65535, "batch_evaluate_any: more than 65535 evaluations in one call");
+    BX_TRY(ensure_scratch(c, 4 * evals * segs));
+    hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
+                       (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)xs.dptr,
+                       c->d_scratch, (uint32_t)segs);
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(eval_final_kernel, dim3((unsigned)((evals + 63) / 64)), dim3(64), 0, c->stream, c->d_scratch,
+                       (uint32_t)segs, (uint32_t*)out.dptr, (uint32_t)evals);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) {
+    if (!c) return "bx_eltwise_add_elem: null ctx";
+    BX_REQUIRE(c, out.len == a.len && a.len == b.len, "eltwise_add_elem: length mismatch");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "eltwise_add_elem", 12.0 * (double)out.len);
+    hipLaunchKernelGGL(eltwise_add_kernel, dim3(grid1d(out.len)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
+                       (const uint32_t*)a.dptr, (const uint32_t*)b.dptr, out.len);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+extern "C" const char* bx_eltwise_copy_elem(bx_ctx* c, bx_buf out, bx_buf in) {
+    if (!c) return "bx_eltwise_copy_elem: null ctx";
+    BX_REQUIRE(c, out.len == in.len, "eltwise_copy_elem: length mismatch");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "eltwise_copy_elem", 8.0 * (double)out.len);
+    BX_HIP(c, hipMemcpyAsync(out.dptr, in.dptr, out.len * 4, hipMemcpyDeviceToDevice, c->stream));
+    return nullptr;
+}
+extern "C" const char* bx_eltwise_zeroize_elem(bx_ctx* c, bx_buf io) {
+    if (!c) return "bx_eltwise_zeroize_elem: null ctx";
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "eltwise_zeroize_elem", 8.0 * (double)io.len);
+    hipLaunchKernelGGL(eltwise_zeroize_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, io.len);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) {
+    if (!c) return "bx_eltwise_sum_extelem: null ctx";
+    BX_REQUIRE(c, out.len % 4 == 0 && out.len > 0 && in.len % out.len == 0, "eltwise_sum_extelem: in.len not a multiple of out.len");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t count = out.len / 4, to_add = in.len / out.len;
+    OpScope op(c, "eltwise_sum_extelem", 4.0 * (double)(in.len + out.len));
+    hipLaunchKernelGGL(eltwise_sum_ext_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
+                       (uint32_t*)out.dptr, (const uint32_t*)in.dptr, count, to_add);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride) {
+    if (!c) return "bx_gather_sample: null ctx";
+    BX_REQUIRE(c, dst.len >= size, "gather_sample: dst too small");
+    BX_REQUIRE(c, size == 0 || idx + (size - 1) * stride < src.len, "gather_sample: source index out of range");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!size) return nullptr;
+    hipLaunchKernelGGL(gather_sample_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)dst.dptr,
+                       (const uint32_t*)src.dptr, idx, size, stride);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4], bx_buf rem_out) {
+    if (!c) return "bx_poly_divide: null ctx";
+    BX_REQUIRE(c, poly.len % 4 == 0 && rem_out.len >= 4, "poly_divide: poly must be AoS ext, remainder buffer >= 4 words");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t size = poly.len / 4;
+    if (!size) return nullptr;
+    OpScope op(c, "poly_divide", 8.0 * (double)poly.len);
+    size_t chunks = (size + DIV_L - 1) / DIV_L;
+    BX_TRY(ensure_scratch(c, 4 * chunks + 8));
+    Fp4 zz = host4(z);
+    Fp4 zL = f4_pow(zz, DIV_L);
+    hipLaunchKernelGGL(div_local_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint32_t*)poly.dptr, size, zz, c->d_scratch, chunks);
+    BX_LAUNCH_CHECK(c);
+    unsigned nt = chunks >= 1024 ? 1024 : (chunks >= 64 ? 64 : 64);
+    hipLaunchKernelGGL(div_scan_kernel, dim3(1), dim3(nt), nt * 32, c->stream, c->d_scratch, chunks, zL, (uint32_t*)rem_out.dptr);
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(div_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)poly.dptr,
+                       size, zz, c->d_scratch, chunks);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}

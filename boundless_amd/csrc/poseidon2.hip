@@ -1,0 +1,268 @@
+// poseidon2.hip — Poseidon2 (BabyBear, t=24, rate 16, 4+21+4 rounds, x^7) Merkle hashing for gfx950.
+//
+// Restates risc0_zkp::hal::Hal::{hash_rows, hash_fold} with the `poseidon2` hash suite and
+// risc0_zkp::core::hash::poseidon2::{poseidon2_mix, unpadded_hash} (risc0-zkp 3.0.3, reference Cargo.lock:9155),
+// reached from bento/crates/workflow/src/tasks/prove.rs:41-49 via MerkleTreeProver::new.
+//
+// MI355X design: the permutation is pure 32-bit integer VALU work (~1.4k Montgomery products per
+// 64 absorbed bytes) — no MFMA shape exists for it and it is nowhere near HBM-bound, so the kernel is organised
+// around registers, not memory: one matrix row per lane, the 24-word state in VGPRs for the whole sponge,
+// round constants fetched through wave-uniform (scalar) loads, loads of the column-major matrix coalesced
+// across the 64 lanes of a wave (lane r reads matrix[c*rows + r]).
+#include "ctx.hpp"
+
+namespace bx {
+
+constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
+
+__device__ __forceinline__ uint32_t sbox7(uint32_t x) {
+    uint32_t x2 = fp_mul(x, x), x3 = fp_mul(x2, x), x4 = fp_mul(x2, x2);
+    return fp_mul(x3, x4);
+}
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with additions only (Poseidon2 paper, appendix B).
+__device__ __forceinline__ void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    uint32_t t0 = fp_add(a, b), t1 = fp_add(c, d);
+    uint32_t t2 = fp_add(fp_dbl(b), t1), t3 = fp_add(fp_dbl(d), t0);
+    uint32_t t4 = fp_add(fp_dbl(fp_dbl(t1)), t3), t5 = fp_add(fp_dbl(fp_dbl(t0)), t2);
+    a = fp_add(t3, t5);
+    b = t5;
+    c = fp_add(t2, t4);
+    d = t4;
+}
+__device__ __forceinline__ void m_ext(uint32_t* s) {
+#pragma unroll
+    for (int i = 0; i < CELLS; i += 4) m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+    uint32_t sum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sum[j] = s[j];
+#pragma unroll
+        for (int i = 4; i < CELLS; i += 4) sum[j] = fp_add(sum[j], s[i + j]);
+    }
+#pragma unroll
+    for (int i = 0; i < CELLS; ++i) s[i] = fp_add(s[i], sum[i & 3]);
+}
+__device__ __forceinline__ void m_int(uint32_t* s, const uint32_t* __restrict__ diag) {
+    // pairwise tree keeps the dependency chain short
+    uint32_t p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = fp_add(s[2 * i], s[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p[i] = fp_add(p[2 * i], p[2 * i + 1]);
+    uint32_t sum = fp_add(fp_add(fp_add(p[0], p[1]), fp_add(p[2], p[3])), fp_add(p[4], p[5]));
+#pragma unroll
+    for (int i = 0; i < CELLS; ++i) s[i] = fp_add(sum, fp_mul(diag[i], s[i]));
+}
+// params: [0,96) first external rounds | [96,117) internal | [117,213) last external | [213,237) diag (Montgomery)
+__device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
+    m_ext(s);
+#pragma unroll 1
+    for (int r = 0; r < RF_HALF; ++r) {
+        const uint32_t* rc = prm + r * CELLS;
+#pragma unroll
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(fp_add(s[i], rc[i]));
+        m_ext(s);
+    }
+    const uint32_t* diag = prm + 213;
+#pragma unroll 1
+    for (int r = 0; r < RP; ++r) {
+        s[0] = sbox7(fp_add(s[0], prm[96 + r]));
+        m_int(s, diag);
+    }
+#pragma unroll 1
+    for (int r = 0; r < RF_HALF; ++r) {
+        const uint32_t* rc = prm + 117 + r * CELLS;
+#pragma unroll
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(fp_add(s[i], rc[i]));
+        m_ext(s);
+    }
+}
+
+// hash_rows: lane = row.  matrix is column-major rows x cols.
+__global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
+                                                        const uint32_t* __restrict__ prm, uint32_t rows, uint32_t cols) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t s[CELLS];
+#pragma unroll
+    for (int i = 0; i < CELLS; ++i) s[i] = 0u;
+    const uint32_t* p = matrix + r;
+    uint32_t c = 0;
+    for (; c + RATE <= cols; c += RATE) {
+#pragma unroll
+        for (int i = 0; i < RATE; ++i) s[i] = p[(size_t)(c + i) * rows];
+        poseidon2_mix(s, prm);
+    }
+    if (c < cols || cols == 0) {
+#pragma unroll
+        for (int i = 0; i < RATE; ++i) s[i] = (c + i < cols) ? p[(size_t)(c + i) * rows] : 0u;
+        poseidon2_mix(s, prm);
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)r * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// hash_fold: lane = output node; io[out+i] = H(io[in+2i] || io[in+2i+1]).
+__global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
+                                                        uint32_t input_size, uint32_t output_size) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= output_size) return;
+    const uint4* src = reinterpret_cast<const uint4*>(io + ((size_t)input_size + 2 * (size_t)i) * 8);
+    uint32_t s[CELLS];
+    uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
+    s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
+    s[8] = v2.x; s[9] = v2.y; s[10] = v2.z; s[11] = v2.w;
+    s[12] = v3.x; s[13] = v3.y; s[14] = v3.z; s[15] = v3.w;
+#pragma unroll
+    for (int k = 16; k < CELLS; ++k) s[k] = 0u;
+    poseidon2_mix(s, prm);
+    uint4* o = reinterpret_cast<uint4*>(io + ((size_t)output_size + i) * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// Bottom of the tree in one launch: a workgroup folds its 256 leaf digests down to one node per level through
+// LDS, writing every intermediate layer.  Levels above log2(256) use hash_fold_kernel.
+__global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
+                                                              uint32_t input_size, int levels) {
+    __shared__ uint32_t sh[256 * 8];
+    const uint32_t tid = threadIdx.x;
+    // level 0: 512 inputs -> 256 outputs, one per lane
+    uint32_t out_size = input_size >> 1;
+    uint32_t i = blockIdx.x * 256u + tid;
+    uint32_t s[CELLS];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(io + ((size_t)input_size + 2 * (size_t)i) * 8);
+        uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
+        s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
+        s[8] = v2.x; s[9] = v2.y; s[10] = v2.z; s[11] = v2.w;
+        s[12] = v3.x; s[13] = v3.y; s[14] = v3.z; s[15] = v3.w;
+#pragma unroll
+        for (int k = 16; k < CELLS; ++k) s[k] = 0u;
+        poseidon2_mix(s, prm);
+        uint4* o = reinterpret_cast<uint4*>(io + ((size_t)out_size + i) * 8);
+        o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+        o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    }
+    uint32_t width = 256;
+    for (int lvl = 1; lvl < levels; ++lvl) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[tid * 8 + k] = s[k];
+        __syncthreads();
+        width >>= 1;
+        out_size >>= 1;
+        if (tid < width) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s[k] = sh[tid * 16 + k];
+#pragma unroll
+            for (int k = 16; k < CELLS; ++k) s[k] = 0u;
+            poseidon2_mix(s, prm);
+            uint4* o = reinterpret_cast<uint4*>(io + ((size_t)out_size + blockIdx.x * width + tid) * 8);
+            o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+            o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+        }
+        __syncthreads();
+    }
+}
+
+const char* poseidon2_upload_params(bx_ctx* c) {
+    uint32_t h[237];
+    for (int i = 0; i < 213; ++i) h[i] = fp_encode(c->h_rc[i]);
+    for (int i = 0; i < 24; ++i) h[213 + i] = fp_encode(c->h_diag[i]);
+    if (!c->d_p2) BX_HIP(c, hipMalloc(&c->d_p2, sizeof h));
+    BX_HIP(c, hipMemcpyAsync(c->d_p2, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+
+static const char* launch_hash_rows(bx_ctx* c, uint32_t* out, const uint32_t* matrix, size_t rows, size_t cols) {
+    if (rows == 0) return nullptr;
+    unsigned bs = (unsigned)c->hash_rows_block;
+    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, c->stream, out, matrix, c->d_p2,
+                       (uint32_t)rows, (uint32_t)cols);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+static const char* launch_hash_fold(bx_ctx* c, uint32_t* io, size_t input_size, size_t output_size) {
+    if (output_size == 0) return nullptr;
+    hipLaunchKernelGGL(hash_fold_kernel, dim3((unsigned)((output_size + 255) / 256)), dim3(256), 0, c->stream, io, c->d_p2,
+                       (uint32_t)input_size, (uint32_t)output_size);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+}  // namespace bx
+
+using namespace bx;
+
+extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213, const uint32_t* diag24) {
+    if (!c) return "bx_poseidon2_set_params: null ctx";
+    BX_REQUIRE(c, rc213 && diag24, "poseidon2_set_params: null table");
+    BX_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < 213; ++i) c->h_rc[i] = rc213[i] % P;
+    for (int i = 0; i < 24; ++i) c->h_diag[i] = diag24[i] % P;
+    return poseidon2_upload_params(c);
+}
+extern "C" const char* bx_poseidon2_get_params(bx_ctx* c, uint32_t* rc213, uint32_t* diag24) {
+    if (!c) return "bx_poseidon2_get_params: null ctx";
+    for (int i = 0; i < 213; ++i) rc213[i] = c->h_rc[i];
+    for (int i = 0; i < 24; ++i) diag24[i] = c->h_diag[i];
+    return nullptr;
+}
+
+extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) {
+    if (!c) return "bx_hash_rows: null ctx";
+    BX_REQUIRE(c, out.len % 8 == 0, "hash_rows: digest buffer length not a multiple of 8 words");
+    size_t rows = out.len / 8;
+    BX_REQUIRE(c, rows > 0 && matrix.len % rows == 0, "hash_rows: matrix.len not a multiple of rows");
+    BX_REQUIRE(c, rows <= 0xffffffffu, "hash_rows: too many rows");
+    size_t cols = matrix.len / rows;
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
+    return launch_hash_rows(c, (uint32_t*)out.dptr, (const uint32_t*)matrix.dptr, rows, cols);
+}
+
+extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, size_t output_size) {
+    if (!c) return "bx_hash_fold: null ctx";
+    BX_REQUIRE(c, input_size == 2 * output_size, "hash_fold: input_size must be 2*output_size");
+    BX_REQUIRE(c, io.len >= (input_size + 2 * output_size) * 8, "hash_fold: digest buffer too small");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "hash_fold", 96.0 * (double)output_size);
+    return launch_hash_fold(c, (uint32_t*)io.dptr, input_size, output_size);
+}
+
+extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) {
+    if (!c) return "bx_merkle_build: null ctx";
+    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
+    BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
+    BX_HIP(c, hipSetDevice(c->device));
+    uint32_t* n = (uint32_t*)nodes.dptr;
+    {
+        OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
+        BX_TRY(launch_hash_rows(c, n + 8 * rows, (const uint32_t*)matrix.dptr, rows, matrix.len / rows));
+    }
+    OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
+    size_t size = rows;
+    while (size > 1) {
+        if (size >= 512) {
+            int levels = 0;
+            size_t s = size;
+            while (levels < 9 && s >= 2) {  // 512 inputs per workgroup -> up to 9 levels (256 .. 1 outputs)
+                s >>= 1;
+                levels++;
+            }
+            // a workgroup owns 512 consecutive inputs: it can fold them 9 levels deep
+            hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / 512)), dim3(256), 0, c->stream, n, c->d_p2,
+                               (uint32_t)size, levels);
+            BX_LAUNCH_CHECK(c);
+            size >>= levels;
+        } else {
+            BX_TRY(launch_hash_fold(c, n, size, size / 2));
+            size >>= 1;
+        }
+    }
+    return nullptr;
+}

@@ -1,0 +1,136 @@
+/*
+ * bx_hal.h — C ABI of libbx_hip_hal.so: the MI355X (gfx950) implementation of the kernel-level
+ * interface that sits under the Bento prove agent's segment-prove hot path.
+ *
+ * Reference boundary this replaces
+ * --------------------------------
+ *   bento/crates/workflow/src/tasks/prove.rs:41-49   prover.prove_segment(&verifier_ctx, &segment)
+ *   bento/crates/workflow/src/tasks/prove.rs:92-100  prover.lift(&segment_receipt)
+ *   bento/crates/workflow/src/lib.rs:246-249         get_prover_server(&ProverOpts::default())
+ *   blake3_groth16/src/prove/cuda.rs:59              risc0_zkp::hal::cuda::singleton()  (the only in-tree
+ *                                                    touch of the HAL module)
+ * Below `ProverServer` the reference reaches `risc0_zkp::hal::Hal` (risc0-zkp 3.0.3, Cargo.lock:9155) whose
+ * CUDA implementation binds `extern "C"` kernels from risc0-sys 1.5.0 (Cargo.lock:9131) that return a
+ * `const char*` error string (NULL = ok).  This header is the HIP counterpart of that `extern "C"` surface:
+ * one entry point per `Hal` trait method the segment prover calls.  INTEGRATION.md shows the Rust
+ * `impl Hal for HipHal` shim that binds it.
+ *
+ * Conventions
+ * -----------
+ *   - Every call returns NULL on success or a NUL-terminated message owned by the library (valid until the
+ *     next call on the same ctx; for bx_init failures a static string).  No call aborts the process and no
+ *     C++ exception crosses the ABI — the agent's retry machinery (bento/crates/workflow/src/lib.rs:381-436)
+ *     relies on errors surfacing as values.
+ *   - A ctx owns one HIP device + one stream.  Calls on one ctx are stream-ordered; only bx_d2h, bx_sync,
+ *     bx_timer_stop, bx_profile_report and the prover entry points block the host.  A ctx is not
+ *     thread-safe; distinct ctxs may be used from distinct threads.
+ *   - All field elements are u32 words in Montgomery form (R = 2^32) over BabyBear P = 15*2^27 + 1 — the
+ *     in-memory representation of risc0_core::field::baby_bear::Elem.  `bx_buf.len` counts u32 words.
+ *     Buffer<ExtElem> is AoS (4 consecutive words); ext data held in a Buffer<Elem> is SoA (plane k at
+ *     k*size).  Digests are 8 words.  Matrices are column-major (column c = [c*rows, (c+1)*rows)).
+ *   - bx_buf is a plain (device pointer, length) pair, so memory owned by another allocator on the same
+ *     device (e.g. a torch tensor's data_ptr) may be passed in.
+ */
+#ifndef BX_HAL_H
+#define BX_HAL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BX_P 2013265921u
+#define BX_DIGEST_WORDS 8
+#define BX_EXT_SIZE 4
+#define BX_FRI_FOLD 16
+#define BX_INV_RATE 4
+#define BX_QUERIES 50
+#define BX_FRI_MIN_DEGREE 256
+#define BX_CHECK_SIZE 16
+#define BX_POSEIDON2_RC_COUNT 213 /* 24*8 external + 21 internal */
+
+typedef struct bx_ctx bx_ctx;
+typedef struct bx_buf {
+    void* dptr;
+    size_t len; /* u32 words */
+} bx_buf;
+
+/* ---- context / memory (Hal::alloc_*, copy_from_*, Buffer::view) ---- */
+const char* bx_init(int device, bx_ctx** out);
+const char* bx_free(bx_ctx* ctx);
+const char* bx_device_name(bx_ctx* ctx, char* out, size_t cap);
+const char* bx_set_stream(bx_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (NULL = own stream) */
+void* bx_get_stream(bx_ctx* ctx);
+const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
+const char* bx_release(bx_ctx* ctx, bx_buf buf);
+const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
+const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */
+const char* bx_d2d(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t words);
+const char* bx_sync(bx_ctx* ctx);
+
+/* ---- Hal NTT family ---- */
+/* Hal::batch_interpolate_ntt(io, count): `count` polys of size io.len/count, natural-order evaluations ->
+ * bit-reversed coefficients, in place. */
+const char* bx_batch_interpolate_ntt(bx_ctx* ctx, bx_buf io, size_t count);
+/* Hal::batch_evaluate_ntt(io, count, expand_bits): bit-reversed coefficients -> natural-order evaluations,
+ * in place, skipping the first expand_bits stages. */
+const char* bx_batch_evaluate_ntt(bx_ctx* ctx, bx_buf io, size_t count, size_t expand_bits);
+/* Hal::batch_expand_into_evaluate_ntt(out, in, count, expand_bits): out[i] = in[i >> bits] then evaluate. */
+const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* ctx, bx_buf out, bx_buf in, size_t count,
+                                              size_t expand_bits);
+/* Hal::batch_bit_reverse(io, count) */
+const char* bx_batch_bit_reverse(bx_ctx* ctx, bx_buf io, size_t count);
+/* Hal::zk_shift(io, count): io[i] *= 3^bitrev(i mod size) */
+const char* bx_zk_shift(bx_ctx* ctx, bx_buf io, size_t count);
+
+/* ---- Hal hash family (Poseidon2 suite: BabyBear t=24, rate 16, 8+21 rounds, x^7) ---- */
+/* Replace the permutation parameters (canonical, non-Montgomery integers): 213 round constants laid out as
+ * 4x24 external | 21 internal | 4x24 external, and the 24-entry internal diagonal (matrix = 1*1^T + diag).
+ * The library default is the published BabyBear t=24 instance used by the reference's `poseidon2` hashfn. */
+const char* bx_poseidon2_set_params(bx_ctx* ctx, const uint32_t* rc213, const uint32_t* diag24);
+const char* bx_poseidon2_get_params(bx_ctx* ctx, uint32_t* rc213, uint32_t* diag24);
+/* Hal::hash_rows(output, matrix): out_digests.len/8 rows; cols = matrix.len/rows. */
+const char* bx_hash_rows(bx_ctx* ctx, bx_buf out_digests, bx_buf matrix);
+/* Hal::hash_fold(io, input_size, output_size): io[out+i] = H(io[in+2i] || io[in+2i+1]), digest indices. */
+const char* bx_hash_fold(bx_ctx* ctx, bx_buf io_digests, size_t input_size, size_t output_size);
+/* MerkleTreeProver::new's loop in one call: nodes has 2*rows digests; hashes the rows of `matrix` into
+ * nodes[rows..2rows) and folds every layer down to nodes[1]. */
+const char* bx_merkle_build(bx_ctx* ctx, bx_buf nodes_digests, bx_buf matrix, size_t rows);
+
+/* ---- Hal FRI / DEEP family ---- */
+/* Hal::fri_fold(output, input, mix): SoA planes; input.len = 16*output.len. `mix` = 4 host words. */
+const char* bx_fri_fold(bx_ctx* ctx, bx_buf out, bx_buf in, const uint32_t mix[4]);
+/* Hal::mix_poly_coeffs(output, mix_start, mix, input, combos, input_size, count):
+ * out_ext[combos[i]*count + idx] += mix_start*mix^i * in[i*count + idx], i < input_size, idx < count. */
+const char* bx_mix_poly_coeffs(bx_ctx* ctx, bx_buf out_ext, const uint32_t mix_start[4],
+                               const uint32_t mix[4], bx_buf in, bx_buf combos_u32, size_t input_size,
+                               size_t count);
+/* Hal::batch_evaluate_any(coeffs, poly_count, which, xs, out): out[i] = sum_j coeffs[which[i]*size+j]*xs[i]^j */
+const char* bx_batch_evaluate_any(bx_ctx* ctx, bx_buf coeffs, size_t poly_count, bx_buf which_u32,
+                                  bx_buf xs_ext, bx_buf out_ext);
+/* Hal::eltwise_add_elem / eltwise_copy_elem / eltwise_zeroize_elem / eltwise_sum_extelem */
+const char* bx_eltwise_add_elem(bx_ctx* ctx, bx_buf out, bx_buf a, bx_buf b);
+const char* bx_eltwise_copy_elem(bx_ctx* ctx, bx_buf out, bx_buf in);
+const char* bx_eltwise_zeroize_elem(bx_ctx* ctx, bx_buf io);
+const char* bx_eltwise_sum_extelem(bx_ctx* ctx, bx_buf out, bx_buf in_ext);
+/* Hal::gather_sample(dst, src, idx, size, stride): dst[i] = src[idx + i*stride] */
+const char* bx_gather_sample(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride);
+/* DEEP quotient (upstream: core/poly.rs poly_divide, run per combo): in-place synthetic division of the
+ * natural-order AoS ext polynomial by (x - z); the remainder (4 words) is written to rem_out_dev. */
+const char* bx_poly_divide(bx_ctx* ctx, bx_buf poly_ext, const uint32_t z[4], bx_buf rem_out_dev);
+
+/* ---- measurement (HIP events on the ctx's stream) ---- */
+const char* bx_timer_start(bx_ctx* ctx);
+const char* bx_timer_stop(bx_ctx* ctx, float* ms_out); /* blocks */
+/* Per-entry-point profiling: when enabled every HAL call is bracketed by hipEvents on the ctx stream and
+ * accumulated by op name together with its algorithmic bytes. */
+const char* bx_profile_enable(bx_ctx* ctx, int on);
+const char* bx_profile_reset(bx_ctx* ctx);
+const char* bx_profile_report(bx_ctx* ctx, char* json_out, size_t cap); /* blocks */
+/* Tunables (NTT pass split, tile sizes); name/value pairs documented in DESIGN.md.  Unknown names error. */
+const char* bx_set_tunable(bx_ctx* ctx, const char* name, long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

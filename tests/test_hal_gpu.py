@@ -1,0 +1,330 @@
+"""GPU parity: every HAL entry point (through the C ABI) against the CPU oracle, bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as npo
+from oracle import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+P = ol.P
+
+
+@pytest.fixture(scope="module")
+def hal():
+    from boundless_amd.hal import HipHal
+
+    h = HipHal(0)
+    yield h
+    h.close()
+
+
+def rnd(seed, n):
+    return ol.random_elems(np.random.default_rng(seed), n)
+
+
+def c(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+# ------------------------------------------------------------------ NTT family
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 8, 10, 12, 13, 14, 16, 18])
+@pytest.mark.parametrize("count", [1, 3])
+def test_interpolate_zkshift_lde_bitreverse(hal, oracle, bits, count):
+    n = 1 << bits
+    x = rnd(100 + bits, n * count)
+    ref = x.copy()
+    io = hal.copy_from(x)
+    hal.batch_interpolate_ntt(io, count)
+    oracle.bxo_batch_interpolate_ntt(ref, count, n)
+    assert np.array_equal(io.view(), ref), "batch_interpolate_ntt"
+    hal.zk_shift(io, count)
+    oracle.bxo_zk_shift(ref, count, n)
+    assert np.array_equal(io.view(), ref), "zk_shift"
+    out = hal.alloc(4 * n * count)
+    hal.batch_expand_into_evaluate_ntt(out, io, count, 2)
+    ref_out = np.zeros(4 * n * count, np.uint32)
+    oracle.bxo_batch_expand_into_evaluate_ntt(ref_out, ref, count, n, 2)
+    assert np.array_equal(out.view(), ref_out), "batch_expand_into_evaluate_ntt"
+    hal.batch_bit_reverse(io, count)
+    oracle.bxo_batch_bit_reverse(ref, count, n)
+    assert np.array_equal(io.view(), ref), "batch_bit_reverse"
+
+
+@pytest.mark.parametrize("bits,expand", [(4, 0), (9, 0), (14, 0), (6, 2), (14, 2), (15, 1)])
+def test_evaluate_ntt_in_place(hal, oracle, bits, expand):
+    n = 1 << bits
+    x = rnd(7 + bits, n * 2)
+    ref = x.copy()
+    io = hal.copy_from(x)
+    hal.batch_evaluate_ntt(io, 2, expand)
+    oracle.bxo_batch_evaluate_ntt(ref, 2, n, expand)
+    assert np.array_equal(io.view(), ref)
+
+
+def test_ntt_golden_vectors(hal, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "ntt_vectors.json")))["cases"]
+    for case in cases:
+        n = 1 << case["bits"]
+        io = hal.copy_from(ol.encode(case["evals"]))
+        hal.batch_interpolate_ntt(io, 1)
+        assert ol.decode(io.view()).tolist() == case["coeffs_bitrev"]
+        hal.zk_shift(io, 1)
+        assert ol.decode(io.view()).tolist() == case["shifted_bitrev"]
+        out = hal.alloc(4 * n)
+        hal.batch_expand_into_evaluate_ntt(out, io, 1, 2)
+        assert ol.decode(out.view()).tolist() == case["lde4"]
+
+
+@pytest.mark.parametrize("block_log,tile_log", [(12, 14), (13, 14), (11, 13), (10, 12)])
+def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, block_log, tile_log):
+    """BASELINE size: N = 2^20 rows -> 2^22 LDE, for every pass-split tunable."""
+    hal.set_tunable("ntt_block_log", block_log)
+    hal.set_tunable("ntt_tile_log", tile_log)
+    try:
+        n, count = 1 << 20, 2
+        x = rnd(2020, n * count)
+        ref = x.copy()
+        io = hal.copy_from(x)
+        hal.batch_interpolate_ntt(io, count)
+        oracle.bxo_batch_interpolate_ntt(ref, count, n)
+        assert np.array_equal(io.view(), ref)
+        out = hal.alloc(4 * n * count)
+        hal.batch_expand_into_evaluate_ntt(out, io, count, 2)
+        lde = out.view()
+        # size-independent property: without zk_shift every 4th LDE point is the original evaluation
+        assert np.array_equal(lde.reshape(count, 4 * n)[:, ::4].reshape(-1), x)
+        ref_out = np.zeros(4 * n * count, np.uint32)
+        oracle.bxo_batch_expand_into_evaluate_ntt(ref_out, ref, count, n, 2)
+        assert np.array_equal(lde, ref_out)
+        # evaluate(interpolate(x)) == x
+        hal.batch_evaluate_ntt(io, count, 0)
+        assert np.array_equal(io.view(), x)
+    finally:
+        hal.set_tunable("ntt_block_log", 12)
+        hal.set_tunable("ntt_tile_log", 14)
+
+
+def test_ntt_linearity_full_size(hal):
+    n = 1 << 20
+    a, b = rnd(1, n), rnd(2, n)
+    s = ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    outs = []
+    for v in (a, b, s):
+        io = hal.copy_from(v)
+        hal.batch_interpolate_ntt(io, 1)
+        outs.append(io.view().astype(np.uint64))
+    assert np.array_equal((outs[0] + outs[1]) % P, outs[2])
+
+
+def test_ntt_errors(hal):
+    from boundless_amd.hal import HalError
+
+    io = hal.alloc(24)
+    with pytest.raises(HalError):
+        hal.batch_interpolate_ntt(io, 1)  # 24 is not a power of two
+    with pytest.raises(HalError):
+        hal.batch_interpolate_ntt(io, 5)  # not divisible
+    out = hal.alloc(64)
+    with pytest.raises(HalError):
+        hal.batch_expand_into_evaluate_ntt(out, hal.alloc(32), 1, 2)  # 32<<2 != 64
+
+
+# ------------------------------------------------------------------ Poseidon2 / Merkle
+def test_poseidon2_params_are_the_published_instance(hal, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "poseidon2_kat.json")))
+    rc, diag = hal.poseidon2_get_params()
+    assert rc.tolist() == g["round_constants"] and diag.tolist() == g["internal_diag"]
+
+
+def test_poseidon2_golden_sponge_pair_merkle(hal, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "poseidon2_sponge.json")))
+    # sponge cases as 1-row matrices (cols = len)
+    for case in g["sponge"]:
+        if not case["in"]:
+            continue
+        m = hal.copy_from(ol.encode(case["in"]))
+        d = hal.alloc_digest(1)
+        hal.hash_rows(d, m)
+        assert ol.decode(d.view()).tolist() == case["digest"]
+    # pair
+    io = hal.alloc_digest(4)
+    host = np.zeros(32, np.uint32)
+    host[16:24] = ol.encode(g["pair"]["a"])
+    host[24:32] = ol.encode(g["pair"]["b"])
+    io.copy_from(host)
+    hal.hash_fold(io, 2, 1)
+    assert ol.decode(io.view()[8:16]).tolist() == g["pair"]["out"]
+    # merkle
+    mk = g["merkle"]
+    rows = mk["rows"]
+    mat = hal.copy_from(ol.encode(np.array(mk["matrix_colmajor"], dtype=np.uint64).reshape(-1)))
+    nodes = hal.alloc_digest(2 * rows)
+    hal.merkle_build(nodes, mat, rows)
+    v = nodes.view()
+    assert ol.decode(v[8 * rows :].reshape(rows, 8)).tolist() == mk["leaves"]
+    assert ol.decode(v[8:16]).tolist() == mk["root"]
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (64, 15), (64, 16), (100, 17), (1000, 40), (4096, 64), (1 << 14, 33)])
+def test_hash_rows_vs_oracle(hal, oracle, rows, cols):
+    x = rnd(rows * 31 + cols, rows * cols)
+    out = hal.alloc_digest(rows)
+    hal.hash_rows(out, hal.copy_from(x))
+    ref = np.zeros(8 * rows, np.uint32)
+    oracle.bxo_hash_rows(ref, x, rows, cols)
+    assert np.array_equal(out.view(), ref)
+
+
+@pytest.mark.parametrize("rows", [2, 8, 256, 512, 1024, 4096, 1 << 15])
+def test_merkle_build_vs_oracle(hal, oracle, rows):
+    cols = 20
+    x = rnd(rows, rows * cols)
+    nodes = hal.alloc_digest(2 * rows)
+    nodes.copy_from(np.zeros(16 * rows, np.uint32))
+    hal.merkle_build(nodes, hal.copy_from(x), rows)
+    ref = np.zeros(16 * rows, np.uint32)
+    leaves = np.zeros(8 * rows, np.uint32)
+    oracle.bxo_hash_rows(leaves, x, rows, cols)
+    ref[8 * rows :] = leaves
+    size = rows
+    while size > 1:
+        oracle.bxo_hash_fold(ref, size, size // 2)
+        size //= 2
+    got = nodes.view()
+    assert np.array_equal(got[8:], ref[8:])
+    # the same tree through the layer-by-layer Hal::hash_fold calls
+    nodes2 = hal.alloc_digest(2 * rows)
+    nodes2.copy_from(np.concatenate([np.zeros(8 * rows, np.uint32), leaves]))
+    size = rows
+    while size > 1:
+        hal.hash_fold(nodes2, size, size // 2)
+        size //= 2
+    assert np.array_equal(nodes2.view()[8:], ref[8:])
+
+
+def test_poseidon2_set_params_roundtrip(hal, oracle):
+    """A different parameter table changes the digests identically on both sides, and restoring works."""
+    rc0, d0 = hal.poseidon2_get_params()
+    rng = np.random.default_rng(3)
+    rc1 = rng.integers(0, P, 213, dtype=np.uint32)
+    d1 = rng.integers(0, P, 24, dtype=np.uint32)
+    x = rnd(5, 64 * 20)
+    try:
+        hal.poseidon2_set_params(rc1, d1)
+        oracle.bxo_poseidon2_set_params(c(rc1), c(d1))
+        out = hal.alloc_digest(64)
+        hal.hash_rows(out, hal.copy_from(x))
+        ref = np.zeros(8 * 64, np.uint32)
+        oracle.bxo_hash_rows(ref, x, 64, 20)
+        assert np.array_equal(out.view(), ref)
+    finally:
+        hal.poseidon2_set_params(rc0, d0)
+        oracle.bxo_poseidon2_set_params(c(rc0), c(d0))
+
+
+# ------------------------------------------------------------------ FRI / DEEP
+@pytest.mark.parametrize("count", [1, 16, 256, 1 << 12, 1 << 16])
+def test_fri_fold_vs_oracle(hal, oracle, count):
+    x = rnd(count, 64 * count)
+    mix = rnd(9, 4)
+    out = hal.alloc(4 * count)
+    hal.fri_fold(out, hal.copy_from(x), mix)
+    ref = np.zeros(4 * count, np.uint32)
+    oracle.bxo_fri_fold(ref, x, c(mix), count)
+    assert np.array_equal(out.view(), ref)
+
+
+def test_fri_fold_golden(hal, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "fri_vectors.json")))["fold"]
+    f = g["coeffs_natural"]
+    total = len(f)
+    count = total // 16
+    bits = npo.log2(total)
+    planes = np.zeros(4 * total, np.uint64)
+    for j in range(total):
+        for k in range(4):
+            planes[k * total + npo.bitrev(j, bits)] = f[j][k]
+    out = hal.alloc(4 * count)
+    hal.fri_fold(out, hal.copy_from(ol.encode(planes)), ol.encode(g["mix"]))
+    o = ol.decode(out.view()).tolist()
+    got = [[o[k * count + npo.bitrev(q, bits - 4)] for k in range(4)] for q in range(count)]
+    assert got == g["out_natural"]
+
+
+@pytest.mark.parametrize("count,npoly,ncombo", [(64, 5, 2), (1000, 33, 4), (1 << 14, 16, 3)])
+def test_mix_poly_coeffs_vs_oracle(hal, oracle, count, npoly, ncombo):
+    rng = np.random.default_rng(count)
+    inp = rnd(count + 1, npoly * count)
+    combos = rng.integers(0, ncombo, npoly, dtype=np.uint32)
+    mix, start = rnd(3, 4), rnd(4, 4)
+    init = rnd(5, ncombo * count * 4)
+    out = hal.copy_from(init)
+    hal.mix_poly_coeffs(out, start, mix, hal.copy_from(inp), hal.copy_from(combos), npoly, count)
+    ref = init.copy()
+    oracle.bxo_mix_poly_coeffs(ref, c(start), c(mix), inp, c(combos), npoly, count)
+    assert np.array_equal(out.view(), ref)
+
+
+@pytest.mark.parametrize("size,npoly,evals", [(16, 3, 4), (256, 2, 3), (8192, 3, 5), (1 << 15, 2, 3), (1 << 18, 2, 2)])
+def test_batch_evaluate_any_vs_oracle(hal, oracle, size, npoly, evals):
+    rng = np.random.default_rng(size)
+    coeffs = rnd(size, npoly * size)
+    which = rng.integers(0, npoly, evals, dtype=np.uint32)
+    xs = rnd(11, 4 * evals)
+    out = hal.alloc(4 * evals)
+    hal.batch_evaluate_any(hal.copy_from(coeffs), npoly, hal.copy_from(which), hal.copy_from(xs), out)
+    ref = np.zeros(4 * evals, np.uint32)
+    oracle.bxo_batch_evaluate_any(coeffs, size, c(which), xs, ref, evals)
+    assert np.array_equal(out.view(), ref)
+
+
+@pytest.mark.parametrize("size", [1, 5, 64, 100, 4096, 1 << 16, 1 << 20])
+def test_poly_divide_vs_oracle(hal, oracle, size):
+    poly = rnd(size, 4 * size)
+    z = rnd(17, 4)
+    buf = hal.copy_from(poly)
+    rem = hal.alloc(4)
+    hal.poly_divide(buf, z, rem)
+    ref = poly.copy()
+    ref_rem = np.zeros(4, np.uint32)
+    oracle.bxo_poly_divide(ref, size, c(z), ref_rem)
+    assert np.array_equal(buf.view(), ref)
+    assert np.array_equal(rem.view(), ref_rem)
+
+
+def test_eltwise_and_gather(hal, oracle):
+    n = 10000
+    a, b = rnd(1, n), rnd(2, n)
+    out = hal.alloc(n)
+    hal.eltwise_add_elem(out, hal.copy_from(a), hal.copy_from(b))
+    ref = np.zeros(n, np.uint32)
+    oracle.bxo_eltwise_add(ref, a, b, n)
+    assert np.array_equal(out.view(), ref)
+    cp = hal.alloc(n)
+    hal.eltwise_copy_elem(cp, out)
+    assert np.array_equal(cp.view(), ref)
+    z = a.copy()
+    z[::7] = 0xFFFFFFFF
+    zb = hal.copy_from(z)
+    hal.eltwise_zeroize_elem(zb)
+    oracle.bxo_eltwise_zeroize(z, n)
+    assert np.array_equal(zb.view(), z)
+    count, to_add = 1000, 5
+    e = rnd(3, 4 * count * to_add)
+    so = hal.alloc(4 * count)
+    hal.eltwise_sum_extelem(so, hal.copy_from(e))
+    sref = np.zeros(4 * count, np.uint32)
+    oracle.bxo_eltwise_sum_extelem(sref, e, count, to_add)
+    assert np.array_equal(so.view(), sref)
+    g = hal.alloc(17)
+    hal.gather_sample(g, hal.copy_from(a), 5, 17, 500)
+    gref = np.zeros(17, np.uint32)
+    oracle.bxo_gather_sample(gref, a, 5, 17, 500)
+    assert np.array_equal(g.view(), gref)
+    from boundless_amd.hal import HalError
+
+    with pytest.raises(HalError):
+        hal.gather_sample(g, hal.copy_from(a), 5, 17, 1000)  # out of range
