@@ -1,0 +1,488 @@
+// prover.hip — the segment prover under `ProverServer::prove_segment` (include/bx_prover.h), host side in C++
+// over the HAL entry points of include/bx_hal.h, plus the few device kernels that stand in for circuit code.
+//
+// Follows risc0_zkp::prove::{Prover::commit_group, Prover::finalize, fri::fri_prove, merkle::MerkleTreeProver,
+// poly_group::PolyGroup} (risc0-zkp 3.0.3, reference Cargo.lock:9155) as called by
+// bento/crates/workflow/src/tasks/prove.rs:41-49.  The call sequence, constants (INV_RATE 4, FRI_FOLD 16,
+// FRI_MIN_DEGREE 256, QUERIES 50, CHECK_SIZE 16), Merkle top-layer rule and transcript order are upstream's; the
+// witness fill and the check polynomial are synthetic stand-ins (see bx_prover.h).
+#include <algorithm>
+#include <memory>
+
+#include "ctx.hpp"
+#include "transcript.hpp"
+#include "../../include/bx_prover.h"
+
+namespace bx {
+
+constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + GOLDEN;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
+    uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
+    return v >= P ? v - P : v;
+}
+
+// stand-in for witness generation: column-major rows x cols of pseudo-random field words
+__global__ void synth_fill_kernel(uint32_t* __restrict__ out, uint32_t rows, uint32_t cols, uint64_t seed) {
+    size_t total = (size_t)rows * cols, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        out[i] = synth_word(seed, (uint32_t)(i / rows), (uint32_t)(i % rows));
+}
+__global__ void ext_pows_kernel(uint32_t* __restrict__ out, Fp4 base, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp4 r = f4_pow(base, i);
+    out[4 * i + 0] = r.c[0]; out[4 * i + 1] = r.c[1]; out[4 * i + 2] = r.c[2]; out[4 * i + 3] = r.c[3];
+}
+// stand-in for eval_check: check[k][r] = sum_c mix^c * (e_c(r)^3 + e_c(r)) over every committed trace column.
+struct CheckArgs {
+    const uint32_t* eval[3];
+    uint32_t width[3];
+};
+__global__ __launch_bounds__(256) void synth_eval_check_kernel(uint32_t* __restrict__ check, CheckArgs a,
+                                                               const uint32_t* __restrict__ mixpows, uint32_t rows) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    Fp4 acc = f4_zero();
+    uint32_t gi = 0;
+    for (int g = 0; g < 3; ++g) {
+        const uint32_t* e = a.eval[g] + r;
+        for (uint32_t c = 0; c < a.width[g]; ++c, ++gi) {
+            uint32_t v = e[(size_t)c * rows];
+            uint32_t t = fp_add(fp_mul(fp_mul(v, v), v), v);
+            uint4 w = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)gi);  // wave-uniform
+            acc = f4_add(acc, f4_scale(Fp4{{w.x, w.y, w.z, w.w}}, t));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) check[(size_t)k * rows + r] = acc.c[k];
+}
+// MerkleTreeProver::prove for a batch of queries (one workgroup per query).
+__global__ void merkle_query_gather_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
+                                           const uint32_t* __restrict__ nodes, uint32_t rows, uint32_t cols,
+                                           const uint32_t* __restrict__ positions, uint32_t depth) {
+    uint32_t q = blockIdx.x;
+    uint32_t pos = positions[q];
+    uint32_t* o = out + (size_t)q * (cols + 8u * depth);
+    for (uint32_t c = threadIdx.x; c < cols; c += blockDim.x) o[c] = matrix[(size_t)c * rows + pos];
+    for (uint32_t w = threadIdx.x; w < 8u * depth; w += blockDim.x) {
+        uint32_t level = w >> 3;
+        uint32_t idx = ((pos + rows) >> level) ^ 1u;
+        o[cols + w] = nodes[(size_t)idx * 8 + (w & 7u)];
+    }
+}
+
+static inline unsigned top_layer_of(unsigned layers) {
+    unsigned top = 0;
+    for (unsigned i = 1; i < layers; ++i) {
+        if ((1u << i) > BX_QUERIES) break;
+        top = i;
+    }
+    return top;
+}
+
+struct DevBuf {
+    bx_ctx* c = nullptr;
+    bx_buf b{nullptr, 0};
+    const char* alloc(bx_ctx* ctx, size_t words) {
+        c = ctx;
+        return bx_alloc(ctx, words, &b);
+    }
+    ~DevBuf() {
+        if (b.dptr) (void)hipFree(b.dptr);
+    }
+    bx_buf slice(size_t off, size_t len) const { return bx_buf{(uint32_t*)b.dptr + off, len}; }
+};
+
+struct Tree {
+    size_t rows = 0, cols = 0;
+    unsigned layers = 0, top_layer = 0;
+    DevBuf nodes;
+    uint32_t root[8];
+    size_t top_size() const { return (size_t)1 << top_layer; }
+    unsigned depth() const { return layers - top_layer; }
+    size_t query_words() const { return cols + 8u * depth(); }
+};
+
+struct Group {
+    uint32_t width = 0;
+    DevBuf coeffs, evaluated, combo_ids;
+    Tree tree;
+    std::vector<uint32_t> taps;  // number of taps per column (1 or 2)
+};
+
+struct FriRound {
+    size_t size = 0;  // ext coefficients entering the round
+    DevBuf evaluated, out_coeffs;
+    Tree tree;
+};
+
+}  // namespace bx
+
+using namespace bx;
+
+struct bx_prover {
+    bx_ctx* c = nullptr;
+    bx_segment_params shape{};
+    size_t N = 0;
+    HostPoseidon2 h2;
+    Group groups[4];  // code, data, accum, check
+    DevBuf mixpows, combos, final_poly, which, xs, evals, rems, positions, qout;
+    std::vector<FriRound> rounds;
+    DevBuf final_coeffs;
+    uint32_t last_roots[32];
+    size_t seal_bound = 0;
+    char err[512];
+};
+
+namespace {
+
+const char* perr(bx_prover* p, const char* m) {
+    snprintf(p->err, sizeof p->err, "%s", m);
+    return p->err;
+}
+#define PV(expr)                                  \
+    do {                                          \
+        const char* _m = (expr);                  \
+        if (_m) return perr(p, _m);               \
+    } while (0)
+
+const char* tree_init(bx_ctx* c, Tree& t, size_t rows, size_t cols) {
+    t.rows = rows;
+    t.cols = cols;
+    t.layers = (unsigned)ilog2(rows);
+    t.top_layer = top_layer_of(t.layers);
+    return t.nodes.alloc(c, 16 * rows);
+}
+
+// MerkleTreeProver::new + commit
+const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
+    bx_ctx* c = p->c;
+    PV(bx_merkle_build(c, t.nodes.b, matrix, t.rows));
+    size_t top = t.top_size();
+    std::vector<uint32_t> host(8 * top + 8);
+    // top layer nodes[top..2*top) and the root nodes[1]
+    PV(bx_d2h(c, host.data(), t.nodes.slice(8 * top, 8 * top), 8 * top));
+    if (top == 1) {
+        memcpy(t.root, host.data(), 32);
+    } else {
+        PV(bx_d2h(c, t.root, t.nodes.slice(8, 8), 8));
+    }
+    T.write(host.data(), 8 * top);
+    T.commit(t.root);
+    return nullptr;
+}
+
+// Prover::commit_group: interpolate -> zk_shift -> PolyGroup::new (expand+evaluate, bit_reverse, Merkle) -> commit
+const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
+    bx_ctx* c = p->c;
+    PV(bx_batch_interpolate_ntt(c, g.coeffs.b, g.width));
+    PV(bx_zk_shift(c, g.coeffs.b, g.width));
+    PV(bx_batch_expand_into_evaluate_ntt(c, g.evaluated.b, g.coeffs.b, g.width, 2));
+    PV(bx_batch_bit_reverse(c, g.coeffs.b, g.width));
+    return tree_commit(p, g.tree, g.evaluated.b, T);
+}
+
+Fp4 host_pow(Fp4 a, uint64_t e) { return f4_pow(a, e); }
+
+}  // namespace
+
+extern "C" const char* bx_merkle_query_gather(bx_ctx* c, bx_buf out, bx_buf matrix, bx_buf nodes, size_t rows, size_t cols,
+                                              bx_buf positions, size_t n_queries, size_t top_size) {
+    if (!c) return "bx_merkle_query_gather: null ctx";
+    BX_REQUIRE(c, is_pow2(rows) && is_pow2(top_size) && top_size <= rows, "merkle_query_gather: rows/top_size must be powers of two");
+    BX_REQUIRE(c, matrix.len == rows * cols && nodes.len == 16 * rows, "merkle_query_gather: matrix/nodes size mismatch");
+    unsigned depth = (unsigned)(ilog2(rows) - ilog2(top_size));
+    BX_REQUIRE(c, out.len >= n_queries * (cols + 8 * depth) && positions.len >= n_queries, "merkle_query_gather: out/positions too small");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!n_queries) return nullptr;
+    OpScope op(c, "merkle_query_gather", 4.0 * (double)(n_queries * (cols + 8 * depth)) * 2.0);
+    hipLaunchKernelGGL(merkle_query_gather_kernel, dim3((unsigned)n_queries), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
+                       (const uint32_t*)matrix.dptr, (const uint32_t*)nodes.dptr, (uint32_t)rows, (uint32_t)cols,
+                       (const uint32_t*)positions.dptr, depth);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shape, bx_prover** out) {
+    if (!c) return "bx_prover_create: null ctx";
+    BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
+    BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 22, "bx_prover_create: po2 must be in [9, 22]");
+    BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
+    BX_HIP(c, hipSetDevice(c->device));
+    std::unique_ptr<bx_prover> p(new (std::nothrow) bx_prover());
+    BX_REQUIRE(c, p != nullptr, "bx_prover_create: out of host memory");
+    p->c = c;
+    p->shape = *shape;
+    p->N = (size_t)1 << shape->po2;
+    p->err[0] = 0;
+    p->h2.load(c->h_rc, c->h_diag);
+    const size_t N = p->N, D = 4 * N;
+    const uint32_t widths[4] = {shape->w_code, shape->w_data, shape->w_accum, BX_CHECK_SIZE};
+    size_t total_taps = 0, max_w = 0;
+    for (int g = 0; g < 4; ++g) {
+        Group& G = p->groups[g];
+        G.width = widths[g];
+        max_w = std::max<size_t>(max_w, G.width);
+        BX_TRY(G.coeffs.alloc(c, (size_t)G.width * N));
+        BX_TRY(G.evaluated.alloc(c, (size_t)G.width * D));
+        BX_TRY(tree_init(c, G.tree, D, G.width));
+        // synthetic tap set: every column is opened at Z; every 4th column of data/accum also one row back
+        G.taps.assign(G.width, 1);
+        if (g == 1 || g == 2)
+            for (uint32_t col = 0; col < G.width; col += 4) G.taps[col] = 2;
+        std::vector<uint32_t> ids(G.width);
+        for (uint32_t col = 0; col < G.width; ++col) ids[col] = g == 3 ? 2u : (G.taps[col] == 2 ? 1u : 0u);
+        BX_TRY(G.combo_ids.alloc(c, G.width));
+        BX_TRY(bx_h2d(c, G.combo_ids.b, ids.data(), G.width));
+        for (uint32_t t : G.taps) total_taps += t;
+    }
+    size_t w_total = (size_t)widths[0] + widths[1] + widths[2];
+    BX_TRY(p->mixpows.alloc(c, 4 * w_total));
+    BX_TRY(p->combos.alloc(c, 3 * 4 * N));
+    BX_TRY(p->final_poly.alloc(c, 4 * N));
+    size_t max_evals = 2 * max_w;
+    BX_TRY(p->which.alloc(c, max_evals));
+    BX_TRY(p->xs.alloc(c, 4 * max_evals));
+    BX_TRY(p->evals.alloc(c, 4 * max_evals));
+    BX_TRY(p->rems.alloc(c, 16));
+    BX_TRY(p->positions.alloc(c, BX_QUERIES));
+    // FRI rounds
+    size_t size = N;
+    size_t fri_query_words = 0;
+    while (size > BX_FRI_MIN_DEGREE) {
+        p->rounds.emplace_back();
+        FriRound& r = p->rounds.back();
+        r.size = size;
+        BX_TRY(r.evaluated.alloc(c, 4 * 4 * size));
+        BX_TRY(r.out_coeffs.alloc(c, 4 * size / BX_FRI_FOLD));
+        BX_TRY(tree_init(c, r.tree, 4 * size / BX_FRI_FOLD, 4 * BX_FRI_FOLD));
+        fri_query_words += r.tree.query_words();
+        size /= BX_FRI_FOLD;
+    }
+    BX_TRY(p->final_coeffs.alloc(c, 4 * size));
+    size_t max_q = 0, trace_query_words = 0;
+    for (int g = 0; g < 4; ++g) {
+        max_q = std::max(max_q, p->groups[g].tree.query_words());
+        trace_query_words += p->groups[g].tree.query_words();
+    }
+    for (auto& r : p->rounds) max_q = std::max(max_q, r.tree.query_words());
+    BX_TRY(p->qout.alloc(c, max_q * BX_QUERIES));
+    // seal bound: header + tops + coeff_u + final coeffs + queries
+    size_t bound = 4;
+    for (int g = 0; g < 4; ++g) bound += 8 * p->groups[g].tree.top_size();
+    for (auto& r : p->rounds) bound += 8 * r.tree.top_size();
+    bound += 4 * total_taps + 4 * size + BX_QUERIES * (trace_query_words + fri_query_words);
+    p->seal_bound = bound;
+    memset(p->last_roots, 0, sizeof p->last_roots);
+    BX_TRY(bx_sync(c));
+    *out = p.release();
+    return nullptr;
+}
+
+extern "C" const char* bx_prover_destroy(bx_prover* p) {
+    if (!p) return nullptr;
+    (void)hipSetDevice(p->c->device);
+    (void)hipStreamSynchronize(p->c->stream);
+    delete p;
+    return nullptr;
+}
+extern "C" size_t bx_prover_seal_words(const bx_prover* p) { return p ? p->seal_bound : 0; }
+extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_out[32]) {
+    if (!p) return "bx_prover_last_roots: null prover";
+    memcpy(roots_out, p->last_roots, sizeof p->last_roots);
+    return nullptr;
+}
+
+extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
+    if (!p) return "bx_prove_segment: null prover";
+    bx_ctx* c = p->c;
+    if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prove_segment: hipSetDevice failed");
+    const size_t N = p->N, D = 4 * N;
+    const uint32_t po2 = p->shape.po2;
+    Transcript T(&p->h2);
+    T.seal.reserve(p->seal_bound);
+
+    // ---- header ----
+    {
+        uint32_t hdr[4] = {po2, p->shape.w_code, p->shape.w_data, p->shape.w_accum}, enc[4], dg[8];
+        for (int i = 0; i < 4; ++i) enc[i] = fp_encode(hdr[i]);
+        T.write(hdr, 4);
+        p->h2.hash_elems(dg, enc, 4);
+        T.commit(dg);
+    }
+    // ---- trace groups: code, data, then accum (which depends on the transcript, like upstream's accum mix) ----
+    for (int g = 0; g < 3; ++g) {
+        Group& G = p->groups[g];
+        uint64_t gseed = seed + GOLDEN * (uint64_t)(g + 1);
+        if (g == 2) {
+            Fp4 am = T.random_ext();
+            gseed ^= ((uint64_t)am.c[0] << 32) | am.c[1];
+        }
+        hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, c->stream, (uint32_t*)G.coeffs.b.dptr, (uint32_t)N, G.width,
+                           gseed);
+        if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: synth_fill launch failed");
+        PV(commit_group(p, G, T));
+        memcpy(p->last_roots + 8 * g, G.tree.root, 32);
+    }
+    // ---- check polynomial (stand-in for eval_check) ----
+    Group& CK = p->groups[3];
+    {
+        Fp4 poly_mix = T.random_ext();
+        uint32_t w_total = p->shape.w_code + p->shape.w_data + p->shape.w_accum;
+        hipLaunchKernelGGL(ext_pows_kernel, dim3((w_total + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->mixpows.b.dptr, poly_mix,
+                           w_total);
+        CheckArgs a;
+        for (int g = 0; g < 3; ++g) {
+            a.eval[g] = (const uint32_t*)p->groups[g].evaluated.b.dptr;
+            a.width[g] = p->groups[g].width;
+        }
+        // the 16N-word check buffer holds the 4 ext planes over the 4N domain
+        hipLaunchKernelGGL(synth_eval_check_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream,
+                           (uint32_t*)CK.coeffs.b.dptr, a, (const uint32_t*)p->mixpows.b.dptr, (uint32_t)D);
+        if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: eval_check launch failed");
+        PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
+        PV(bx_zk_shift(c, CK.coeffs.b, BX_CHECK_SIZE));         // viewed as 16 polynomials of size N
+        PV(bx_batch_expand_into_evaluate_ntt(c, CK.evaluated.b, CK.coeffs.b, BX_CHECK_SIZE, 2));
+        PV(bx_batch_bit_reverse(c, CK.coeffs.b, BX_CHECK_SIZE));
+        PV(tree_commit(p, CK.tree, CK.evaluated.b, T));
+        memcpy(p->last_roots + 24, CK.tree.root, 32);
+    }
+    // ---- DEEP: evaluate every tap at Z * back_one^back, write/commit coeff_u ----
+    const Fp4 Z = T.random_ext();
+    const uint32_t back_one = fp_inv(fp_pow(fp_encode(137u), (uint64_t)1 << (27 - po2)));  // ROU_REV[po2]
+    const Fp4 Zb = f4_scale(Z, back_one);
+    const Fp4 Z4 = host_pow(Z, 4);
+    std::vector<uint32_t> coeff_u;  // flattened ext elems, column by column, group by group
+    for (int g = 0; g < 4; ++g) {
+        Group& G = p->groups[g];
+        std::vector<uint32_t> which, xs;
+        for (uint32_t col = 0; col < G.width; ++col)
+            for (uint32_t t = 0; t < G.taps[col]; ++t) {
+                which.push_back(col);
+                const Fp4& x = g == 3 ? Z4 : (t == 0 ? Z : Zb);
+                xs.insert(xs.end(), x.c, x.c + 4);
+            }
+        size_t ne = which.size();
+        PV(bx_h2d(c, p->which.slice(0, ne), which.data(), ne));
+        PV(bx_h2d(c, p->xs.slice(0, 4 * ne), xs.data(), 4 * ne));
+        PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
+        std::vector<uint32_t> ev(4 * ne);
+        PV(bx_d2h(c, ev.data(), p->evals.slice(0, 4 * ne), 4 * ne));
+        size_t e = 0;
+        for (uint32_t col = 0; col < G.width; ++col) {
+            if (G.taps[col] == 1) {
+                coeff_u.insert(coeff_u.end(), ev.begin() + 4 * e, ev.begin() + 4 * e + 4);
+                e += 1;
+            } else {
+                // line through (Z, y0), (Zb, y1): c1 = (y1 - y0)/(Zb - Z), c0 = y0 - c1*Z
+                Fp4 y0{{ev[4 * e], ev[4 * e + 1], ev[4 * e + 2], ev[4 * e + 3]}};
+                Fp4 y1{{ev[4 * e + 4], ev[4 * e + 5], ev[4 * e + 6], ev[4 * e + 7]}};
+                Fp4 c1 = f4_mul(f4_sub(y1, y0), f4_inv(f4_sub(Zb, Z)));
+                Fp4 c0 = f4_sub(y0, f4_mul(c1, Z));
+                coeff_u.insert(coeff_u.end(), c0.c, c0.c + 4);
+                coeff_u.insert(coeff_u.end(), c1.c, c1.c + 4);
+                e += 2;
+            }
+        }
+    }
+    {
+        uint32_t dg[8];
+        T.write(coeff_u.data(), coeff_u.size());
+        p->h2.hash_elems(dg, coeff_u.data(), coeff_u.size());
+        T.commit(dg);
+    }
+    // ---- DEEP: mix every column into its combo, subtract the mixed u polynomials, divide ----
+    const Fp4 mix = T.random_ext();
+    if (hipMemsetAsync(p->combos.b.dptr, 0, p->combos.b.len * 4, c->stream) != hipSuccess) return perr(p, "bx_prove_segment: memset failed");
+    {
+        Fp4 cur = f4_one();
+        Fp4 combo_u[3][2] = {{f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}};
+        size_t u = 0;
+        for (int g = 0; g < 4; ++g) {
+            Group& G = p->groups[g];
+            PV(bx_mix_poly_coeffs(c, p->combos.b, cur.c, mix.c, G.coeffs.b, G.combo_ids.b, G.width, N));
+            for (uint32_t col = 0; col < G.width; ++col) {
+                int id = g == 3 ? 2 : (G.taps[col] == 2 ? 1 : 0);
+                for (uint32_t t = 0; t < G.taps[col]; ++t, u += 4) {
+                    Fp4 cu{{coeff_u[u], coeff_u[u + 1], coeff_u[u + 2], coeff_u[u + 3]}};
+                    combo_u[id][t] = f4_add(combo_u[id][t], f4_mul(cur, cu));
+                }
+                cur = f4_mul(cur, mix);
+            }
+        }
+        for (int id = 0; id < 3; ++id) {
+            uint32_t low[8];
+            bx_buf head = p->combos.slice((size_t)id * 4 * N, 8);
+            PV(bx_d2h(c, low, head, 8));
+            for (int t = 0; t < 2; ++t)
+                for (int k = 0; k < 4; ++k) low[4 * t + k] = fp_sub(low[4 * t + k], combo_u[id][t].c[k]);
+            PV(bx_h2d(c, head, low, 8));
+        }
+        PV(bx_poly_divide(c, p->combos.slice(0, 4 * N), Z.c, p->rems.slice(0, 4)));
+        PV(bx_poly_divide(c, p->combos.slice(4 * N, 4 * N), Z.c, p->rems.slice(4, 4)));
+        PV(bx_poly_divide(c, p->combos.slice(4 * N, 4 * N), Zb.c, p->rems.slice(8, 4)));
+        PV(bx_poly_divide(c, p->combos.slice(8 * N, 4 * N), Z4.c, p->rems.slice(12, 4)));
+        uint32_t rems[16];
+        PV(bx_d2h(c, rems, p->rems.b, 16));
+        for (int i = 0; i < 16; ++i)
+            if (rems[i] != 0) return perr(p, "bx_prove_segment: DEEP quotient has a non-zero remainder");
+    }
+    PV(bx_eltwise_sum_extelem(c, p->final_poly.b, p->combos.b));
+    PV(bx_batch_bit_reverse(c, p->final_poly.b, 4));
+
+    // ---- fri_prove ----
+    {
+        bx_buf coeffs = p->final_poly.b;
+        for (FriRound& r : p->rounds) {
+            PV(bx_batch_expand_into_evaluate_ntt(c, r.evaluated.b, coeffs, 4, 2));
+            PV(tree_commit(p, r.tree, r.evaluated.b, T));
+            Fp4 fold_mix = T.random_ext();
+            PV(bx_fri_fold(c, r.out_coeffs.b, coeffs, fold_mix.c));
+            coeffs = r.out_coeffs.b;
+        }
+        PV(bx_eltwise_copy_elem(c, p->final_coeffs.b, coeffs));
+        PV(bx_batch_bit_reverse(c, p->final_coeffs.b, 4));
+        std::vector<uint32_t> fc(p->final_coeffs.b.len);
+        uint32_t dg[8];
+        PV(bx_d2h(c, fc.data(), p->final_coeffs.b, fc.size()));
+        T.write(fc.data(), fc.size());
+        p->h2.hash_elems(dg, fc.data(), fc.size());
+        T.commit(dg);
+    }
+    // ---- queries: positions come only from the RNG (writes do not feed it), so draw all 50 first, gather each tree
+    //      for the whole batch on the device, then lay the seal out in upstream's query-major order ----
+    {
+        const unsigned bits = (unsigned)ilog2(D);
+        uint32_t pos0[BX_QUERIES];
+        for (int q = 0; q < BX_QUERIES; ++q) pos0[q] = T.random_bits(bits) % (uint32_t)D;
+        size_t n_trees = 4 + p->rounds.size();
+        std::vector<std::vector<uint32_t>> host(n_trees);
+        std::vector<size_t> qw(n_trees);
+        uint32_t pos[BX_QUERIES];
+        memcpy(pos, pos0, sizeof pos);
+        for (size_t t = 0; t < n_trees; ++t) {
+            Tree& tr = t < 4 ? p->groups[t].tree : p->rounds[t - 4].tree;
+            bx_buf matrix = t < 4 ? p->groups[t].evaluated.b : p->rounds[t - 4].evaluated.b;
+            if (t >= 4)
+                for (int q = 0; q < BX_QUERIES; ++q) pos[q] %= (uint32_t)tr.rows;  // group = pos % (domain / FRI_FOLD)
+            qw[t] = tr.query_words();
+            PV(bx_h2d(c, p->positions.b, pos, BX_QUERIES));
+            PV(bx_merkle_query_gather(c, p->qout.b, matrix, tr.nodes.b, tr.rows, tr.cols, p->positions.b, BX_QUERIES, tr.top_size()));
+            host[t].resize(qw[t] * BX_QUERIES);
+            PV(bx_d2h(c, host[t].data(), p->qout.b, host[t].size()));
+        }
+        for (int q = 0; q < BX_QUERIES; ++q)
+            for (size_t t = 0; t < n_trees; ++t) T.write(host[t].data() + (size_t)q * qw[t], qw[t]);
+    }
+    if (seal_words) *seal_words = T.seal.size();
+    if (T.seal.size() > seal_cap) return perr(p, "bx_prove_segment: seal buffer too small");
+    memcpy(seal_out, T.seal.data(), T.seal.size() * 4);
+    return nullptr;
+}

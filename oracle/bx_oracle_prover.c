@@ -1,2 +1,368 @@
-/* placeholder translation unit: the oracle's segment-skeleton prover lands here */
+/*
+ * bx_oracle_prover.c — CPU ORACLE of the segment-prover pipeline (test infrastructure only).
+ *
+ * Sequential restatement, on host arrays and with the oracle's own HAL functions (bx_oracle.c), of
+ *   risc0_zkp::prove::Prover::{commit_group, finalize}, prove::fri::fri_prove, prove::merkle::MerkleTreeProver,
+ *   prove::write_iop::WriteIOP and core::hash::poseidon2::Poseidon2Rng            [EXT: risc0-zkp 3.0.3]
+ * as driven by ProverServer::prove_segment (bento/crates/workflow/src/tasks/prove.rs:41-49).  The witness fill
+ * and the check polynomial are the synthetic stand-ins documented in include/bx_prover.h; everything else keeps
+ * upstream's order and constants.  Written straight-line (one query at a time, one layer at a time) so that it
+ * shares no structure with the product's batched device code.  Seal parity vs the Rust prover: UNPINNED (no
+ * circuit, no vectors in the reference); this oracle pins the product against an independent implementation.
+ */
+#include <stdlib.h>
+#include <string.h>
+
 #include "bx_oracle.h"
+
+#define QUERIES 50
+#define INV_RATE 4
+#define FRI_FOLD 16
+#define FRI_MIN_DEGREE 256
+#define CHECK_SIZE 16
+#define GOLDEN 0x9E3779B97F4A7C15ull
+
+typedef struct { uint32_t c[4]; } e4;
+
+/* ---- transcript: WriteIOP + Poseidon2Rng ---- */
+typedef struct {
+    uint32_t* seal;
+    size_t len, cap;
+    uint32_t cells[24];
+    unsigned pool_used;
+} iop_t;
+static void iop_write(iop_t* io, const uint32_t* w, size_t n) {
+    if (io->len + n > io->cap) {
+        io->cap = (io->len + n) * 2;
+        io->seal = (uint32_t*)realloc(io->seal, io->cap * 4);
+    }
+    memcpy(io->seal + io->len, w, n * 4);
+    io->len += n;
+}
+/* [EXT] Poseidon2Rng::mix */
+static void iop_commit(iop_t* io, const uint32_t d[8]) {
+    if (io->pool_used != 0) {
+        bxo_poseidon2_mix(io->cells);
+        io->pool_used = 0;
+    }
+    for (int i = 0; i < 8; i++) io->cells[i] = bxo_fp_add(io->cells[i], d[i]);
+    bxo_poseidon2_mix(io->cells);
+}
+/* [EXT] Poseidon2Rng::random_elem */
+static uint32_t iop_random_elem(iop_t* io) {
+    if (io->pool_used == BXO_RATE) {
+        bxo_poseidon2_mix(io->cells);
+        io->pool_used = 0;
+    }
+    return io->cells[io->pool_used++];
+}
+static e4 iop_random_ext(iop_t* io) {
+    e4 r;
+    for (int k = 0; k < 4; k++) r.c[k] = iop_random_elem(io);
+    return r;
+}
+/* [EXT] Poseidon2Rng::random_bits */
+static uint32_t iop_random_bits(iop_t* io, unsigned bits) {
+    uint32_t val = bxo_fp_decode(iop_random_elem(io));
+    for (int i = 0; i < 3; i++) {
+        uint32_t nv = bxo_fp_decode(iop_random_elem(io));
+        if (val == 0) val = nv;
+    }
+    return val & (uint32_t)(((uint64_t)1 << bits) - 1);
+}
+
+/* ---- ext helpers on top of the oracle field ---- */
+static e4 e4mul(e4 a, e4 b) { e4 r; bxo_fp4_mul(r.c, a.c, b.c); return r; }
+static e4 e4inv(e4 a) { e4 r; bxo_fp4_inv(r.c, a.c); return r; }
+
+static e4 e4sub(e4 a, e4 b) { e4 r; for (int k = 0; k < 4; k++) r.c[k] = bxo_fp_sub(a.c[k], b.c[k]); return r; }
+static e4 e4scale(e4 a, uint32_t s) { e4 r; for (int k = 0; k < 4; k++) r.c[k] = bxo_fp_mul(a.c[k], s); return r; }
+static e4 e4one(void) { e4 r = {{bxo_fp_encode(1), 0, 0, 0}}; return r; }
+
+
+/* ---- synthetic witness (stand-in for witgen; same definition as include/bx_prover.h) ---- */
+static uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + GOLDEN;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
+    uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
+    return v >= BXO_P ? v - BXO_P : v;
+}
+
+/* ---- MerkleTreeProver ---- */
+typedef struct {
+    size_t rows, cols;
+    unsigned layers, top_layer;
+    uint32_t* nodes;         /* 2*rows digests */
+    const uint32_t* matrix;  /* rows x cols column-major */
+} tree_t;
+static unsigned ilog2sz(size_t n) { unsigned k = 0; while (((size_t)1 << k) < n) k++; return k; }
+/* [EXT] MerkleTreeParams::new + MerkleTreeProver::new */
+static void tree_build(tree_t* t, const uint32_t* matrix, size_t rows, size_t cols) {
+    t->rows = rows;
+    t->cols = cols;
+    t->matrix = matrix;
+    t->layers = ilog2sz(rows);
+    t->top_layer = 0;
+    for (unsigned i = 1; i < t->layers; i++) {
+        if (((size_t)1 << i) > QUERIES) break;
+        t->top_layer = i;
+    }
+    t->nodes = (uint32_t*)calloc(16 * rows, 4);
+    bxo_hash_rows(t->nodes + 8 * rows, matrix, rows, cols);
+    for (unsigned i = t->layers; i-- > 0;) bxo_hash_fold(t->nodes, (size_t)2 << i, (size_t)1 << i);
+}
+/* [EXT] MerkleTreeProver::commit */
+static void tree_commit(tree_t* t, iop_t* io) {
+    size_t top = (size_t)1 << t->top_layer;
+    iop_write(io, t->nodes + 8 * top, 8 * top);
+    iop_commit(io, t->nodes + 8);
+}
+/* [EXT] MerkleTreeProver::prove */
+static void tree_prove(const tree_t* t, iop_t* io, size_t idx) {
+    size_t top = (size_t)1 << t->top_layer;
+    uint32_t* col = (uint32_t*)malloc(t->cols * 4);
+    bxo_gather_sample(col, t->matrix, idx, t->cols, t->rows);
+    iop_write(io, col, t->cols);
+    free(col);
+    idx += t->rows;
+    while (idx >= 2 * top) {
+        size_t low = idx & 1;
+        idx >>= 1;
+        iop_write(io, t->nodes + 8 * (2 * idx + (1 - low)), 8);
+    }
+}
+
+/* ---- PolyGroup ---- */
+typedef struct {
+    uint32_t width;
+    uint32_t* coeffs;     /* width x N, natural-order coefficients after the bit reverse */
+    uint32_t* evaluated;  /* width x 4N */
+    tree_t tree;
+    uint32_t* taps;       /* taps per column */
+} group_t;
+/* [EXT] Prover::commit_group + PolyGroup::new; `coeffs` holds the witness evaluations on entry */
+static void commit_group(group_t* g, size_t n, iop_t* io) {
+    bxo_batch_interpolate_ntt(g->coeffs, g->width, n);
+    bxo_zk_shift(g->coeffs, g->width, n);
+    g->evaluated = (uint32_t*)malloc((size_t)g->width * 4 * n * 4);
+    bxo_batch_expand_into_evaluate_ntt(g->evaluated, g->coeffs, g->width, n, 2);
+    bxo_batch_bit_reverse(g->coeffs, g->width, n);
+    tree_build(&g->tree, g->evaluated, 4 * n, g->width);
+    tree_commit(&g->tree, io);
+}
+static void group_free(group_t* g) {
+    free(g->coeffs);
+    free(g->evaluated);
+    free(g->tree.nodes);
+    free(g->taps);
+}
+
+/* Returns a malloc'ed seal (caller frees with bxo_free) or NULL on an internal consistency failure. */
+uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
+                            size_t* seal_words, uint32_t roots_out[32]) {
+    bxo_init();
+    const size_t n = (size_t)1 << po2, dom = 4 * n;
+    const uint32_t widths[4] = {w_code, w_data, w_accum, CHECK_SIZE};
+    iop_t io;
+    memset(&io, 0, sizeof io);
+    group_t grp[4];
+    memset(grp, 0, sizeof grp);
+
+    /* header */
+    {
+        uint32_t hdr[4] = {po2, w_code, w_data, w_accum}, enc[4], dg[8];
+        for (int i = 0; i < 4; i++) enc[i] = bxo_fp_encode(hdr[i]);
+        iop_write(&io, hdr, 4);
+        bxo_hash_elem_slice(dg, enc, 4, 1);
+        iop_commit(&io, dg);
+    }
+    /* trace groups */
+    for (int g = 0; g < 3; g++) {
+        group_t* G = &grp[g];
+        G->width = widths[g];
+        uint64_t gseed = seed + GOLDEN * (uint64_t)(g + 1);
+        if (g == 2) {
+            e4 am = iop_random_ext(&io);
+            gseed ^= ((uint64_t)am.c[0] << 32) | am.c[1];
+        }
+        G->coeffs = (uint32_t*)malloc((size_t)G->width * n * 4);
+        for (uint32_t c = 0; c < G->width; c++)
+            for (size_t r = 0; r < n; r++) G->coeffs[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
+        G->taps = (uint32_t*)malloc(G->width * 4);
+        for (uint32_t c = 0; c < G->width; c++) G->taps[c] = (g != 0 && c % 4 == 0) ? 2 : 1;
+        commit_group(G, n, &io);
+        if (roots_out) memcpy(roots_out + 8 * g, G->tree.nodes + 8, 32);
+    }
+    /* check polynomial: check(r) = sum_c mix^c (e_c^3 + e_c) over all trace columns, on the 4N domain */
+    group_t* CK = &grp[3];
+    {
+        CK->width = CHECK_SIZE;
+        e4 poly_mix = iop_random_ext(&io);
+        uint32_t* check = (uint32_t*)calloc(16 * n, 4); /* 4 planes x 4N */
+        e4 cur = e4one();
+        for (int g = 0; g < 3; g++)
+            for (uint32_t c = 0; c < grp[g].width; c++) {
+                const uint32_t* e = grp[g].evaluated + (size_t)c * dom;
+                _Pragma("omp parallel for schedule(static) num_threads(bxo_get_threads())")
+                for (size_t r = 0; r < dom; r++) {
+                    uint32_t v = e[r];
+                    uint32_t t = bxo_fp_add(bxo_fp_mul(bxo_fp_mul(v, v), v), v);
+                    for (int k = 0; k < 4; k++) check[(size_t)k * dom + r] = bxo_fp_add(check[(size_t)k * dom + r], bxo_fp_mul(cur.c[k], t));
+                }
+                cur = e4mul(cur, poly_mix);
+            }
+        bxo_batch_interpolate_ntt(check, 4, dom);
+        CK->coeffs = check; /* now viewed as 16 polynomials of size n */
+        CK->taps = (uint32_t*)malloc(CHECK_SIZE * 4);
+        for (int c = 0; c < CHECK_SIZE; c++) CK->taps[c] = 1;
+        bxo_zk_shift(CK->coeffs, CHECK_SIZE, n);
+        CK->evaluated = (uint32_t*)malloc((size_t)CHECK_SIZE * dom * 4);
+        bxo_batch_expand_into_evaluate_ntt(CK->evaluated, CK->coeffs, CHECK_SIZE, n, 2);
+        bxo_batch_bit_reverse(CK->coeffs, CHECK_SIZE, n);
+        tree_build(&CK->tree, CK->evaluated, dom, CHECK_SIZE);
+        tree_commit(&CK->tree, &io);
+        if (roots_out) memcpy(roots_out + 24, CK->tree.nodes + 8, 32);
+    }
+    /* DEEP: taps */
+    e4 Z = iop_random_ext(&io);
+    e4 Zb = e4scale(Z, bxo_rou_rev(po2));
+    e4 Z4 = e4mul(e4mul(Z, Z), e4mul(Z, Z));
+    size_t total_taps = 0;
+    for (int g = 0; g < 4; g++)
+        for (uint32_t c = 0; c < grp[g].width; c++) total_taps += grp[g].taps[c];
+    uint32_t* coeff_u = (uint32_t*)malloc(total_taps * 16);
+    {
+        size_t u = 0;
+        for (int g = 0; g < 4; g++) {
+            /* one batch_evaluate_any per group, like upstream (which = column, xs = Z * back_one^back) */
+            size_t ne = 0;
+            for (uint32_t c = 0; c < grp[g].width; c++) ne += grp[g].taps[c];
+            uint32_t* which = (uint32_t*)malloc(ne * 4);
+            uint32_t* xs = (uint32_t*)malloc(ne * 16);
+            uint32_t* ev = (uint32_t*)malloc(ne * 16);
+            size_t e = 0;
+            for (uint32_t c = 0; c < grp[g].width; c++)
+                for (uint32_t t = 0; t < grp[g].taps[c]; t++, e++) {
+                    which[e] = c;
+                    memcpy(xs + 4 * e, g == 3 ? Z4.c : (t == 0 ? Z.c : Zb.c), 16);
+                }
+            bxo_batch_evaluate_any(grp[g].coeffs, n, which, xs, ev, ne);
+            e = 0;
+            for (uint32_t c = 0; c < grp[g].width; c++) {
+                e4 y0, y1;
+                memcpy(y0.c, ev + 4 * e, 16);
+                if (grp[g].taps[c] == 1) {
+                    memcpy(coeff_u + u, y0.c, 16);
+                    u += 4;
+                    e += 1;
+                } else {
+                    memcpy(y1.c, ev + 4 * e + 4, 16);
+                    e4 c1 = e4mul(e4sub(y1, y0), e4inv(e4sub(Zb, Z)));
+                    e4 c0 = e4sub(y0, e4mul(c1, Z));
+                    memcpy(coeff_u + u, c0.c, 16);
+                    memcpy(coeff_u + u + 4, c1.c, 16);
+                    u += 8;
+                    e += 2;
+                }
+            }
+            free(which);
+            free(xs);
+            free(ev);
+        }
+        uint32_t dg[8];
+        iop_write(&io, coeff_u, 4 * total_taps);
+        bxo_hash_elem_slice(dg, coeff_u, 4 * total_taps, 1);
+        iop_commit(&io, dg);
+    }
+    /* DEEP: mix, subtract u, divide */
+    e4 mix = iop_random_ext(&io);
+    uint32_t* combos = (uint32_t*)calloc(3 * 4 * n, 4);
+    int ok = 1;
+    {
+        e4 cur = e4one();
+        size_t u = 0;
+        for (int g = 0; g < 4; g++) {
+            uint32_t* ids = (uint32_t*)malloc(grp[g].width * 4);
+            for (uint32_t c = 0; c < grp[g].width; c++) ids[c] = g == 3 ? 2u : (grp[g].taps[c] == 2 ? 1u : 0u);
+            bxo_mix_poly_coeffs(combos, cur.c, mix.c, grp[g].coeffs, ids, grp[g].width, n);
+            for (uint32_t c = 0; c < grp[g].width; c++) {
+                uint32_t* target = combos + (size_t)ids[c] * 4 * n;
+                for (uint32_t t = 0; t < grp[g].taps[c]; t++, u += 4) {
+                    e4 cu;
+                    memcpy(cu.c, coeff_u + u, 16);
+                    e4 m = e4mul(cur, cu);
+                    for (int k = 0; k < 4; k++) target[4 * t + k] = bxo_fp_sub(target[4 * t + k], m.c[k]);
+                }
+                cur = e4mul(cur, mix);
+            }
+            free(ids);
+        }
+        uint32_t rem[4];
+        ok &= bxo_poly_divide(combos, n, Z.c, rem);
+        ok &= bxo_poly_divide(combos + 4 * n, n, Z.c, rem);
+        ok &= bxo_poly_divide(combos + 4 * n, n, Zb.c, rem);
+        ok &= bxo_poly_divide(combos + 8 * n, n, Z4.c, rem);
+    }
+    uint32_t* fin = (uint32_t*)malloc(4 * n * 4);
+    bxo_eltwise_sum_extelem(fin, combos, n, 3);
+    bxo_batch_bit_reverse(fin, 4, n);
+    free(combos);
+    free(coeff_u);
+
+    /* fri_prove */
+    size_t n_rounds = 0;
+    for (size_t s = n; s > FRI_MIN_DEGREE; s /= FRI_FOLD) n_rounds++;
+    tree_t* rt = (tree_t*)calloc(n_rounds ? n_rounds : 1, sizeof(tree_t));
+    uint32_t** revals = (uint32_t**)calloc(n_rounds ? n_rounds : 1, sizeof(uint32_t*));
+    uint32_t* coeffs = fin;
+    size_t size = n;
+    for (size_t r = 0; r < n_rounds; r++) {
+        size_t domain = size * INV_RATE;
+        revals[r] = (uint32_t*)malloc(4 * domain * 4);
+        bxo_batch_expand_into_evaluate_ntt(revals[r], coeffs, 4, size, 2);
+        tree_build(&rt[r], revals[r], domain / FRI_FOLD, FRI_FOLD * 4);
+        tree_commit(&rt[r], &io);
+        e4 fold_mix = iop_random_ext(&io);
+        uint32_t* out = (uint32_t*)malloc(4 * (size / FRI_FOLD) * 4);
+        bxo_fri_fold(out, coeffs, fold_mix.c, size / FRI_FOLD);
+        free(coeffs);
+        coeffs = out;
+        size /= FRI_FOLD;
+    }
+    {
+        bxo_batch_bit_reverse(coeffs, 4, size);
+        uint32_t dg[8];
+        iop_write(&io, coeffs, 4 * size);
+        bxo_hash_elem_slice(dg, coeffs, 4 * size, 1);
+        iop_commit(&io, dg);
+        free(coeffs);
+    }
+    for (int q = 0; q < QUERIES; q++) {
+        uint32_t rng = iop_random_bits(&io, ilog2sz(dom));
+        size_t pos = rng % dom;
+        for (int g = 0; g < 4; g++) tree_prove(&grp[g].tree, &io, pos);
+        for (size_t r = 0; r < n_rounds; r++) {
+            size_t group = pos % rt[r].rows;
+            tree_prove(&rt[r], &io, group);
+            pos = group;
+        }
+    }
+    for (size_t r = 0; r < n_rounds; r++) {
+        free(rt[r].nodes);
+        free(revals[r]);
+    }
+    free(rt);
+    free(revals);
+    for (int g = 0; g < 4; g++) group_free(&grp[g]);
+    if (!ok) {
+        free(io.seal);
+        return NULL;
+    }
+    *seal_words = io.len;
+    return io.seal;
+}
+void bxo_free(void* p) { free(p); }

@@ -69,6 +69,8 @@ def lib(path=None):
         "bxo_eltwise_zeroize": ([u32p, sz], None),
         "bxo_gather_sample": ([u32p, u32p, sz, sz, sz], None),
         "bxo_poly_divide": ([u32p, sz, u32p, u32p], C.c_int),
+        "bxo_prove_segment": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
+        "bxo_free": ([C.c_void_p], None),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -99,3 +101,16 @@ def decode(m):
 def random_elems(rng, shape):
     """uniform field elements as Montgomery words (any word < P is a valid Montgomery element)"""
     return rng.integers(0, P, size=shape, dtype=np.uint32)
+
+
+def prove_segment(po2, w_code, w_data, w_accum, seed, L=None):
+    """Run the oracle's segment prover; returns (seal as uint32 array, roots[4][8])."""
+    L = L or lib()
+    n = C.c_size_t(0)
+    roots = np.zeros(32, np.uint32)
+    ptr = L.bxo_prove_segment(po2, w_code, w_data, w_accum, seed, C.byref(n), roots)
+    if not ptr:
+        raise RuntimeError("oracle prover: DEEP remainder non-zero")
+    seal = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+    L.bxo_free(ptr)
+    return seal, roots.reshape(4, 8)

@@ -1,0 +1,29 @@
+"""CPU: the oracle's segment prover is self-consistent (DEEP quotients exact, deterministic, seal layout)."""
+import numpy as np
+
+from oracle import oracle_lib as ol
+
+
+def test_oracle_prover_runs_and_is_deterministic():
+    a, ra = ol.prove_segment(10, 4, 8, 4, 1234)
+    b, rb = ol.prove_segment(10, 4, 8, 4, 1234)
+    c, _ = ol.prove_segment(10, 4, 8, 4, 1235)
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
+    assert not np.array_equal(a, c)
+    assert a[:4].tolist() == [10, 4, 8, 4]
+    # layout: header 4 | 4 trace tops (32 digests each) | coeff_u | fri tops | final coeffs | 50 queries
+    n = 1 << 10
+    taps = 4 + (8 + 2) + (4 + 1) + 16
+    rows_fri = 4 * n // 16
+    per_query = sum(w + 8 * (12 - 5) for w in (4, 8, 4, 16)) + (64 + 8 * (8 - 5))
+    expect = 4 + 4 * 32 * 8 + 4 * taps + 32 * 8 + 4 * (n // 16) + 50 * per_query
+    assert rows_fri == 256 and a.size == expect
+
+
+def test_oracle_prover_threads_do_not_change_the_seal():
+    L = ol.lib()
+    L.bxo_set_threads(1)
+    a, _ = ol.prove_segment(9, 2, 3, 2, 9)
+    L.bxo_set_threads(0)
+    b, _ = ol.prove_segment(9, 2, 3, 2, 9)
+    assert np.array_equal(a, b)
