@@ -87,9 +87,22 @@ static inline unsigned top_layer_of(unsigned layers) {
     return top;
 }
 
-struct DevBuf {
+struct DevBuf {  // owning device allocation; movable, not copyable
     bx_ctx* c = nullptr;
     bx_buf b{nullptr, 0};
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : c(o.c), b(o.b) { o.b = bx_buf{nullptr, 0}; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            if (b.dptr) (void)hipFree(b.dptr);
+            c = o.c;
+            b = o.b;
+            o.b = bx_buf{nullptr, 0};
+        }
+        return *this;
+    }
     const char* alloc(bx_ctx* ctx, size_t words) {
         c = ctx;
         return bx_alloc(ctx, words, &b);
@@ -256,6 +269,7 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     // FRI rounds
     size_t size = N;
     size_t fri_query_words = 0;
+    p->rounds.reserve(8);
     while (size > BX_FRI_MIN_DEGREE) {
         p->rounds.emplace_back();
         FriRound& r = p->rounds.back();
