@@ -66,7 +66,11 @@ struct bx_ctx {
     // tunables
     long ntt_block_log = 12;   // log2 of the contiguous-pass sub-transform (13 when the size needs it)
     long ntt_tile_log = 14;    // log2 of the strided-pass LDS tile (elements)
+    long ntt_fast = 1;         // 1 = register-radix-16 passes (ntt_r16.hpp), 0 = one-stage-per-barrier v1 kernels
+    long ntt_tile_a_log = 12;  // log2 elements per pass-A workgroup (fast path)
+    long ntt_tile_b_log = 13;  // log2 elements per pass-B workgroup (fast path)
     long hash_rows_block = 256;
+    long fold_fuse_below = 1 << 15;  // Merkle layers with at most this many inputs are folded 9 levels per launch
 
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -235,6 +235,17 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
     } else if (!strcmp(name, "hash_rows_block")) {
         BX_REQUIRE(c, value == 64 || value == 128 || value == 256, "hash_rows_block must be 64, 128 or 256");
         c->hash_rows_block = value;
+    } else if (!strcmp(name, "ntt_fast")) {
+        c->ntt_fast = value != 0;
+    } else if (!strcmp(name, "ntt_tile_a_log")) {
+        BX_REQUIRE(c, value >= 10 && value <= 13, "ntt_tile_a_log out of range [10,13]");
+        c->ntt_tile_a_log = value;
+    } else if (!strcmp(name, "ntt_tile_b_log")) {
+        BX_REQUIRE(c, value >= 10 && value <= 13, "ntt_tile_b_log out of range [10,13]");
+        c->ntt_tile_b_log = value;
+    } else if (!strcmp(name, "fold_fuse_below")) {
+        BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
+        c->fold_fuse_below = value;
     } else {
         return set_msg(c, "bx_set_tunable: unknown tunable");
     }

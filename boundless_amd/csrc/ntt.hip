@@ -17,6 +17,7 @@
 // Inverse (interpolate) = B then A.  Each pass moves every element HBM->LDS->HBM once: 2 reads + 2 writes per
 // element for m <= 26 instead of m reads/writes.  Sizes with m <= m_hi need pass A only.
 #include "ctx.hpp"
+#include "ntt_r16.hpp"
 
 namespace bx {
 
@@ -253,6 +254,59 @@ static const char* allow_lds(bx_ctx* c, K kernel, size_t bytes) {
 }
 
 // forward transform of `count` columns: in (size M >> expand_bits per column) -> out (size M per column).
+// ---- register-radix-16 fast path (ntt_r16.hpp) -------------------------------------------------------------
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <bool INV, bool PASS_A, int SKIP>
+static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
+    uint32_t tile_elems = 1u << (a.lrows + a.lt);
+    size_t lds = ((size_t)tile_elems + (tile_elems >> 4) + ((size_t)1 << a.lr)) * 4;
+    BX_TRY(allow_lds(c, ntt_r16_kernel<INV, PASS_A, SKIP>, lds));
+    hipLaunchKernelGGL((ntt_r16_kernel<INV, PASS_A, SKIP>), dim3(a.tiles, (unsigned)count), dim3(tile_elems / 16), lds, c->stream, a);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+// pass A over `count` columns of size 2^m made of 2^(m - m_hi) blocks; returns false in *ok if the shape is not covered
+static const char* fast_pass_a(bx_ctx* c, bool inv, uint32_t* out, const uint32_t* in, const uint32_t* twist, uint32_t scale,
+                               size_t count, int m, int m_hi, int expand, int skip, bool* ok) {
+    *ok = false;
+    int lrows = (int)c->ntt_tile_a_log;
+    if (lrows < m_hi) lrows = m_hi;
+    if (lrows > m) lrows = m;
+    if (lrows < 10 || m_hi < 1 || m_hi > TW_LOG) return nullptr;  // tile must fill at least one wave (16 elements/lane)
+    if (!aligned16(out) || !aligned16(in) || (((size_t)1 << m) >> expand) % 4 != 0) return nullptr;
+    if (!(skip == 0 || (skip == 2 && !inv))) return nullptr;
+    R16Args a;
+    a.out = out; a.in = in; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.twist = twist; a.scale = scale;
+    a.lr = m_hi; a.lrows = lrows; a.lt = 0; a.expand = expand; a.row_shift = 0;
+    a.tile_stride = 1u << lrows;
+    a.in_col_stride = ((size_t)1 << m) >> expand; a.out_col_stride = (size_t)1 << m;
+    a.tiles = 1u << (m - lrows);
+    *ok = true;
+    if (inv) return launch_r16<true, true, 0>(c, a, count);
+    if (skip == 2) return launch_r16<false, true, 2>(c, a, count);
+    return launch_r16<false, true, 0>(c, a, count);
+}
+static const char* fast_pass_b(bx_ctx* c, bool inv, uint32_t* io, size_t count, int m, int m_hi, bool* ok) {
+    *ok = false;
+    int m_lo = m - m_hi;
+    int tile = (int)c->ntt_tile_b_log;
+    if (tile < m_lo) tile = m_lo;
+    int lt = tile - m_lo;
+    if (lt > m_hi) lt = m_hi;
+    if (m_lo + lt < 10 || m_lo < 1 || m_lo > TW_LOG || m_lo + lt > 13) return nullptr;
+    R16Args a;
+    a.out = io; a.in = io; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.twist = nullptr; a.scale = MONT_ONE;
+    a.lr = m_lo; a.lrows = m_lo; a.lt = lt; a.expand = 0; a.row_shift = m_hi;
+    a.tile_stride = 1u << lt;
+    a.in_col_stride = a.out_col_stride = (size_t)1 << m;
+    a.tiles = 1u << (m_hi - lt);
+    *ok = true;
+    if (inv) return launch_r16<true, false, 0>(c, a, count);
+    return launch_r16<false, false, 0>(c, a, count);
+}
+
 // `expand_bits` = load shift (out[i] = in[i >> bits]); `skip_bits` = leading stages skipped (== expand_bits for the
 // expanding form, and for the in-place Hal::batch_evaluate_ntt(io, count, expand_bits) with no load shift).
 static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t count, int m, int expand_bits,
@@ -267,7 +321,9 @@ static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t 
     size_t M = (size_t)1 << m;
     uint32_t* twist = nullptr;
     if (sp.m_lo) BX_TRY(get_twist(c, m, sp.m_hi, false, &twist));
-    {
+    bool done_a = false, done_b = false;
+    if (c->ntt_fast) BX_TRY(fast_pass_a(c, false, out, in, twist, MONT_ONE, count, m, sp.m_hi, expand_bits, skip_bits, &done_a));
+    if (!done_a) {
         unsigned R = 1u << sp.m_hi;
         unsigned threads = R / 2 < 64 ? 64 : (R / 2 > 256 ? 256 : R / 2);
         size_t lds = (size_t)R * 8;
@@ -276,7 +332,8 @@ static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t 
                            in, c->d_tw_fwd, twist, MONT_ONE, sp.m_hi, expand_bits, skip_bits + 1, M >> expand_bits, M);
         BX_LAUNCH_CHECK(c);
     }
-    if (sp.m_lo) {
+    if (sp.m_lo && c->ntt_fast) BX_TRY(fast_pass_b(c, false, out, count, m, sp.m_hi, &done_b));
+    if (sp.m_lo && !done_b) {
         unsigned rows = 1u << sp.m_lo;
         unsigned total = rows << sp.lt;
         unsigned threads = total / 2 > 1024 ? 1024 : (total / 2 < 64 ? 64 : total / 2);
@@ -297,8 +354,10 @@ static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m) {
     BX_REQUIRE(c, sp.m_hi <= TW_LOG && sp.m_lo <= TW_LOG, "ntt: size too large");
     size_t M = (size_t)1 << m;
     uint32_t* twist = nullptr;
-    if (sp.m_lo) {
-        BX_TRY(get_twist(c, m, sp.m_hi, true, &twist));
+    bool done_a = false, done_b = false;
+    if (sp.m_lo) BX_TRY(get_twist(c, m, sp.m_hi, true, &twist));
+    if (sp.m_lo && c->ntt_fast) BX_TRY(fast_pass_b(c, true, io, count, m, sp.m_hi, &done_b));
+    if (sp.m_lo && !done_b) {
         unsigned rows = 1u << sp.m_lo;
         unsigned total = rows << sp.lt;
         unsigned threads = total / 2 > 1024 ? 1024 : (total / 2 < 64 ? 64 : total / 2);
@@ -310,11 +369,12 @@ static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m) {
                            c->d_tw_inv, sp.m_lo, sp.lt, sp.m_hi, M, tiles);
         BX_LAUNCH_CHECK(c);
     }
-    {
+    uint32_t scale = fp_inv(fp_encode((uint32_t)M));
+    if (c->ntt_fast) BX_TRY(fast_pass_a(c, true, io, io, twist, scale, count, m, sp.m_hi, 0, 0, &done_a));
+    if (!done_a) {
         unsigned R = 1u << sp.m_hi;
         unsigned threads = R / 2 < 64 ? 64 : (R / 2 > 256 ? 256 : R / 2);
         size_t lds = (size_t)R * 8;
-        uint32_t scale = fp_inv(fp_encode((uint32_t)M));
         BX_TRY(allow_lds(c, ntt_block_kernel<true>, lds));
         hipLaunchKernelGGL(ntt_block_kernel<true>, dim3(1u << sp.m_lo, (unsigned)count), dim3(threads), lds, c->stream, io,
                            io, c->d_tw_inv, twist, scale, sp.m_hi, 0, 1, M, M);

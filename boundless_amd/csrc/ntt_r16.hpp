@@ -1,0 +1,286 @@
+// ntt_r16.hpp — register-resident radix-16 NTT passes for gfx950 (included by ntt.hip).
+//
+// The measured bound of this path is VALU issue: a radix-2 butterfly is ~11 integer instructions and
+// everything else (LDS traffic, index arithmetic, barriers) is overhead on the same issue port.  The v1 kernels did one
+// stage per LDS round trip (2 reads + 2 writes + twiddle read + index math per butterfly).  Here every thread keeps
+// 16 elements in VGPRs and runs up to four consecutive stages on them ("step"); LDS is touched only to regroup
+// elements between steps, the first step is fed straight from global memory and the last one stores straight back:
+// for a 2^12 sub-transform that is 2 LDS writes + 2 LDS reads per element instead of 24 + 24.
+//
+// Tile = 2^lrows rows x 2^lt adjacent columns, `lr` <= lrows radix-2 stages along the row index:
+//   pass A (contiguous blocks)  lt = 0, rows are consecutive words, several 2^lr blocks per tile when lr < lrows;
+//   pass B (across blocks)      rows are 2^row_shift words apart, T = 2^lt adjacent positions side by side.
+// Step (s0, K) runs stages s0+1 .. s0+K: row = hi * 2^(s0+K) + mid * 2^s0 + lo; a "unit" (hi, lo, t) owns the 2^K
+// elements mid = 0..2^K-1; a thread owns 16 / 2^K units, enumerated so that consecutive lanes take consecutive
+// (t, lo) — global accesses coalesce and LDS accesses (layout i + (i >> 4)) are conflict-free or 2-way.
+// Stage-s twiddles w_{2^s}^e are read from the LDS copy of the stage table at [2^(s-1) + e].
+#pragma once
+#include "ctx.hpp"
+
+namespace bx {
+
+struct R16Args {
+    uint32_t* out;
+    const uint32_t* in;
+    const uint32_t* tw;     // stage table (forward or inverse roots)
+    const uint32_t* twist;  // pass A only: per-element factor (nullptr = none)
+    uint32_t scale;         // pass A inverse without twist: 1/M
+    int lr, lrows, lt;
+    int expand;     // pass A forward: load shift (out[i] = in[i >> expand])
+    int row_shift;  // log2 of the global distance between consecutive rows (0 for pass A)
+    uint32_t tile_stride;  // words between consecutive tiles (pass A: tile size, pass B: T)
+    size_t in_col_stride, out_col_stride;
+    uint32_t tiles;
+};
+
+__device__ __forceinline__ uint32_t lds_phys(uint32_t i) { return i + (i >> 4); }
+
+template <bool INV>
+__device__ __forceinline__ void bfly_tw(uint32_t& a, uint32_t& b, uint32_t w) {
+    if (!INV) {
+        uint32_t t = fp_mul(b, w);
+        b = fp_sub(a, t);
+        a = fp_add(a, t);
+    } else {
+        uint32_t u = fp_add(a, b);
+        b = fp_mul(fp_sub(a, b), w);
+        a = u;
+    }
+}
+__device__ __forceinline__ void bfly_one(uint32_t& a, uint32_t& b) {
+    uint32_t u = fp_add(a, b);
+    b = fp_sub(a, b);
+    a = u;
+}
+
+// the K stages of one step on the thread's 16 registers
+template <int K, bool INV, bool S0ZERO, int SKIP>
+__device__ __forceinline__ void step_compute(uint32_t (&x)[16], const uint32_t* __restrict__ ltw, int s0, int lt, uint32_t tid,
+                                             uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        const uint32_t rl = (tid + nt * w) >> lt;
+        const uint32_t lo = S0ZERO ? 0u : (rl & ((1u << s0) - 1u));
+        uint32_t* xu = &x[w * E];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int k = INV ? K - kk : kk + 1;  // DIT ascends, DIF descends
+            if (k <= SKIP) continue;
+            const int half = 1 << (k - 1);
+#pragma unroll
+            for (int jj = 0; jj < half; ++jj) {
+                if (S0ZERO && jj == 0) {
+#pragma unroll
+                    for (int j = 0; j < E; j += 2 * half) bfly_one(xu[j], xu[j + half]);
+                } else {
+                    const uint32_t wv = ltw[(1u << (s0 + k - 1)) + lo + ((uint32_t)jj << s0)];
+#pragma unroll
+                    for (int j = jj; j < E; j += 2 * half) bfly_tw<INV>(xu[j], xu[j + half], wv);
+                }
+            }
+        }
+    }
+}
+
+// row/col of register (w, mid) for step (s0, K)
+template <int K>
+__device__ __forceinline__ void unit_coords(int w, int s0, int lt, uint32_t tid, uint32_t nt, uint32_t& base_row, uint32_t& t) {
+    const uint32_t q = tid + nt * w;
+    t = q & ((1u << lt) - 1u);
+    const uint32_t rl = q >> lt;
+    const uint32_t lo = rl & ((1u << s0) - 1u);
+    const uint32_t hi = rl >> s0;
+    base_row = (hi << (s0 + K)) | lo;
+}
+
+template <int K>
+__device__ __forceinline__ void lds_put(const uint32_t (&x)[16], uint32_t* __restrict__ s, int s0, int lt, uint32_t tid, uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        uint32_t base_row, t;
+        unit_coords<K>(w, s0, lt, tid, nt, base_row, t);
+#pragma unroll
+        for (int mid = 0; mid < E; ++mid) s[lds_phys(((base_row + ((uint32_t)mid << s0)) << lt) | t)] = x[w * E + mid];
+    }
+}
+template <int K>
+__device__ __forceinline__ void lds_get(uint32_t (&x)[16], const uint32_t* __restrict__ s, int s0, int lt, uint32_t tid, uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        uint32_t base_row, t;
+        unit_coords<K>(w, s0, lt, tid, nt, base_row, t);
+#pragma unroll
+        for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[lds_phys(((base_row + ((uint32_t)mid << s0)) << lt) | t)];
+    }
+}
+
+// global <-> registers for step (s0, K).  PASS_A: rows are consecutive words (lt == 0) and the twist/scale/expand apply.
+template <int K, bool INV, bool PASS_A>
+__device__ __forceinline__ void glb_get(uint32_t (&x)[16], const R16Args& a, const uint32_t* __restrict__ src, size_t tile_off, int s0,
+                                        uint32_t tid, uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+    if (PASS_A && !INV && K == 4 && s0 == 0 && (a.expand == 0 || a.expand == 2)) {
+        // 16 consecutive words per thread: wide loads (one dwordx4 per thread when expanding by 4)
+        const size_t g = tile_off + (size_t)tid * 16;
+        if (a.expand == 2) {
+            uint4 v = *reinterpret_cast<const uint4*>(src + (g >> 2));
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = vv[i >> 2];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 v = reinterpret_cast<const uint4*>(src + g)[i];
+                x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        uint32_t base_row, t;
+        unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+#pragma unroll
+        for (int mid = 0; mid < E; ++mid) {
+            // 32-bit offsets from wave-uniform bases keep one VGPR per address
+            const uint32_t off = ((base_row + ((uint32_t)mid << s0)) << a.row_shift) + t;
+            uint32_t v = PASS_A ? src[(tile_off >> a.expand) + (off >> a.expand)] : (src + tile_off)[off];
+            if (PASS_A && INV) v = fp_mul(v, a.twist ? (a.twist + tile_off)[off] : a.scale);
+            x[w * E + mid] = v;
+        }
+    }
+}
+template <int K, bool INV, bool PASS_A>
+__device__ __forceinline__ void glb_put(const uint32_t (&x)[16], const R16Args& a, uint32_t* __restrict__ dst, size_t tile_off, int s0,
+                                        uint32_t tid, uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+    if (PASS_A && INV && K == 4 && s0 == 0) {
+        uint4* o = reinterpret_cast<uint4*>(dst + tile_off + (size_t)tid * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = make_uint4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+        return;
+    }
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        uint32_t base_row, t;
+        unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+#pragma unroll
+        for (int mid = 0; mid < E; ++mid) {
+            const uint32_t off = ((base_row + ((uint32_t)mid << s0)) << a.row_shift) + t;
+            uint32_t v = x[w * E + mid];
+            if (PASS_A && !INV && a.twist) v = fp_mul(v, (a.twist + tile_off)[off]);
+            (dst + tile_off)[off] = v;
+        }
+    }
+}
+
+// Forward (DIT) order: step 0 (s0 = 0, from global, trivial twiddles, optional skipped stages), then the higher steps.
+template <int K, bool PASS_A, int SKIP>
+__device__ __forceinline__ void fwd_first(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, const uint32_t* src,
+                                          uint32_t* dst, size_t tile_off, bool only, uint32_t tid, uint32_t nt) {
+    glb_get<K, false, PASS_A>(x, a, src, tile_off, 0, tid, nt);
+    step_compute<K, false, true, SKIP>(x, ltw, 0, a.lt, tid, nt);
+    if (only) {
+        glb_put<K, false, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
+    } else {
+        lds_put<K>(x, s, 0, a.lt, tid, nt);
+        __syncthreads();
+    }
+}
+template <int K, bool PASS_A>
+__device__ __forceinline__ void fwd_next(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, uint32_t* dst,
+                                         size_t tile_off, int s0, bool last, uint32_t tid, uint32_t nt) {
+    lds_get<K>(x, s, s0, a.lt, tid, nt);
+    step_compute<K, false, false, 0>(x, ltw, s0, a.lt, tid, nt);
+    if (last) {
+        glb_put<K, false, PASS_A>(x, a, dst, tile_off, s0, tid, nt);
+    } else {
+        __syncthreads();  // every thread has finished reading the previous regrouping
+        lds_put<K>(x, s, s0, a.lt, tid, nt);
+        __syncthreads();
+    }
+}
+// Inverse (DIF) order: the top step comes from global (twist / scale applied on load), step 0 goes back to global.
+template <int K, bool PASS_A>
+__device__ __forceinline__ void inv_top(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, const uint32_t* src,
+                                        size_t tile_off, int s0, uint32_t tid, uint32_t nt) {
+    glb_get<K, true, PASS_A>(x, a, src, tile_off, s0, tid, nt);
+    step_compute<K, true, false, 0>(x, ltw, s0, a.lt, tid, nt);
+    lds_put<K>(x, s, s0, a.lt, tid, nt);
+    __syncthreads();
+}
+
+// One workgroup per (tile, column).  blockDim.x = tile elements / 16.
+template <bool INV, bool PASS_A, int SKIP>
+__global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t tile_elems = 1u << (a.lrows + a.lt);
+    uint32_t* s = lds;
+    uint32_t* ltw = lds + tile_elems + (tile_elems >> 4);
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    uint32_t b = blockIdx.x;
+    // pass B: keep tiles that share a 128-byte line on one XCD (block b is observed on XCD b % 8; speed only)
+    const uint32_t tile = (!PASS_A && (a.tiles % 8u == 0u)) ? (b % 8u) * (a.tiles / 8u) + b / 8u : b;
+    const size_t tile_off = (size_t)tile * a.tile_stride;
+    const uint32_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint32_t* dst = a.out + (size_t)blockIdx.y * a.out_col_stride;
+
+    const uint32_t ntw = 1u << a.lr;
+    for (uint32_t i = tid; i < ntw; i += nt) ltw[i] = a.tw[i];
+    __syncthreads();
+
+    uint32_t x[16];
+    const int ns = (a.lr + 3) >> 2;
+    if (!INV) {
+        const int K0 = a.lr < 4 ? a.lr : 4;
+        switch (K0) {
+            case 4: fwd_first<4, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, ns == 1, tid, nt); break;
+            case 3: fwd_first<3, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+            case 2: fwd_first<2, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+            default: fwd_first<1, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+        }
+        for (int si = 1; si < ns; ++si) {
+            const int s0 = 4 * si;
+            const int K = a.lr - s0 < 4 ? a.lr - s0 : 4;
+            const bool last = si == ns - 1;
+            switch (K) {
+                case 4: fwd_next<4, PASS_A>(x, a, s, ltw, dst, tile_off, s0, last, tid, nt); break;
+                case 3: fwd_next<3, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+                case 2: fwd_next<2, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+                default: fwd_next<1, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+            }
+        }
+    } else {
+        if (ns == 1) {
+            switch (a.lr) {
+                case 4: glb_get<4, true, PASS_A>(x, a, src, tile_off, 0, tid, nt); step_compute<4, true, true, 0>(x, ltw, 0, a.lt, tid, nt); glb_put<4, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt); break;
+                case 3: glb_get<3, true, PASS_A>(x, a, src, tile_off, 0, tid, nt); step_compute<3, true, true, 0>(x, ltw, 0, a.lt, tid, nt); glb_put<3, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt); break;
+                case 2: glb_get<2, true, PASS_A>(x, a, src, tile_off, 0, tid, nt); step_compute<2, true, true, 0>(x, ltw, 0, a.lt, tid, nt); glb_put<2, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt); break;
+                default: glb_get<1, true, PASS_A>(x, a, src, tile_off, 0, tid, nt); step_compute<1, true, true, 0>(x, ltw, 0, a.lt, tid, nt); glb_put<1, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt); break;
+            }
+            return;
+        }
+        const int s_top = 4 * (ns - 1);
+        switch (a.lr - s_top) {
+            case 4: inv_top<4, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            case 3: inv_top<3, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            case 2: inv_top<2, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            default: inv_top<1, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+        }
+        for (int si = ns - 2; si >= 1; --si) {
+            lds_get<4>(x, s, 4 * si, a.lt, tid, nt);
+            step_compute<4, true, false, 0>(x, ltw, 4 * si, a.lt, tid, nt);
+            __syncthreads();
+            lds_put<4>(x, s, 4 * si, a.lt, tid, nt);
+            __syncthreads();
+        }
+        lds_get<4>(x, s, 0, a.lt, tid, nt);
+        step_compute<4, true, true, 0>(x, ltw, 0, a.lt, tid, nt);
+        glb_put<4, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
+    }
+}
+
+}  // namespace bx

@@ -245,16 +245,19 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
         BX_TRY(launch_hash_rows(c, n + 8 * rows, (const uint32_t*)matrix.dptr, rows, matrix.len / rows));
     }
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
+    // Large layers: one full-utilisation launch per layer (lane = output node).  Once a layer no longer fills the chip
+    // (<= fold_fuse_below inputs) the remaining levels are latency-bound, so a workgroup folds 512 inputs nine levels
+    // deep through LDS in one launch.
     size_t size = rows;
+    const size_t fuse_below = (size_t)c->fold_fuse_below;
     while (size > 1) {
-        if (size >= 512) {
+        if (size >= 512 && size <= fuse_below) {
             int levels = 0;
             size_t s = size;
-            while (levels < 9 && s >= 2) {  // 512 inputs per workgroup -> up to 9 levels (256 .. 1 outputs)
+            while (levels < 9 && s >= 2) {
                 s >>= 1;
                 levels++;
             }
-            // a workgroup owns 512 consecutive inputs: it can fold them 9 levels deep
             hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / 512)), dim3(256), 0, c->stream, n, c->d_p2,
                                (uint32_t)size, levels);
             BX_LAUNCH_CHECK(c);

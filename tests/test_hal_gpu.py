@@ -30,9 +30,17 @@ def c(a):
 
 
 # ------------------------------------------------------------------ NTT family
-@pytest.mark.parametrize("bits", [1, 2, 3, 5, 8, 10, 12, 13, 14, 16, 18])
+@pytest.fixture(params=[1, 0], ids=["r16", "v1"])
+def ntt_path(hal, request):
+    """Run the NTT tests on both kernel families: register-radix-16 (default) and the one-stage-per-barrier v1."""
+    hal.set_tunable("ntt_fast", request.param)
+    yield request.param
+    hal.set_tunable("ntt_fast", 1)
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("count", [1, 3])
-def test_interpolate_zkshift_lde_bitreverse(hal, oracle, bits, count):
+def test_interpolate_zkshift_lde_bitreverse(hal, oracle, ntt_path, bits, count):
     n = 1 << bits
     x = rnd(100 + bits, n * count)
     ref = x.copy()
@@ -53,8 +61,8 @@ def test_interpolate_zkshift_lde_bitreverse(hal, oracle, bits, count):
     assert np.array_equal(io.view(), ref), "batch_bit_reverse"
 
 
-@pytest.mark.parametrize("bits,expand", [(4, 0), (9, 0), (14, 0), (6, 2), (14, 2), (15, 1)])
-def test_evaluate_ntt_in_place(hal, oracle, bits, expand):
+@pytest.mark.parametrize("bits,expand", [(4, 0), (9, 0), (11, 0), (14, 0), (6, 2), (12, 2), (14, 2), (15, 1)])
+def test_evaluate_ntt_in_place(hal, oracle, ntt_path, bits, expand):
     n = 1 << bits
     x = rnd(7 + bits, n * 2)
     ref = x.copy()
@@ -78,11 +86,16 @@ def test_ntt_golden_vectors(hal, golden_dir):
         assert ol.decode(out.view()).tolist() == case["lde4"]
 
 
-@pytest.mark.parametrize("block_log,tile_log", [(12, 14), (13, 14), (11, 13), (10, 12)])
-def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, block_log, tile_log):
-    """BASELINE size: N = 2^20 rows -> 2^22 LDE, for every pass-split tunable."""
+@pytest.mark.parametrize("fast,block_log,tile_log,tile_a,tile_b", [
+    (0, 12, 14, 12, 13), (0, 13, 14, 12, 13), (0, 11, 13, 12, 13), (0, 10, 12, 12, 13),
+    (1, 12, 14, 12, 13), (1, 13, 14, 13, 13), (1, 11, 14, 12, 12), (1, 10, 14, 11, 13), (1, 12, 14, 13, 11)])
+def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, fast, block_log, tile_log, tile_a, tile_b):
+    """BASELINE size: N = 2^20 rows -> 2^22 LDE, for both kernel families and every pass-split / tile tunable."""
+    hal.set_tunable("ntt_fast", fast)
     hal.set_tunable("ntt_block_log", block_log)
     hal.set_tunable("ntt_tile_log", tile_log)
+    hal.set_tunable("ntt_tile_a_log", tile_a)
+    hal.set_tunable("ntt_tile_b_log", tile_b)
     try:
         n, count = 1 << 20, 2
         x = rnd(2020, n * count)
@@ -103,8 +116,11 @@ def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, block_log, tile_log)
         hal.batch_evaluate_ntt(io, count, 0)
         assert np.array_equal(io.view(), x)
     finally:
+        hal.set_tunable("ntt_fast", 1)
         hal.set_tunable("ntt_block_log", 12)
         hal.set_tunable("ntt_tile_log", 14)
+        hal.set_tunable("ntt_tile_a_log", 12)
+        hal.set_tunable("ntt_tile_b_log", 13)
 
 
 def test_ntt_linearity_full_size(hal):

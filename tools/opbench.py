@@ -66,10 +66,13 @@ def main():
     hal = HipHal(0)
     print(json.dumps({"device": hal.device_name()}))
     if a.sweep:
-        for blk, tile in ((12, 14), (13, 14), (12, 13), (11, 14), (11, 13), (10, 14), (13, 15), (12, 15)):
+        for fast, blk, ta, tb in ((0, 12, 12, 13), (1, 12, 12, 13), (1, 12, 12, 12), (1, 12, 13, 13), (1, 13, 13, 13), (1, 13, 13, 12),
+                                  (1, 11, 12, 13), (1, 11, 11, 13), (1, 10, 12, 13), (1, 12, 12, 11)):
+            hal.set_tunable("ntt_fast", fast)
             hal.set_tunable("ntt_block_log", blk)
-            hal.set_tunable("ntt_tile_log", tile)
-            run(hal, a.po2, a.cols, a.reps, tag=f"blk{blk}_tile{tile}")
+            hal.set_tunable("ntt_tile_a_log", ta)
+            hal.set_tunable("ntt_tile_b_log", tb)
+            run(hal, a.po2, a.cols, a.reps, tag=f"fast{fast}_blk{blk}_ta{ta}_tb{tb}")
     else:
         run(hal, a.po2, a.cols, a.reps)
 
