@@ -36,17 +36,24 @@ BX_HD uint32_t fp_sub(uint32_t a, uint32_t b) {
 BX_HD uint32_t fp_neg(uint32_t a) { return fp_sub(0u, a); }
 BX_HD uint32_t fp_dbl(uint32_t a) { return fp_add(a, a); }
 
-// Montgomery product a*b*2^-32 mod P, canonical.  With t = lo(ab)*P^-1 mod 2^32 the low words of ab and t*P
-// agree, so (ab - tP)/2^32 = hi(ab) - hi(tP) exactly, in (-P, P).  lo*P_INV is two shift-adds on the VALU
-// (P_INV = 2^31 + 2^27 + 1) instead of a quarter-rate 32-bit multiply.
-BX_HD uint32_t fp_mul(uint32_t a, uint32_t b) {
-    uint64_t ab = (uint64_t)a * (uint64_t)b;
-    uint32_t lo = (uint32_t)ab, hi = (uint32_t)(ab >> 32);
-    uint32_t t = lo + (lo << 27) + (lo << 31);
-    uint32_t u = (uint32_t)(((uint64_t)t * (uint64_t)P) >> 32);
-    uint32_t d = hi - u;
-    return umin(d, d + P);
+constexpr uint32_t NEG_P_INV = 0x77FFFFFFu;  // -P^-1 mod 2^32
+
+// Lazy Montgomery multiply-add: r == (a*b + c) * 2^-32 (mod P) with r < (a*b + c)/2^32 + P, NOT reduced.
+// With m = -(a*b + c) * P^-1 mod 2^32 the sum a*b + c + m*P is divisible by 2^32.  Three VALU instructions on gfx950
+// (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32).  Contract: a*b + c + (2^32 - 1)*P < 2^64, i.e. a*b + c < 2.42 * P^2.
+BX_HD uint32_t fp_mad_lazy(uint32_t a, uint32_t b, uint32_t c) {
+    uint64_t ab = (uint64_t)a * (uint64_t)b + c;
+    uint32_t m = (uint32_t)ab * NEG_P_INV;
+    return (uint32_t)((ab + (uint64_t)m * (uint64_t)P) >> 32);
 }
+BX_HD uint32_t fp_mul_lazy(uint32_t a, uint32_t b) { return fp_mad_lazy(a, b, 0u); }
+// x in [0, 2P) -> canonical
+BX_HD uint32_t fp_reduce(uint32_t x) { return umin(x, x - P); }
+
+// Montgomery product a*b*2^-32 mod P, canonical, for canonical inputs: the lazy result is < P^2/2^32 + P < 1.47 P,
+// so one conditional subtraction finishes it (5 instructions; every 32-bit integer VALU op issues at the same rate on
+// gfx950, see profiles/r01_microbench_valu.jsonl, so instruction count is what matters).
+BX_HD uint32_t fp_mul(uint32_t a, uint32_t b) { return fp_reduce(fp_mul_lazy(a, b)); }
 BX_HD uint32_t fp_sqr(uint32_t a) { return fp_mul(a, a); }
 BX_HD uint32_t fp_encode(uint32_t canonical) { return fp_mul(R2, canonical % P); }
 BX_HD uint32_t fp_decode(uint32_t mont) { return fp_mul(1u, mont); }

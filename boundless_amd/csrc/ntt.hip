@@ -159,6 +159,32 @@ __global__ void bit_reverse_kernel(uint32_t* __restrict__ io, int n, size_t tota
     }
 }
 
+// Tiled bit reversal for n >= 12: index i = (a:6 | b:n-12 | c:6) maps to (rev c | rev b | rev a), so the 64x64 tile
+// {all a, all c} with middle bits b lands, transposed, on the tile with middle bits rev(b).  A workgroup loads the pair
+// (b, rev b) with 256-byte row reads, swaps them through LDS and stores 256-byte rows: each word moves HBM->HBM once.
+__global__ __launch_bounds__(256) void bit_reverse_tiled_kernel(uint32_t* __restrict__ io, int n) {
+    __shared__ uint32_t A[64][65], B[64][65];
+    const int nb = n - 12;
+    const uint32_t b = blockIdx.x, rb = bit_reverse(b, nb);
+    if (rb < b) return;
+    uint32_t* col = io + ((size_t)blockIdx.y << n);
+    const uint32_t lane = threadIdx.x & 63u, r0 = threadIdx.x >> 6;
+    const int hs = n - 6;
+#pragma unroll 4
+    for (uint32_t a = r0; a < 64; a += 4) {
+        A[a][lane] = col[((size_t)a << hs) + (b << 6) + lane];
+        if (rb != b) B[a][lane] = col[((size_t)a << hs) + (rb << 6) + lane];
+    }
+    __syncthreads();
+    const uint32_t rl = bit_reverse(lane, 6);
+#pragma unroll 4
+    for (uint32_t a = r0; a < 64; a += 4) {
+        const uint32_t ra = bit_reverse(a, 6);
+        col[((size_t)a << hs) + (rb << 6) + lane] = A[rl][ra];
+        if (rb != b) col[((size_t)a << hs) + (b << 6) + lane] = B[rl][ra];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -260,7 +286,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 template <bool INV, bool PASS_A, int SKIP>
 static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
     uint32_t tile_elems = 1u << (a.lrows + a.lt);
-    size_t lds = ((size_t)tile_elems + (tile_elems >> 4) + ((size_t)1 << a.lr)) * 4;
+    size_t lds = ((size_t)tile_elems + (tile_elems >> 4)) * 4;
     BX_TRY(allow_lds(c, ntt_r16_kernel<INV, PASS_A, SKIP>, lds));
     hipLaunchKernelGGL((ntt_r16_kernel<INV, PASS_A, SKIP>), dim3(a.tiles, (unsigned)count), dim3(tile_elems / 16), lds, c->stream, a);
     BX_LAUNCH_CHECK(c);
@@ -441,6 +467,12 @@ extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) 
     OpScope op(c, "batch_bit_reverse", 8.0 * (double)io.len);
     int n = ilog2(io.len / count);
     if (n == 0) return nullptr;
+    if (n >= 12 && n <= 30) {
+        hipLaunchKernelGGL(bit_reverse_tiled_kernel, dim3(1u << (n - 12), (unsigned)count), dim3(256), 0, c->stream,
+                           (uint32_t*)io.dptr, n);
+        BX_LAUNCH_CHECK(c);
+        return nullptr;
+    }
     size_t blocks = (io.len + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(bit_reverse_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n, io.len);

@@ -13,7 +13,9 @@
 // Step (s0, K) runs stages s0+1 .. s0+K: row = hi * 2^(s0+K) + mid * 2^s0 + lo; a "unit" (hi, lo, t) owns the 2^K
 // elements mid = 0..2^K-1; a thread owns 16 / 2^K units, enumerated so that consecutive lanes take consecutive
 // (t, lo) — global accesses coalesce and LDS accesses (layout i + (i >> 4)) are conflict-free or 2-way.
-// Stage-s twiddles w_{2^s}^e are read from the LDS copy of the stage table at [2^(s-1) + e].
+// Stage-s twiddles w_{2^s}^e come straight from the global stage table at [2^(s-1) + e]: every entry is used by exactly
+// one unit per tile, so staging the table in LDS would cost more LDS traffic than the data itself; consecutive lanes read
+// consecutive entries (or broadcast), and the table (<= 32 KiB) lives in L1/L2.
 #pragma once
 #include "ctx.hpp"
 
@@ -94,26 +96,44 @@ __device__ __forceinline__ void unit_coords(int w, int s0, int lt, uint32_t tid,
     base_row = (hi << (s0 + K)) | lo;
 }
 
+// LDS index of register (w, mid): element i = ib + mid * 2^(s0+lt) with ib = (base_row << lt) | t.  When the element
+// stride is a multiple of 16 the padding term splits, phys(i) = phys(ib) + mid * (stride + stride/16): one add per access.
 template <int K>
 __device__ __forceinline__ void lds_put(const uint32_t (&x)[16], uint32_t* __restrict__ s, int s0, int lt, uint32_t tid, uint32_t nt) {
     constexpr int U = 16 >> K, E = 1 << K;
+    const int sh = s0 + lt;
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t base_row, t;
         unit_coords<K>(w, s0, lt, tid, nt, base_row, t);
+        const uint32_t ib = (base_row << lt) | t;
+        if (sh >= 4) {
+            const uint32_t pb = lds_phys(ib), step = (1u << sh) + (1u << (sh - 4));
 #pragma unroll
-        for (int mid = 0; mid < E; ++mid) s[lds_phys(((base_row + ((uint32_t)mid << s0)) << lt) | t)] = x[w * E + mid];
+            for (int mid = 0; mid < E; ++mid) s[pb + (uint32_t)mid * step] = x[w * E + mid];
+        } else {
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid) s[lds_phys(ib + ((uint32_t)mid << sh))] = x[w * E + mid];
+        }
     }
 }
 template <int K>
 __device__ __forceinline__ void lds_get(uint32_t (&x)[16], const uint32_t* __restrict__ s, int s0, int lt, uint32_t tid, uint32_t nt) {
     constexpr int U = 16 >> K, E = 1 << K;
+    const int sh = s0 + lt;
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t base_row, t;
         unit_coords<K>(w, s0, lt, tid, nt, base_row, t);
+        const uint32_t ib = (base_row << lt) | t;
+        if (sh >= 4) {
+            const uint32_t pb = lds_phys(ib), step = (1u << sh) + (1u << (sh - 4));
 #pragma unroll
-        for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[lds_phys(((base_row + ((uint32_t)mid << s0)) << lt) | t)];
+            for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[pb + (uint32_t)mid * step];
+        } else {
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[lds_phys(ib + ((uint32_t)mid << sh))];
+        }
     }
 }
 
@@ -139,17 +159,34 @@ __device__ __forceinline__ void glb_get(uint32_t (&x)[16], const R16Args& a, con
         }
         return;
     }
+    // 32-bit offsets from wave-uniform bases keep one VGPR per address
+    const uint32_t* sp = PASS_A ? src + (tile_off >> a.expand) : src + tile_off;
+    const int rsh = a.row_shift + s0;
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t base_row, t;
         unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+        const uint32_t ob = (base_row << a.row_shift) + t;
 #pragma unroll
         for (int mid = 0; mid < E; ++mid) {
-            // 32-bit offsets from wave-uniform bases keep one VGPR per address
-            const uint32_t off = ((base_row + ((uint32_t)mid << s0)) << a.row_shift) + t;
-            uint32_t v = PASS_A ? src[(tile_off >> a.expand) + (off >> a.expand)] : (src + tile_off)[off];
-            if (PASS_A && INV) v = fp_mul(v, a.twist ? (a.twist + tile_off)[off] : a.scale);
-            x[w * E + mid] = v;
+            const uint32_t off = ob + ((uint32_t)mid << rsh);
+            x[w * E + mid] = sp[PASS_A ? (off >> a.expand) : off];
+        }
+    }
+    if (PASS_A && INV) {
+        if (a.twist) {
+            const uint32_t* tp = a.twist + tile_off;
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                uint32_t base_row, t;
+                unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+                const uint32_t ob = (base_row << a.row_shift) + t;
+#pragma unroll
+                for (int mid = 0; mid < E; ++mid) x[w * E + mid] = fp_mul(x[w * E + mid], tp[ob + ((uint32_t)mid << rsh)]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = fp_mul(x[i], a.scale);
         }
     }
 }
@@ -163,16 +200,24 @@ __device__ __forceinline__ void glb_put(const uint32_t (&x)[16], const R16Args& 
         for (int i = 0; i < 4; ++i) o[i] = make_uint4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
         return;
     }
+    uint32_t* dp = dst + tile_off;
+    const int rsh = a.row_shift + s0;
+    const bool tw = PASS_A && !INV && a.twist != nullptr;
+    const uint32_t* tp = tw ? a.twist + tile_off : nullptr;
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t base_row, t;
         unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+        const uint32_t ob = (base_row << a.row_shift) + t;
+        if (tw) {
+            uint32_t f[E];
 #pragma unroll
-        for (int mid = 0; mid < E; ++mid) {
-            const uint32_t off = ((base_row + ((uint32_t)mid << s0)) << a.row_shift) + t;
-            uint32_t v = x[w * E + mid];
-            if (PASS_A && !INV && a.twist) v = fp_mul(v, (a.twist + tile_off)[off]);
-            (dst + tile_off)[off] = v;
+            for (int mid = 0; mid < E; ++mid) f[mid] = tp[ob + ((uint32_t)mid << rsh)];
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid) dp[ob + ((uint32_t)mid << rsh)] = fp_mul(x[w * E + mid], f[mid]);
+        } else {
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid) dp[ob + ((uint32_t)mid << rsh)] = x[w * E + mid];
         }
     }
 }
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
     extern __shared__ uint32_t lds[];
     const uint32_t tile_elems = 1u << (a.lrows + a.lt);
     uint32_t* s = lds;
-    uint32_t* ltw = lds + tile_elems + (tile_elems >> 4);
+    const uint32_t* __restrict__ ltw = a.tw;  // global stage table (see the header comment)
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     uint32_t b = blockIdx.x;
     // pass B: keep tiles that share a 128-byte line on one XCD (block b is observed on XCD b % 8; speed only)
@@ -228,10 +273,7 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
     const uint32_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint32_t* dst = a.out + (size_t)blockIdx.y * a.out_col_stride;
 
-    const uint32_t ntw = 1u << a.lr;
-    for (uint32_t i = tid; i < ntw; i += nt) ltw[i] = a.tw[i];
-    __syncthreads();
-
+    (void)tile_elems;
     uint32_t x[16];
     const int ns = (a.lr + 3) >> 2;
     if (!INV) {
