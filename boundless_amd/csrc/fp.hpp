@@ -20,6 +20,7 @@ constexpr uint32_t P = 2013265921u;      // 15 * 2^27 + 1
 constexpr uint32_t P_INV = 0x88000001u;  // P^-1 mod 2^32  (= 2^31 + 2^27 + 1)
 constexpr uint32_t R2 = 1172168163u;     // 2^64 mod P
 constexpr uint32_t MONT_ONE = 268435454u;  // 2^32 mod P
+constexpr uint32_t R3 = 317946875u;      // 2^96 mod P
 
 BX_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 

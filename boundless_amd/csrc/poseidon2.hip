@@ -15,75 +15,128 @@ namespace bx {
 
 constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Instruction budget.  Every 32-bit integer VALU op issues at the same rate on gfx950 (profiles/r01_microbench_valu.jsonl),
+// a canonical modular add is 3 instructions and a Montgomery product 5, so the permutation is organised to minimise
+// instruction count:
+//   * linear layers run UNREDUCED in 64 bits: v_mad_u64_u32 multiplies by the small matrix entries and accumulates in
+//     one instruction (external layer: every output < 112 P < 2^38; internal-layer sum < 24 P);
+//   * the return to 32 bits is one Montgomery reduction per cell, and the next round constant rides in its
+//     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [all mod P, REDC = * 2^-32];
+//   * the S-box keeps lazy intermediates (see sbox7).
+// ~9.0 k instructions per permutation instead of ~14.5 k for the reduce-after-every-add form.
+// All cell values handed between rounds are canonical (< P); the bounds that make each step exact are stated inline.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
+
 // x^7 for canonical x with lazy intermediates (fp_mad_lazy's contract: product < 2.42 P^2, result < product/2^32 + P):
 //   x2 = x*x          < 1.469 P        x3 = x2*x  (1.469 P^2)   < 1.689 P
 //   x4 = x2*x2 (2.158 P^2) < 2.012 P -> one conditional subtract: x4r < 1.012 P
-//   x7 = x3*x4r (1.709 P^2) < 1.802 P -> reduce.      19 instructions with the round-constant add instead of 27.
+//   x7 = x3*x4r (1.709 P^2) < 1.802 P -> reduce.      16 instructions.
 __device__ __forceinline__ uint32_t sbox7(uint32_t x) {
     uint32_t x2 = fp_mul_lazy(x, x);
     uint32_t x3 = fp_mul_lazy(x2, x);
     uint32_t x4 = fp_reduce(fp_mul_lazy(x2, x2));
     return fp_reduce(fp_mul_lazy(x3, x4));
 }
-// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with additions only (Poseidon2 paper, appendix B).
-__device__ __forceinline__ void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-    uint32_t t0 = fp_add(a, b), t1 = fp_add(c, d);
-    uint32_t t2 = fp_add(fp_dbl(b), t1), t3 = fp_add(fp_dbl(d), t0);
-    uint32_t t4 = fp_add(fp_dbl(fp_dbl(t1)), t3), t5 = fp_add(fp_dbl(fp_dbl(t0)), t2);
-    a = fp_add(t3, t5);
-    b = t5;
-    c = fp_add(t2, t4);
-    d = t4;
+
+// (y + add * 2^-32 ... ) -> canonical:  returns (y mod P + a) mod P where `add_rr` = a * 2^64 mod P (a in the cells'
+// Montgomery representation).  y < 2^38.  acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr
+//   < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18, so acc + m*P < 2^64 and the lazy result is
+//   < 268435473 + P < 2P: one conditional subtraction makes it canonical.  6 instructions.
+__device__ __forceinline__ uint32_t red64(uint64_t y, uint32_t add_rr) {
+    uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
+    acc = mad64((uint32_t)(y >> 32), R2, acc);
+    uint32_t m = (uint32_t)acc * NEG_P_INV;
+    return fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
 }
-__device__ __forceinline__ void m_ext(uint32_t* s) {
+
+// external layer circ(2*M4, M4, ..., M4) on canonical cells, unreduced 64-bit outputs:
+//   w_k = M4 * x_k  (rows [5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]; each < 16 P),  T = sum_k w_k (< 96 P),  y_k = w_k + T.
+__device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
 #pragma unroll
-    for (int i = 0; i < CELLS; i += 4) m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
-    uint32_t sum[4];
+    for (int k = 0; k < CELLS; k += 4) {
+        const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
+        y[k] = mad64(5u, a, mad64(7u, b, mad64(3u, d, (uint64_t)c)));
+        y[k + 1] = mad64(4u, a, mad64(6u, b, (uint64_t)(c + d)));  // c + d < 2P < 2^32
+        y[k + 2] = mad64(3u, b, mad64(5u, c, mad64(7u, d, (uint64_t)a)));
+        y[k + 3] = mad64(4u, c, mad64(6u, d, (uint64_t)(a + b)));
+    }
+    uint64_t t[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        sum[j] = s[j];
+        t[j] = y[j];
 #pragma unroll
-        for (int i = 4; i < CELLS; i += 4) sum[j] = fp_add(sum[j], s[i + j]);
+        for (int k = 4; k < CELLS; k += 4) t[j] += y[k + j];
     }
 #pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = fp_add(s[i], sum[i & 3]);
+    for (int i = 0; i < CELLS; ++i) y[i] += t[i & 3];
 }
-__device__ __forceinline__ void m_int(uint32_t* s, const uint32_t* __restrict__ diag) {
-    // pairwise tree keeps the dependency chain short
-    uint32_t p[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) p[i] = fp_add(s[2 * i], s[2 * i + 1]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) p[i] = fp_add(p[2 * i], p[2 * i + 1]);
-    uint32_t sum = fp_add(fp_add(fp_add(p[0], p[1]), fp_add(p[2], p[3])), fp_add(p[4], p[5]));
-    // sum + d_i*s_i*2^-32 = (d_i*s_i + sum*2^32) * 2^-32: put sum*2^32 mod P into the Montgomery accumulator, so the
-    // addition rides on the v_mad_u64_u32 and each cell costs 5 instructions instead of 9.
-    const uint32_t sum_r = fp_mul(sum, R2);
-#pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r));
-}
-// params: [0,96) first external rounds | [96,117) internal | [117,213) last external | [213,237) diag (Montgomery)
+
+// Device parameter table (all words Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride in a
+// REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
+// [213,237) internal diagonal (plain Montgomery form, used as a multiplier).
 __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
-    m_ext(s);
+    uint64_t y[CELLS];
+    // initial external layer; round-0 constants ride in the reduction
+    m_ext64(s, y);
+#pragma unroll
+    for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], prm[i]);
+    // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
+    // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        const uint32_t* rc = prm + r * CELLS;
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(fp_add(s[i], rc[i]));
-        m_ext(s);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(s[i]);
+        m_ext64(s, y);
+        if (r < RF_HALF - 1) {
+            const uint32_t* rc = prm + (r + 1) * CELLS;
+#pragma unroll
+            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], rc[i]);
+        } else {
+            s[0] = red64(y[0], prm[96]);
+#pragma unroll
+            for (int i = 1; i < CELLS; ++i) s[i] = red64(y[i], 0u);
+        }
     }
+    // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum (< 24 P) is accumulated in 64 bits, turned into
+    // sum_r = sum * 2^32 mod P by one reduction (acc < 2^32 * R2 + 24 * R3, lazy result < R2 + 24 + P < 2P), and rides
+    // in each cell's REDC accumulator together with the next constant: d*s + sum_r + rc < P^2 + 3P.
     const uint32_t* diag = prm + 213;
 #pragma unroll 1
     for (int r = 0; r < RP; ++r) {
-        s[0] = sbox7(fp_add(s[0], prm[96 + r]));
-        m_int(s, diag);
+        s[0] = sbox7(s[0]);
+        uint64_t sum = (uint64_t)s[0];
+#pragma unroll
+        for (int i = 1; i < CELLS; ++i) sum = mad64(1u, s[i], sum);
+        uint64_t acc = mad64((uint32_t)sum, R2, 0ull);
+        acc = mad64((uint32_t)(sum >> 32), R3, acc);
+        const uint32_t m = (uint32_t)acc * NEG_P_INV;
+        const uint32_t sum_r = fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
+        if (r < RP - 1) {
+            s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));  // next internal constant (sum < 2P)
+#pragma unroll
+            for (int i = 1; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r));
+        } else {
+            const uint32_t* rc = prm + 117;  // external round 4's constants
+#pragma unroll
+            for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r + rc[i]));
+        }
     }
+    // external rounds 4..7
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        const uint32_t* rc = prm + 117 + r * CELLS;
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(fp_add(s[i], rc[i]));
-        m_ext(s);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(s[i]);
+        m_ext64(s, y);
+        if (r < RF_HALF - 1) {
+            const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
+#pragma unroll
+            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], rc[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], 0u);
+        }
     }
 }
 
@@ -179,7 +232,8 @@ __global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restri
 
 const char* poseidon2_upload_params(bx_ctx* c) {
     uint32_t h[237];
-    for (int i = 0; i < 213; ++i) h[i] = fp_encode(c->h_rc[i]);
+    // round constants ride in REDC accumulators: store rc * 2^64 mod P (Montgomery form encoded once more)
+    for (int i = 0; i < 213; ++i) h[i] = fp_encode(fp_encode(c->h_rc[i]));
     for (int i = 0; i < 24; ++i) h[213 + i] = fp_encode(c->h_diag[i]);
     if (!c->d_p2) BX_HIP(c, hipMalloc(&c->d_p2, sizeof h));
     BX_HIP(c, hipMemcpyAsync(c->d_p2, h, sizeof h, hipMemcpyHostToDevice, c->stream));

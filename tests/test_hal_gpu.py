@@ -194,6 +194,35 @@ def test_hash_rows_vs_oracle(hal, oracle, rows, cols):
     assert np.array_equal(out.view(), ref)
 
 
+def test_hash_rows_extreme_values(hal, oracle):
+    """Lazy-reduction bounds: rows made of the extreme words 0, 1, P-1 and mixtures must still match exactly."""
+    rows, cols = 256, 48
+    rng = np.random.default_rng(99)
+    pool = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, 268435454, 1172168163], dtype=np.uint32)
+    x = pool[rng.integers(0, len(pool), rows * cols)]
+    x[:cols] = P - 1  # note: column-major, so this sets the first rows of column 0; set whole rows explicitly below
+    m = x.reshape(cols, rows)
+    m[:, 0] = P - 1
+    m[:, 1] = 0
+    m[:, 2] = 1
+    m[:, 3] = P - 2
+    x = np.ascontiguousarray(m.reshape(-1))
+    out = hal.alloc_digest(rows)
+    hal.hash_rows(out, hal.copy_from(x))
+    ref = np.zeros(8 * rows, np.uint32)
+    oracle.bxo_hash_rows(ref, x, rows, cols)
+    assert np.array_equal(out.view(), ref)
+    # digests of extreme words through hash_fold as well
+    nodes = np.zeros(4 * 8, np.uint32)
+    nodes[16:24] = P - 1
+    nodes[24:32] = P - 1
+    io = hal.copy_from(nodes)
+    hal.hash_fold(io, 2, 1)
+    want = np.zeros(8, np.uint32)
+    oracle.bxo_hash_pair(want, c(nodes[16:24]), c(nodes[24:32]))
+    assert np.array_equal(io.view()[8:16], want)
+
+
 @pytest.mark.parametrize("rows", [2, 8, 256, 512, 1024, 4096, 1 << 15])
 def test_merkle_build_vs_oracle(hal, oracle, rows):
     cols = 20
