@@ -160,35 +160,36 @@ __global__ void div_local_kernel(const uint32_t* __restrict__ poly, size_t size,
     for (size_t i = hi; i-- > lo;) cur = f4_add(f4_mul(z, cur), ld4(poly + 4 * i));
     st4(local + 4 * ch, cur);
 }
-// carry_in[ch] = value of `cur` entering chunk ch from above; processed top chunk first.
+// carry_in[ch] = value of `cur` entering chunk ch from above.  One workgroup: thread t owns a contiguous run of chunks
+// (thread 0 the highest), reduces it to the affine map carry -> a*carry + b, the maps are composed across threads with a
+// log-step (Hillis-Steele) scan in LDS, and each thread replays its run with the carry that enters it.
 __global__ void div_scan_kernel(uint32_t* __restrict__ local_then_carry, size_t chunks, Fp4 zL, uint32_t* __restrict__ rem) {
-    // block-sequential two-level scan: thread t owns a contiguous run of chunks.
-    extern __shared__ uint32_t sh[];  // per-thread aggregate (a = zL^run, b) -> 8 words
+    extern __shared__ uint32_t sh[];  // per thread: a (4 words) | b (4 words)
     const uint32_t nt = blockDim.x, tid = threadIdx.x;
     size_t per = (chunks + nt - 1) / nt;
-    // runs are assigned from the top: thread 0 owns the highest chunks
     size_t hi = chunks > (size_t)tid * per ? chunks - (size_t)tid * per : 0;
     size_t lo = hi > per ? hi - per : 0;
-    // aggregate of my run with zero carry-in: b = carry-out below my run, a = zL^(len)
     Fp4 a = f4_one(), b = f4_zero();
     for (size_t ch = hi; ch-- > lo;) {
         b = f4_add(f4_mul(zL, b), ld4(local_then_carry + 4 * ch));
         a = f4_mul(a, zL);
     }
-    st4(sh + 8 * tid, a);
+    // inclusive scan of F_t = f_t o f_(t-1) o ... o f_0 with (a2,b2) o (a1,b1) = (a2*a1, a2*b1 + b2)
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        st4(sh + 8 * tid, a);
+        st4(sh + 8 * tid + 4, b);
+        __syncthreads();
+        if (tid >= d) {
+            Fp4 pa = ld4(sh + 8 * (tid - d)), pb = ld4(sh + 8 * (tid - d) + 4);
+            b = f4_add(f4_mul(a, pb), b);
+            a = f4_mul(a, pa);
+        }
+        __syncthreads();
+    }
     st4(sh + 8 * tid + 4, b);
     __syncthreads();
-    if (tid == 0) {
-        Fp4 carry = f4_zero();
-        for (uint32_t t = 0; t < nt; ++t) {
-            Fp4 ta = ld4(sh + 8 * t), tb = ld4(sh + 8 * t + 4);
-            st4(sh + 8 * t, carry);  // carry entering thread t's run
-            carry = f4_add(f4_mul(ta, carry), tb);
-        }
-        st4(rem, carry);  // after the lowest chunk: remainder
-    }
-    __syncthreads();
-    Fp4 carry = ld4(sh + 8 * tid);
+    if (tid == nt - 1) st4(rem, b);  // composition of every run applied to carry 0 = the remainder
+    Fp4 carry = tid == 0 ? f4_zero() : ld4(sh + 8 * (tid - 1) + 4);
     for (size_t ch = hi; ch-- > lo;) {
         Fp4 l = ld4(local_then_carry + 4 * ch);
         st4(local_then_carry + 4 * ch, carry);
