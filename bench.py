@@ -68,79 +68,102 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,256,64")
+    ap.add_argument("--inflight", type=int, default=1, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="BASELINE configs[2]: prove this many segments in total, claimed from a shared queue (--steal) instead of --steps per rank")
+    ap.add_argument("--steal", action="store_true", help="claim-when-idle ticket queue instead of the static rank split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-po2", type=int, default=16)
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
 
-    import torch
-    import torch.distributed as dist
+    import threading
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    from boundless_amd.dist import SegmentQueue, init_distributed, max_over_ranks, sum_over_ranks
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
+    rank, world, local_rank, dist = init_distributed()
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from boundless_amd.prover import HipProverServer, Segment
 
-    server = HipProverServer(device=local_rank, po2=args.po2, widths=widths)
-    hal = server.hal
+    servers = [HipProverServer(device=local_rank, po2=args.po2, widths=widths) for _ in range(max(1, args.inflight))]
+    hal = servers[0].hal
 
     def barrier():
         torch.cuda.synchronize()
-        hal.sync()
-        if world > 1:
+        for sv in servers:
+            sv.hal.sync()
+        if dist is not None:
             dist.barrier()
 
-    step_no = 0
+    def run(total_per_rank, total_global, tag):
+        """Prove segments claimed from the queue with `inflight` provers per GPU; returns (proved by this rank, last receipt)."""
+        q = SegmentQueue(total_global, rank=rank, world=world, dist=dist, mode="steal" if args.steal else "static", name=tag)
+        lock = threading.Lock()
+        done = [0]
+        last = [None]
 
-    def one_step():
-        nonlocal step_no
-        seg = Segment.synthetic(index=step_no * world + rank, po2=args.po2)
-        step_no += 1
-        return server.prove_segment(seg)
+        def worker(sv):
+            while True:
+                with lock:
+                    if not args.steal and done[0] >= total_per_rank:
+                        return
+                    idx = q.claim()
+                    if idx is None:
+                        return
+                    done[0] += 1
+                last[0] = sv.prove_segment(Segment.synthetic(index=idx, po2=args.po2))
 
-    for _ in range(args.warmup):
-        one_step()
+        if len(servers) == 1:
+            worker(servers[0])
+        else:
+            ts = [threading.Thread(target=worker, args=(sv,)) for sv in servers]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+        return done[0], last[0]
+
+    per_rank = args.steps * len(servers)
+    total_global = args.batch if args.batch else per_rank * world
+    run(args.warmup * len(servers), args.warmup * len(servers) * world, "warm")
     barrier()
-    hal.profile_reset()
-    hal.profile_enable(True)
+    for sv in servers:
+        sv.hal.profile_reset()
+        sv.hal.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        receipt = one_step()
+    proved, receipt = run(per_rank if not args.batch else total_global, total_global, "timed")
     barrier()
     elapsed = time.perf_counter() - t0
-    hal.profile_enable(False)
-    prof = hal.profile_report()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    prof = {}
+    for sv in servers:
+        sv.hal.profile_enable(False)
+        for name, r in sv.hal.profile_report().items():
+            a0 = prof.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0.0})
+            for k in a0:
+                a0[k] += r[k]
+    elapsed = max_over_ranks(elapsed, dist)
+    proved_total = int(round(sum_over_ranks(proved, dist)))
 
     if rank == 0:
         kernels = {}
         for name, r in prof.items():
             ms = r["ms"] / max(r["calls"], 1)
             gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            kernels[name] = {"calls_per_step": r["calls"] / args.steps, "avg_ms": round(ms, 4),
-                             "ms_per_step": round(r["ms"] / args.steps, 3), "alg_GBps": round(gbps, 1),
+            kernels[name] = {"calls_per_step": r["calls"] / max(proved, 1), "avg_ms": round(ms, 4),
+                             "ms_per_step": round(r["ms"] / max(proved, 1), 3), "alg_GBps": round(gbps, 1),
                              "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
         ntt = kernels.get("batch_expand_into_evaluate_ntt", {})
         dom_name = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         out = {
             "metric": "segment-proofs/sec @ 2^20 cycles",
-            "value": world * args.steps / elapsed,
+            "value": proved_total / elapsed,
             "unit": "segment-proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps if not args.batch else 1e3 * elapsed / max(proved_total, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -148,8 +171,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"single 2^{args.po2}-cycle synthetic segment per GPU via the HIP HAL (NTT+Poseidon2+FRI), "
                                    f"trace widths code/data/accum = {'/'.join(map(str, widths))}, check 16, 50 queries",
-                       "po2": args.po2, "parallelism": f"segments sharded over {world} GPU(s), no collective",
-                       "khz_equiv": world * args.steps * (1 << args.po2) / elapsed / 1e3},
+                       "po2": args.po2, "segments_proved": proved_total, "segments_in_flight_per_gpu": len(servers),
+                       "queue": ("claim-when-idle ticket queue (c10d store)" if args.steal else "static rank split"),
+                       "parallelism": f"segments sharded over {world} GPU(s), no collective",
+                       "khz_equiv": proved_total * (1 << args.po2) / elapsed / 1e3},
             "seal_words": int(receipt.seal.size),
             "roofline": {
                 "kernel": "batch_expand_into_evaluate_ntt (ntt_block_kernel + ntt_strided_kernel, 4x LDE)",
@@ -171,8 +196,9 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))
-    server.close()
-    if world > 1:
+    for sv in servers:
+        sv.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 
