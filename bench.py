@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,256,64")
-    ap.add_argument("--inflight", type=int, default=1, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
+    ap.add_argument("--inflight", type=int, default=2, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE configs[2]: prove this many segments in total, claimed from a shared queue (--steal) instead of --steps per rank")
     ap.add_argument("--steal", action="store_true", help="claim-when-idle ticket queue instead of the static rank split")
     ap.add_argument("--no-cpu-baseline", action="store_true")

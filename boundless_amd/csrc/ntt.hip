@@ -283,14 +283,25 @@ static const char* allow_lds(bx_ctx* c, K kernel, size_t bytes) {
 // ---- register-radix-16 fast path (ntt_r16.hpp) -------------------------------------------------------------
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
-template <bool INV, bool PASS_A, int SKIP>
-static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
+template <bool INV, bool PASS_A, int SKIP, int LR, int LT>
+static const char* launch_r16_geom(bx_ctx* c, R16Args a, size_t count) {
     uint32_t tile_elems = 1u << (a.lrows + a.lt);
     size_t lds = ((size_t)tile_elems + (tile_elems >> 4)) * 4;
-    BX_TRY(allow_lds(c, ntt_r16_kernel<INV, PASS_A, SKIP>, lds));
-    hipLaunchKernelGGL((ntt_r16_kernel<INV, PASS_A, SKIP>), dim3(a.tiles, (unsigned)count), dim3(tile_elems / 16), lds, c->stream, a);
+    a.cols = (uint32_t)count;
+    BX_REQUIRE(c, (size_t)a.tiles * count < ((size_t)1 << 31), "ntt: too many workgroups in one launch");
+    BX_TRY(allow_lds(c, ntt_r16_kernel<INV, PASS_A, SKIP, LR, LT>, lds));
+    hipLaunchKernelGGL((ntt_r16_kernel<INV, PASS_A, SKIP, LR, LT>), dim3(a.tiles * (unsigned)count), dim3(tile_elems / 16), lds,
+                       c->stream, a);
     BX_LAUNCH_CHECK(c);
     return nullptr;
+}
+// hot geometries (BASELINE sizes 2^20 / 2^22, default tunables) get a compile-time specialisation
+template <bool INV, bool PASS_A, int SKIP>
+static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
+    if (PASS_A && a.lr == 12 && a.lt == 0) return launch_r16_geom<INV, PASS_A, SKIP, 12, 0>(c, a, count);
+    if (!PASS_A && a.lr == 10 && a.lt == 3) return launch_r16_geom<INV, PASS_A, SKIP, 10, 3>(c, a, count);
+    if (!PASS_A && a.lr == 8 && a.lt == 5) return launch_r16_geom<INV, PASS_A, SKIP, 8, 5>(c, a, count);
+    return launch_r16_geom<INV, PASS_A, SKIP, 0, 0>(c, a, count);
 }
 
 // pass A over `count` columns of size 2^m made of 2^(m - m_hi) blocks; returns false in *ok if the shape is not covered

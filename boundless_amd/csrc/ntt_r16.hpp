@@ -33,6 +33,7 @@ struct R16Args {
     uint32_t tile_stride;  // words between consecutive tiles (pass A: tile size, pass B: T)
     size_t in_col_stride, out_col_stride;
     uint32_t tiles;
+    uint32_t cols;  // number of columns (polynomials) in the launch
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t i) { return i + (i >> 4); }
@@ -258,22 +259,40 @@ __device__ __forceinline__ void inv_top(uint32_t (&x)[16], const R16Args& a, uin
     __syncthreads();
 }
 
-// One workgroup per (tile, column).  blockDim.x = tile elements / 16.
-template <bool INV, bool PASS_A, int SKIP>
+// One workgroup per (tile, column).  blockDim.x = tile elements / 16.  LR/LT > 0 / >= 0 bake the hot geometries in at
+// compile time (stage loops unroll, shifts and LDS strides become immediates); LR = 0 is the generic runtime version.
+// Grid: blockIdx.x enumerates (tile, column) pairs so that every column of one tile lands on one XCD (block b is
+// observed on XCD b % 8; speed only): the pass-A twist slice of a tile is then fetched into that XCD's L2 once instead of
+// once per column, and pass-B tiles that share a 128-byte line stay together.
+template <bool INV, bool PASS_A, int SKIP, int LR, int LT>
 __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
     extern __shared__ uint32_t lds[];
-    const uint32_t tile_elems = 1u << (a.lrows + a.lt);
+    if (LR > 0) {
+        a.lr = LR;
+        a.lt = LT;
+        if (!PASS_A) a.lrows = LR;
+    }
     uint32_t* s = lds;
     const uint32_t* __restrict__ ltw = a.tw;  // global stage table (see the header comment)
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    uint32_t b = blockIdx.x;
-    // pass B: keep tiles that share a 128-byte line on one XCD (block b is observed on XCD b % 8; speed only)
-    const uint32_t tile = (!PASS_A && (a.tiles % 8u == 0u)) ? (b % 8u) * (a.tiles / 8u) + b / 8u : b;
+    uint32_t tile, col;
+    {
+        const uint32_t L = blockIdx.x, cols = a.cols;
+        if (a.tiles % 8u == 0u) {
+            const uint32_t xcd = L % 8u, j = L / 8u;
+            col = j % cols;
+            const uint32_t tq = j / cols;
+            // pass A: tile = tq*8 + xcd (all columns of a tile on one XCD); pass B: neighbouring tiles on one XCD
+            tile = PASS_A ? tq * 8u + xcd : xcd * (a.tiles / 8u) + tq;
+        } else {
+            tile = L % a.tiles;
+            col = L / a.tiles;
+        }
+    }
     const size_t tile_off = (size_t)tile * a.tile_stride;
-    const uint32_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride;
-    uint32_t* dst = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const uint32_t* src = a.in + (size_t)col * a.in_col_stride;
+    uint32_t* dst = a.out + (size_t)col * a.out_col_stride;
 
-    (void)tile_elems;
     uint32_t x[16];
     const int ns = (a.lr + 3) >> 2;
     if (!INV) {
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
             case 2: fwd_first<2, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
             default: fwd_first<1, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
         }
+#pragma unroll
         for (int si = 1; si < ns; ++si) {
             const int s0 = 4 * si;
             const int K = a.lr - s0 < 4 ? a.lr - s0 : 4;
@@ -312,6 +332,7 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
             case 2: inv_top<2, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
             default: inv_top<1, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
         }
+#pragma unroll
         for (int si = ns - 2; si >= 1; --si) {
             lds_get<4>(x, s, 4 * si, a.lt, tid, nt);
             step_compute<4, true, false, 0>(x, ltw, 4 * si, a.lt, tid, nt);
