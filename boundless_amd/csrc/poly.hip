@@ -68,50 +68,67 @@ __global__ __launch_bounds__(256) void mix_poly_kernel(uint32_t* __restrict__ ou
     }
     st4(o, acc);
 }
-__global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
-    __shared__ uint32_t sh[256];
-    uint32_t m = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) m = v[i] > m ? v[i] : m;
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *out = sh[0];
-}
-
 // ---- batch_evaluate_any ----
-// grid = (segments, evals).  A workgroup evaluates SEG = 256*K coefficients of polynomial which[e] at xs[e]:
-//   sum_{t<256} x^t * sum_{i<K} c[seg + t + 256 i] * (x^256)^i,  then scales by x^seg and writes a partial.
-constexpr int EV_K = 32, EV_T = 256;
+// grid = (segments, evals).  A workgroup evaluates SEG = 256*K consecutive coefficients of polynomial which[e] at x:
+//   x^seg_base * sum_{t<256} x^t * sum_{i<K} c[base + t + 256 i] * (x^256)^i.
+// The 256 + K powers are built once per workgroup by doubling in LDS (pw[d + i] = pw[d] * pw[i]), so the per-coefficient
+// cost is one Fp4-by-Fp product (4 Montgomery products) plus one LDS broadcast read.
+constexpr int EV_K = 128, EV_T = 256;
 __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __restrict__ coeffs, size_t poly_size,
                                                             const uint32_t* __restrict__ which, const uint32_t* __restrict__ xs,
                                                             uint32_t* __restrict__ partials, uint32_t segs) {
-    __shared__ uint32_t ypow[EV_K * 4];
-    __shared__ uint32_t red[EV_T * 4];
+    __shared__ uint32_t xpow[EV_T * 4];  // x^t (reused for the final reduction)
+    __shared__ uint32_t ypow[EV_K * 4];  // (x^256)^i
     const uint32_t e = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const Fp4 x = ld4(xs + 4 * (size_t)e);
     const size_t seg_elems = (size_t)EV_T * EV_K;
     const size_t base = (size_t)seg * seg_elems;
     const uint32_t* c = coeffs + (size_t)which[e] * poly_size + base;
     const size_t remaining = poly_size - base;
-    if (tid < EV_K) st4(ypow + 4 * tid, f4_pow(f4_pow(x, EV_T), tid));
-    __syncthreads();
-    Fp4 acc = f4_zero();
-#pragma unroll 4
-    for (int i = 0; i < EV_K; ++i) {
-        size_t j = (size_t)tid + (size_t)EV_T * i;
-        if (j < remaining) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[j]));
+    if (tid == 0) {
+        st4(xpow, f4_one());
+        st4(xpow + 4, x);
     }
-    acc = f4_mul(acc, f4_pow(x, tid));
-    st4(red + 4 * tid, acc);
     __syncthreads();
-    for (int s = EV_T / 2; s > 0; s >>= 1) {
-        if ((int)tid < s) st4(red + 4 * tid, f4_add(ld4(red + 4 * tid), ld4(red + 4 * (tid + s))));
+    for (uint32_t d = 2; d < EV_T; d <<= 1) {  // pw[d .. 2d) = pw[d-1] * x * pw[0 .. d)  ==  pw[d] * pw[i]
+        if (tid < d) {
+            Fp4 top = f4_mul(ld4(xpow + 4 * (d - 1)), x);  // x^d
+            st4(xpow + 4 * (d + tid), f4_mul(top, ld4(xpow + 4 * tid)));
+        }
         __syncthreads();
     }
-    if (tid == 0) st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(red), f4_pow(x, base)));
+    const Fp4 X = f4_mul(ld4(xpow + 4 * (EV_T - 1)), x);  // x^256
+    if (tid == 0) {
+        st4(ypow, f4_one());
+        st4(ypow + 4, X);
+    }
+    __syncthreads();
+    for (uint32_t d = 2; d < EV_K; d <<= 1) {
+        if (tid < d) {
+            Fp4 top = f4_mul(ld4(ypow + 4 * (d - 1)), X);
+            st4(ypow + 4 * (d + tid), f4_mul(top, ld4(ypow + 4 * tid)));
+        }
+        __syncthreads();
+    }
+    Fp4 acc = f4_zero();
+    if (remaining >= seg_elems) {
+#pragma unroll 8
+        for (int i = 0; i < EV_K; ++i) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[(size_t)tid + (size_t)EV_T * i]));
+    } else {
+        for (int i = 0; i < EV_K; ++i) {
+            size_t j = (size_t)tid + (size_t)EV_T * i;
+            if (j < remaining) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[j]));
+        }
+    }
+    acc = f4_mul(acc, ld4(xpow + 4 * tid));
+    __syncthreads();
+    st4(xpow + 4 * tid, acc);
+    __syncthreads();
+    for (int s = EV_T / 2; s > 0; s >>= 1) {
+        if ((int)tid < s) st4(xpow + 4 * tid, f4_add(ld4(xpow + 4 * tid), ld4(xpow + 4 * (tid + s))));
+        __syncthreads();
+    }
+    if (tid == 0) st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(xpow), f4_pow(x, base)));
 }
 __global__ void eval_final_kernel(const uint32_t* __restrict__ partials, uint32_t segs, uint32_t* __restrict__ out,
                                   uint32_t evals) {

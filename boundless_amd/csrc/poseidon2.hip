@@ -185,17 +185,18 @@ __global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ i
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// Bottom of the tree in one launch: a workgroup folds its 256 leaf digests down to one node per level through
-// LDS, writing every intermediate layer.  Levels above log2(256) use hash_fold_kernel.
+// Small layers in one launch: a workgroup owns `per_wg` (<= 512) consecutive input digests and folds them `levels`
+// levels deep through LDS, writing every intermediate layer.  Used once a layer no longer fills the chip, where each
+// separate launch would cost a full single-wave permutation latency.
 __global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
-                                                              uint32_t input_size, int levels) {
+                                                              uint32_t input_size, uint32_t per_wg, int levels) {
     __shared__ uint32_t sh[256 * 8];
     const uint32_t tid = threadIdx.x;
-    // level 0: 512 inputs -> 256 outputs, one per lane
+    uint32_t width = per_wg >> 1;  // outputs of this workgroup at the current level
     uint32_t out_size = input_size >> 1;
-    uint32_t i = blockIdx.x * 256u + tid;
     uint32_t s[CELLS];
-    {
+    if (tid < width) {
+        const uint32_t i = blockIdx.x * width + tid;
         const uint4* src = reinterpret_cast<const uint4*>(io + ((size_t)input_size + 2 * (size_t)i) * 8);
         uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
         s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
@@ -209,10 +210,11 @@ __global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restri
         o[0] = make_uint4(s[0], s[1], s[2], s[3]);
         o[1] = make_uint4(s[4], s[5], s[6], s[7]);
     }
-    uint32_t width = 256;
     for (int lvl = 1; lvl < levels; ++lvl) {
+        if (tid < width) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sh[tid * 8 + k] = s[k];
+            for (int k = 0; k < 8; ++k) sh[tid * 8 + k] = s[k];
+        }
         __syncthreads();
         width >>= 1;
         out_size >>= 1;
@@ -314,15 +316,11 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
     size_t size = rows;
     const size_t fuse_below = (size_t)c->fold_fuse_below;
     while (size > 1) {
-        if (size >= 512 && size <= fuse_below) {
-            int levels = 0;
-            size_t s = size;
-            while (levels < 9 && s >= 2) {
-                s >>= 1;
-                levels++;
-            }
-            hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / 512)), dim3(256), 0, c->stream, n, c->d_p2,
-                               (uint32_t)size, levels);
+        if (size <= fuse_below) {
+            size_t per_wg = size < 512 ? size : 512;
+            int levels = ilog2(per_wg);
+            hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / per_wg)), dim3(256), 0, c->stream, n, c->d_p2,
+                               (uint32_t)size, (uint32_t)per_wg, levels);
             BX_LAUNCH_CHECK(c);
             size >>= levels;
         } else {

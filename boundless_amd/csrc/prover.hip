@@ -47,21 +47,28 @@ struct CheckArgs {
 };
 __global__ __launch_bounds__(256) void synth_eval_check_kernel(uint32_t* __restrict__ check, CheckArgs a,
                                                                const uint32_t* __restrict__ mixpows, uint32_t rows) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // 4 consecutive rows per lane: 16-byte loads/stores, HBM-bound (every committed evaluation is read once)
+    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (r >= rows) return;
-    Fp4 acc = f4_zero();
+    Fp4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
     uint32_t gi = 0;
     for (int g = 0; g < 3; ++g) {
         const uint32_t* e = a.eval[g] + r;
         for (uint32_t c = 0; c < a.width[g]; ++c, ++gi) {
-            uint32_t v = e[(size_t)c * rows];
-            uint32_t t = fp_add(fp_mul(fp_mul(v, v), v), v);
-            uint4 w = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)gi);  // wave-uniform
-            acc = f4_add(acc, f4_scale(Fp4{{w.x, w.y, w.z, w.w}}, t));
+            const uint4 v4 = *reinterpret_cast<const uint4*>(e + (size_t)c * rows);
+            const uint4 w4 = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)gi);  // wave-uniform
+            const Fp4 w{{w4.x, w4.y, w4.z, w4.w}};
+            const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t t = fp_add(fp_mul(fp_mul(v[k], v[k]), v[k]), v[k]);
+                acc[k] = f4_add(acc[k], f4_scale(w, t));
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) check[(size_t)k * rows + r] = acc.c[k];
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<uint4*>(check + (size_t)k * rows + r) = make_uint4(acc[0].c[k], acc[1].c[k], acc[2].c[k], acc[3].c[k]);
 }
 // MerkleTreeProver::prove for a batch of queries (one workgroup per query).
 __global__ void merkle_query_gather_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
@@ -358,7 +365,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
             a.width[g] = p->groups[g].width;
         }
         // the 16N-word check buffer holds the 4 ext planes over the 4N domain
-        hipLaunchKernelGGL(synth_eval_check_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(synth_eval_check_kernel, dim3((unsigned)((D / 4 + 255) / 256)), dim3(256), 0, c->stream,
                            (uint32_t*)CK.coeffs.b.dptr, a, (const uint32_t*)p->mixpows.b.dptr, (uint32_t)D);
         if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: eval_check launch failed");
         PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
