@@ -17,50 +17,63 @@ constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Instruction budget.  Every 32-bit integer VALU op issues at the same rate on gfx950 (profiles/r01_microbench_valu.jsonl),
-// a canonical modular add is 3 instructions and a Montgomery product 5, so the permutation is organised to minimise
-// instruction count:
+// a canonical modular add is 3 instructions and a canonical Montgomery product 5, so the permutation is organised to
+// minimise instruction count, not multiplications:
 //   * linear layers run UNREDUCED in 64 bits: v_mad_u64_u32 multiplies by the small matrix entries and accumulates in
-//     one instruction (external layer: every output < 112 P < 2^38; internal-layer sum < 24 P);
+//     one instruction (external layer outputs < 2^38, internal-layer sum < 2^37);
 //   * the return to 32 bits is one Montgomery reduction per cell, and the next round constant rides in its
-//     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [all mod P, REDC = * 2^-32];
-//   * the S-box keeps lazy intermediates (see sbox7).
-// ~9.0 k instructions per permutation instead of ~14.5 k for the reduce-after-every-add form.
-// All cell values handed between rounds are canonical (< P); the bounds that make each step exact are stated inline.
+//     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [mod P, REDC = * 2^-32];
+//   * cells are kept only BOUNDED, not canonical, between rounds; a conditional subtraction is spent only where a
+//     bound would otherwise break.  Results are congruent mod P at every step and the words that leave the permutation
+//     are canonical, so the output is bit-identical to the reduce-everywhere form (~8 k instead of ~14.5 k instructions).
+//
+// Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
+//   red64_lazy output                  < M1 + 18 + P                       < 1.13334 P          (M1 = 2^32 mod P)
+//   sbox7_bounded(x < 1.13334 P):  x2 = lazy(x,x) < 1.60209 P -> reduce -> x2r < P
+//                                  x3 = lazy(x2r,x) < 1.53125 P,  x4 = lazy(x2r,x2r) < 1.46875 P
+//                                  x7 = lazy(x3,x4): product 2.24902 P^2 (ok), x7 < 2.05423 P < 2^32 -> one subtract -> < 1.05423 P
+//   m_ext64(cells < 1.05423 P):    32-bit pair sums < 2.10846 P < 2^32; rows sum to <= 16 so w < 16.87 P, y < 118.1 P < 2^38, y_hi < 56
+//   internal rounds:               cell i >= 1: lazy(d_i, s_i, sum_r) with s_i < B P gives < (rho B + 1) P: B grows from 1.13334
+//                                  towards the fixed point 1/(1 - rho) = 1.88235 and never passes it (< 2^32 / P = 2.1333);
+//                                  product B P^2 + 2P < 2.42 P^2;  sum < (1.06 + 23 * 1.8824) P < 2^37, sum_hi < 22;
+//                                  sum_r and the S-box cell are reduced to canonical every round.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
 
-// x^7 for canonical x with lazy intermediates (fp_mad_lazy's contract: product < 2.42 P^2, result < product/2^32 + P):
-//   x2 = x*x          < 1.469 P        x3 = x2*x  (1.469 P^2)   < 1.689 P
-//   x4 = x2*x2 (2.158 P^2) < 2.012 P -> one conditional subtract: x4r < 1.012 P
-//   x7 = x3*x4r (1.709 P^2) < 1.802 P -> reduce.      16 instructions.
-__device__ __forceinline__ uint32_t sbox7(uint32_t x) {
-    uint32_t x2 = fp_mul_lazy(x, x);
+// x^7 for x < 1.13334 P; returns a value < 1.05423 P congruent to x^7 * 2^(-6*32) (Montgomery).  16 instructions.
+__device__ __forceinline__ uint32_t sbox7_bounded(uint32_t x) {
+    uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
     uint32_t x3 = fp_mul_lazy(x2, x);
-    uint32_t x4 = fp_reduce(fp_mul_lazy(x2, x2));
+    uint32_t x4 = fp_mul_lazy(x2, x2);
     return fp_reduce(fp_mul_lazy(x3, x4));
 }
 
-// (y + add * 2^-32 ... ) -> canonical:  returns (y mod P + a) mod P where `add_rr` = a * 2^64 mod P (a in the cells'
-// Montgomery representation).  y < 2^38.  acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr
-//   < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18, so acc + m*P < 2^64 and the lazy result is
-//   < 268435473 + P < 2P: one conditional subtraction makes it canonical.  6 instructions.
-__device__ __forceinline__ uint32_t red64(uint64_t y, uint32_t add_rr) {
+// y (< 2^38, unreduced linear-layer output) plus a round constant -> 32 bits:  r == y + a (mod P), r < 1.13334 P, where
+// `add_rr` = a * 2^64 mod P (a in the cells' Montgomery representation).
+//   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18,
+// so acc + m*P < 2^64 and r < 268435473 + P.  4 instructions (+2 for the canonical form).
+__device__ __forceinline__ uint32_t red64_lazy(uint64_t y, uint32_t add_rr) {
     uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
     acc = mad64((uint32_t)(y >> 32), R2, acc);
     uint32_t m = (uint32_t)acc * NEG_P_INV;
-    return fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
+    return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
 }
+__device__ __forceinline__ uint32_t red64(uint64_t y, uint32_t add_rr) { return fp_reduce(red64_lazy(y, add_rr)); }
 
-// external layer circ(2*M4, M4, ..., M4) on canonical cells, unreduced 64-bit outputs:
-//   w_k = M4 * x_k  (rows [5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]; each < 16 P),  T = sum_k w_k (< 96 P),  y_k = w_k + T.
+// external layer circ(2*M4, M4, ..., M4) on bounded cells (< 1.05423 P), unreduced 64-bit outputs:
+//   w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B) in mixed width:
+//   t0 = a+b, t1 = c+d (32-bit), t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
 __device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
 #pragma unroll
     for (int k = 0; k < CELLS; k += 4) {
         const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
-        y[k] = mad64(5u, a, mad64(7u, b, mad64(3u, d, (uint64_t)c)));
-        y[k + 1] = mad64(4u, a, mad64(6u, b, (uint64_t)(c + d)));  // c + d < 2P < 2^32
-        y[k + 2] = mad64(3u, b, mad64(5u, c, mad64(7u, d, (uint64_t)a)));
-        y[k + 3] = mad64(4u, c, mad64(6u, d, (uint64_t)(a + b)));
+        const uint32_t t0 = a + b, t1 = c + d;
+        const uint64_t t2 = mad64(2u, b, (uint64_t)t1), t3 = mad64(2u, d, (uint64_t)t0);
+        const uint64_t t4 = mad64(4u, t1, t3), t5 = mad64(4u, t0, t2);
+        y[k] = t3 + t5;
+        y[k + 1] = t5;
+        y[k + 2] = t2 + t4;
+        y[k + 3] = t4;
     }
     uint64_t t[4];
 #pragma unroll
@@ -73,39 +86,40 @@ __device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
     for (int i = 0; i < CELLS; ++i) y[i] += t[i & 3];
 }
 
-// Device parameter table (all words Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride in a
-// REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
+// Device parameter table (round constants Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride
+// in a REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
 // [213,237) internal diagonal (plain Montgomery form, used as a multiplier).
+// Input: cells < P (canonical).  Output: canonical.
 __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
     uint64_t y[CELLS];
     // initial external layer; round-0 constants ride in the reduction
     m_ext64(s, y);
 #pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], prm[i]);
+    for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
     // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
     // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(s[i]);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
         m_ext64(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], rc[i]);
+            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
         } else {
-            s[0] = red64(y[0], prm[96]);
+            s[0] = red64_lazy(y[0], prm[96]);
 #pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = red64(y[i], 0u);
+            for (int i = 1; i < CELLS; ++i) s[i] = red64_lazy(y[i], 0u);
         }
     }
-    // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum (< 24 P) is accumulated in 64 bits, turned into
-    // sum_r = sum * 2^32 mod P by one reduction (acc < 2^32 * R2 + 24 * R3, lazy result < R2 + 24 + P < 2P), and rides
-    // in each cell's REDC accumulator together with the next constant: d*s + sum_r + rc < P^2 + 3P.
+    // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
+    // sum_r = sum * 2^32 mod P (canonical) by one reduction (acc < 2^32 * R2 + 22 * R3), and rides in each cell's REDC
+    // accumulator together with the next constant (sum_r + rc < 2P fits 32 bits).
     const uint32_t* diag = prm + 213;
 #pragma unroll 1
     for (int r = 0; r < RP; ++r) {
-        s[0] = sbox7(s[0]);
+        s[0] = sbox7_bounded(s[0]);
         uint64_t sum = (uint64_t)s[0];
 #pragma unroll
         for (int i = 1; i < CELLS; ++i) sum = mad64(1u, s[i], sum);
@@ -114,11 +128,11 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
         const uint32_t m = (uint32_t)acc * NEG_P_INV;
         const uint32_t sum_r = fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
         if (r < RP - 1) {
-            s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));  // next internal constant (sum < 2P)
+            s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));  // next internal constant rides along
 #pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r));
+            for (int i = 1; i < CELLS; ++i) s[i] = fp_mad_lazy(diag[i], s[i], sum_r);  // bounded, see the table above
         } else {
-            const uint32_t* rc = prm + 117;  // external round 4's constants
+            const uint32_t* rc = prm + 117;  // external round 4's constants; back to canonical for the S-boxes
 #pragma unroll
             for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r + rc[i]));
         }
@@ -127,15 +141,15 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7(s[i]);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
         m_ext64(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], rc[i]);
+            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], 0u);
+            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], 0u);  // canonical words leave the permutation
         }
     }
 }
