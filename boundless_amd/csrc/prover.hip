@@ -379,7 +379,9 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     const Fp4 Z = T.random_ext();
     const uint32_t back_one = fp_inv(fp_pow(fp_encode(137u), (uint64_t)1 << (27 - po2)));  // ROU_REV[po2]
     const Fp4 Zb = f4_scale(Z, back_one);
-    const Fp4 Z4 = host_pow(Z, 4);
+    // check columns hold g(3z) of the split check(y) = sum_q y^q g_q(y^4), so their tap is z = Z^4 / 3: the verifier can
+    // then test check(Z) against the trace taps (verify.cpp)
+    const Fp4 Z4 = f4_scale(host_pow(Z, 4), fp_inv(MONT_THREE));
     std::vector<uint32_t> coeff_u;  // flattened ext elems, column by column, group by group
     for (int g = 0; g < 4; ++g) {
         Group& G = p->groups[g];

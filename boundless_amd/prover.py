@@ -45,6 +45,11 @@ class SegmentReceipt:
     def get_seal_bytes(self):
         return self.seal.tobytes()
 
+    def verify_integrity(self):
+        """`SegmentReceipt::verify_integrity_with_context` (bento/crates/workflow/src/tasks/prove.rs:53-55): CPU check of the
+        whole seal (transcript, check identity, Merkle openings, DEEP quotients, FRI chain).  Raises on rejection."""
+        verify_seal(self.seal)
+
 
 def _declare(lib):
     if getattr(lib, "_bx_prover_declared", False):
@@ -60,7 +65,19 @@ def _declare(lib):
     lib.bx_prove_segment.restype = C.c_char_p
     lib.bx_prover_last_roots.argtypes = [C.c_void_p, C.c_void_p]
     lib.bx_prover_last_roots.restype = C.c_char_p
+    lib.bx_verify_segment.argtypes = [C.c_void_p, sz]
+    lib.bx_verify_segment.restype = C.c_char_p
     lib._bx_prover_declared = True
+
+
+def verify_seal(seal_words):
+    """Host-side verifier (include/bx_prover.h: bx_verify_segment); needs no GPU."""
+    lib = load_library()
+    _declare(lib)
+    a = np.ascontiguousarray(seal_words, dtype=np.uint32)
+    msg = lib.bx_verify_segment(a.ctypes.data, a.size)
+    if msg:
+        raise HalError(msg.decode())
 
 
 class HipProverServer:

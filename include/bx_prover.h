@@ -57,6 +57,13 @@ const char* bx_prover_last_roots(const bx_prover* prover, uint32_t roots_out[32]
 const char* bx_merkle_query_gather(bx_ctx* ctx, bx_buf out, bx_buf matrix, bx_buf nodes_digests, size_t rows,
                                    size_t cols, bx_buf positions_u32, size_t n_queries, size_t top_size);
 
+/* CPU verifier of a seal produced by bx_prove_segment (the reference verifies every receipt right after proving it:
+ * bento/crates/workflow/src/tasks/prove.rs:53-55 `segment_receipt.verify_integrity_with_context`).  Pure host code, no
+ * ctx and no GPU needed.  Replays the Poseidon2 transcript, checks the check-polynomial identity at Z, every Merkle
+ * opening, the DEEP quotient at each of the 50 query points and the FRI folding chain down to the final polynomial.
+ * Returns NULL when the seal is accepted, otherwise a message (thread-local storage) naming the first failed check. */
+const char* bx_verify_segment(const uint32_t* seal, size_t seal_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,7 +230,7 @@ uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint
     /* DEEP: taps */
     e4 Z = iop_random_ext(&io);
     e4 Zb = e4scale(Z, bxo_rou_rev(po2));
-    e4 Z4 = e4mul(e4mul(Z, Z), e4mul(Z, Z));
+    e4 Z4 = e4scale(e4mul(e4mul(Z, Z), e4mul(Z, Z)), bxo_fp_inv(bxo_fp_encode(3))); /* tap of the check columns: Z^4 / 3 */
     size_t total_taps = 0;
     for (int g = 0; g < 4; g++)
         for (uint32_t c = 0; c < grp[g].width; c++) total_taps += grp[g].taps[c];

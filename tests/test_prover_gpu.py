@@ -25,6 +25,7 @@ def test_seal_bit_exact_vs_oracle(po2, widths, seed):
         assert receipt.seal.size == seal.size
         bad = np.nonzero(receipt.seal != seal)[0]
         assert bad.size == 0, f"first differing seal word at {bad[:5]}"
+        receipt.verify_integrity()  # prove.rs:53-55
         # same prover object, next segment (buffers are reused): still exact, and different from the first
         r2 = srv.prove_segment(Segment(index=1, po2=po2, seed=seed + 1))
         s2, _ = ol.prove_segment(po2, *widths, seed + 1)
@@ -65,6 +66,7 @@ def test_full_size_properties(po2):
             s //= 16
             n_rounds += 1
         assert r.seal[:4].tolist() == [po2, 16, 256, 64]
+        r.verify_integrity()  # the full-size seal is accepted by the CPU verifier
         assert r.seal.size == srv.lib.bx_prover_seal_words(srv.handle)
         r2 = srv.prove_segment(Segment.synthetic(0, po2))
         assert np.array_equal(r.seal, r2.seal)
