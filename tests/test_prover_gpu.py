@@ -72,3 +72,27 @@ def test_full_size_properties(po2):
         assert np.array_equal(r.seal, r2.seal)
     finally:
         srv.close()
+
+
+def test_agent_feed_loop_with_the_hip_prover():
+    """tasks/prove.rs flow end to end on the GPU: segment blob in the hot store -> prove -> verify -> receipt stored."""
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import HipProverServer, Segment, verify_seal
+
+    srv = HipProverServer(0, po2=12, widths=(4, 12, 4))
+    try:
+        a = ag.Agent(prover=srv, poll_time=0.0)
+        for i in range(3):
+            a.store.set_key_with_expiry(f"job:J:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=12)), 600)
+            a.stream.create_task("J", f"prove-{i}", {"Prove": {"index": i}})
+        assert ag.poll_work(a, max_idle_polls=1) == 3
+        assert a.store.keys() == [f"job:J:recursion_receipts:prove-{i}" for i in range(3)]
+        for i in range(3):
+            rec = ag.deserialize_receipt(a.store.get(f"job:J:recursion_receipts:prove-{i}"))
+            assert rec.index == i
+            verify_seal(rec.seal)
+            want, _ = ol.prove_segment(12, 4, 12, 4, Segment.synthetic(i, po2=12).seed)
+            assert np.array_equal(rec.seal, want)
+        assert a.metrics.ops[("prove", "complete", "success")] == 3
+    finally:
+        srv.close()
