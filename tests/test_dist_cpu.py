@@ -4,6 +4,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,10 +22,9 @@ def run_world(script, world=2, timeout=180):
     port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-"]
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    outdir = tempfile.mkdtemp(prefix="bxdist")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", BX_TEST_OUT=outdir)
     # torchrun cannot read a script from stdin: write it to a temp file
-    import tempfile
-
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(textwrap.dedent(script))
         path = f.name
@@ -34,7 +34,8 @@ def run_world(script, world=2, timeout=180):
     finally:
         os.unlink(path)
     assert r.returncode == 0, r.stdout + r.stderr
-    return [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    # one file per rank: concurrent prints to a shared stdout can interleave
+    return [json.load(open(os.path.join(outdir, f))) for f in sorted(os.listdir(outdir))]
 
 
 WORKER = """
@@ -55,7 +56,8 @@ for mode in ("static", "steal"):
         return len(mine)
     elapsed, n = timed_region(work, dist)
     out[mode] = {"mine": mine, "elapsed": elapsed}
-print(json.dumps(out), flush=True)
+import os
+json.dump(out, open(os.path.join(os.environ["BX_TEST_OUT"], f"rank{rank}.json"), "w"))
 dist.destroy_process_group()
 """
 
