@@ -75,12 +75,12 @@ __device__ __forceinline__ uint32_t sbox7_bounded(uint32_t x) {
 //   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18,
 // so acc + m*P < 2^64 and r < 268435473 + P.  4 instructions (+2 for the canonical form).
 __device__ __forceinline__ uint32_t red64_lazy(uint64_t y, uint32_t add_rr) {
-    const uint32_t m1 = MONT_ONE;  // in a VGPR: the SGPR addend already uses the instruction's constant-bus slot
-    uint64_t acc = mad_vvs((uint32_t)y, m1, (uint64_t)add_rr);  // add_rr is wave-uniform (scalar load of the table)
+    uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
     acc = mad64((uint32_t)(y >> 32), R2, acc);
     uint32_t m = (uint32_t)acc * NEG_P_INV;
     return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
 }
+__device__ __forceinline__ uint32_t red64(uint64_t y, uint32_t add_rr) { return fp_reduce(red64_lazy(y, add_rr)); }
 // the same without a constant (addend literal 0)
 __device__ __forceinline__ uint32_t red64_lazy0(uint64_t y) {
     uint64_t acc = mad64((uint32_t)(y >> 32), R2, mad64((uint32_t)y, MONT_ONE, 0ull));
@@ -96,13 +96,12 @@ __device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
     for (int k = 0; k < CELLS; k += 4) {
         const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
         const uint32_t t0 = a + b, t1 = c + d;  // < 2.10846 P < 2^32
-        // 32-bit values only ever enter as multiplicands, so nothing needs zero-extending:
-        const uint64_t w1 = madk<4>(t0, madk<2>(b, madk0<1>(t1)));  // t5 = 4 t0 + 2b + t1 = 4a + 6b + c + d
-        const uint64_t w3 = madk<4>(t1, madk<2>(d, madk0<1>(t0)));  // t4 = 4 t1 + 2d + t0 = a + b + 4c + 6d
-        y[k] = madk<2>(d, madk<1>(t0, w1));                         // t3 + t5 = 5a + 7b + c + 3d
-        y[k + 1] = w1;
-        y[k + 2] = madk<2>(b, madk<1>(t1, w3));                     // t2 + t4 = a + 3b + 5c + 7d
-        y[k + 3] = w3;
+        const uint64_t t2 = mad64(2u, b, (uint64_t)t1), t3 = mad64(2u, d, (uint64_t)t0);
+        const uint64_t t4 = mad64(4u, t1, t3), t5 = mad64(4u, t0, t2);
+        y[k] = t3 + t5;
+        y[k + 1] = t5;
+        y[k + 2] = t2 + t4;
+        y[k + 3] = t4;
     }
     uint64_t t[4];
 #pragma unroll
@@ -125,24 +124,22 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
     m_ext64(s, y);
 #pragma unroll
     for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
-    // external rounds 0..2: S-box, layer, reduction with the NEXT round's constants
+    // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
+    // the first internal round's)
 #pragma unroll 1
-    for (int r = 0; r < RF_HALF - 1; ++r) {
+    for (int r = 0; r < RF_HALF; ++r) {
 #pragma unroll
         for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
         m_ext64(s, y);
-        const uint32_t* rc = prm + (r + 1) * CELLS;
+        if (r < RF_HALF - 1) {
+            const uint32_t* rc = prm + (r + 1) * CELLS;
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
-    }
-    // external round 3: afterwards only cell 0 has a constant (the first internal round's)
-    {
+            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
+        } else {
+            s[0] = red64_lazy(y[0], prm[96]);
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
-        s[0] = red64_lazy(y[0], prm[96]);
-#pragma unroll
-        for (int i = 1; i < CELLS; ++i) s[i] = red64_lazy0(y[i]);
+            for (int i = 1; i < CELLS; ++i) s[i] = red64_lazy(y[i], 0u);
+        }
     }
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
     // sum_r = sum * 2^32 mod P (canonical) by one reduction (acc < 2^32 * R2 + 22 * R3), and rides in each cell's REDC
@@ -168,23 +165,20 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
             for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r + rc[i]));
         }
     }
-    // external rounds 4..6
+    // external rounds 4..7
 #pragma unroll 1
-    for (int r = 0; r < RF_HALF - 1; ++r) {
+    for (int r = 0; r < RF_HALF; ++r) {
 #pragma unroll
         for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
         m_ext64(s, y);
-        const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
+        if (r < RF_HALF - 1) {
+            const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
-    }
-    // external round 7: canonical words leave the permutation
-    {
+            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
-#pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(red64_lazy0(y[i]));
+            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], 0u);  // canonical words leave the permutation
+        }
     }
 }
 
