@@ -13,9 +13,14 @@ data-path collective ("scaling": "weak"); torch.distributed (RCCL) only provides
 Inputs are generated on the device (no host buffers cross PCIe in the timed region except the seal and the
 Fiat-Shamir digests, exactly as in the reference's prover).
 
+By default two segments are in flight per GPU (two provers, two streams, two host threads): the second segment fills the
+latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +15 % throughput; a step is then one
+batch of `--inflight` segments per GPU and `value` counts segments.
+
 The JSON line also carries
   roofline      the NTT/LDE entry point named by BASELINE's metric: algorithmic bytes / HIP-event time on the HAL
-                stream, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is VALU-issue-bound);
+                stream over the timed region, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is
+                VALU-issue-bound); `roofline_isolated` is the same measured with a single segment in flight;
   kernels       the same for every HAL entry point in the timed region;
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
                 box's host cores on a bounded sample.
@@ -146,6 +151,19 @@ def main():
     elapsed = max_over_ranks(elapsed, dist)
     proved_total = int(round(sum_over_ranks(proved, dist)))
 
+    # Isolated probe (untimed, rank 0 only): with several segments in flight the HIP-event durations of the timed region
+    # include time-slicing with the other stream, so one extra segment is proved alone to get each entry point's own
+    # duration (this is what a rocprofv3 --kernel-trace of `--inflight 1` reports).
+    iso = {}
+    if rank == 0 and len(servers) > 1:
+        sv = servers[0]
+        sv.hal.profile_reset()
+        sv.hal.profile_enable(True)
+        sv.prove_segment(Segment.synthetic(index=10**6, po2=args.po2))
+        sv.hal.profile_enable(False)
+        iso = sv.hal.profile_report()
+    barrier()
+
     if rank == 0:
         kernels = {}
         for name, r in prof.items():
@@ -155,6 +173,23 @@ def main():
                              "ms_per_step": round(r["ms"] / max(proved, 1), 3), "alg_GBps": round(gbps, 1),
                              "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
         ntt = kernels.get("batch_expand_into_evaluate_ntt", {})
+        iso_k = {}
+        for name, r in iso.items():
+            ms = r["ms"] / max(r["calls"], 1)
+            gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            iso_k[name] = {"avg_ms": round(ms, 4), "ms_per_step": round(r["ms"], 3), "alg_GBps": round(gbps, 1),
+                           "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
+        # HBM traffic of the LDE's two kernels from the committed PMC passes of this same command (separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/pmc_traffic.py); None when the file is absent
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")))["kernels"]
+            sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k]
+            if sel:
+                launches = max(v["launches"] for v in sel)
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / launches
+        except Exception:
+            traffic = None
         dom_name = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         out = {
             "metric": "segment-proofs/sec @ 2^20 cycles",
@@ -183,9 +218,16 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": ntt.get("frac_hbm"),
-                "traffic": None,
-                "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream",
+                "traffic": traffic,
+                "achieved_bytes_per_launch": (ntt.get("alg_GBps", 0) or 0) * 1e9 * (ntt.get("avg_ms", 0) or 0) * 1e-3,
+                "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream; traffic = "
+                        "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r01_bench_pmc_traffic.json",
             },
+            "roofline_isolated": ({"kernel": "batch_expand_into_evaluate_ntt", "bound": "hbm",
+                                   "achieved": iso_k["batch_expand_into_evaluate_ntt"]["alg_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": iso_k["batch_expand_into_evaluate_ntt"]["frac_hbm"],
+                                   "note": "same entry point with one segment in flight (no stream sharing)",
+                                   "kernels": iso_k} if iso_k else None),
             "roofline_dominant": {"kernel": dom_name, **(kernels.get(dom_name, {}) if dom_name else {}),
                                   "note": "Poseidon2 is VALU-issue-bound (no HBM or MFMA roofline applies); see DESIGN.md §4"},
             "kernels": kernels,
