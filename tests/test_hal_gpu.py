@@ -123,6 +123,26 @@ def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, fast, block_log, til
         hal.set_tunable("ntt_tile_b_log", 13)
 
 
+@pytest.mark.parametrize("bits", [21, 22])
+def test_ntt_largest_segment_sizes(hal, oracle, bits):
+    """po2 21/22 segments: 2^23 / 2^24-point LDEs (pass B with 2^11 / 2^12 rows), one column, vs the oracle."""
+    n = 1 << bits
+    x = rnd(bits, n)
+    ref = x.copy()
+    io = hal.copy_from(x)
+    hal.batch_interpolate_ntt(io, 1)
+    oracle.bxo_batch_interpolate_ntt(ref, 1, n)
+    assert np.array_equal(io.view(), ref)
+    out = hal.alloc(4 * n)
+    hal.batch_expand_into_evaluate_ntt(out, io, 1, 2)
+    ref_out = np.zeros(4 * n, np.uint32)
+    oracle.bxo_batch_expand_into_evaluate_ntt(ref_out, ref, 1, n, 2)
+    assert np.array_equal(out.view(), ref_out)
+    hal.batch_bit_reverse(io, 1)
+    oracle.bxo_batch_bit_reverse(ref, 1, n)
+    assert np.array_equal(io.view(), ref)
+
+
 def test_ntt_linearity_full_size(hal):
     n = 1 << 20
     a, b = rnd(1, n), rnd(2, n)
