@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE configs[2]: prove this many segments in total, claimed from a shared queue (--steal) instead of --steps per rank")
     ap.add_argument("--steal", action="store_true", help="claim-when-idle ticket queue instead of the static rank split")
+    ap.add_argument("--dist-backend", type=str, default=None, help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 path be exercised on a single-GPU box")
+    ap.add_argument("--device", type=int, default=None, help="force the HIP device index for every rank (testing only; default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-po2", type=int, default=16)
     args = ap.parse_args()
@@ -89,7 +91,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
-    rank, world, local_rank, dist = init_distributed()
+    rank, world, local_rank, dist = init_distributed(args.dist_backend)
+    if args.device is not None:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
 
     from boundless_amd.prover import HipProverServer, Segment

@@ -25,6 +25,7 @@ def init_distributed(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kwargs = {}
     if backend == "nccl":
+        torch.cuda.set_device(local_rank)
         kwargs["device_id"] = torch.device("cuda", local_rank)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, **kwargs)
