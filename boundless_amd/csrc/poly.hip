@@ -226,6 +226,63 @@ __global__ void div_apply_kernel(uint32_t* __restrict__ poly, size_t size, Fp4 z
     }
 }
 
+// ---- prefix_products: inclusive running product of ext elements, same three-phase shape as poly_divide ----
+constexpr int PP_L = 64;
+__global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, uint32_t* __restrict__ agg, size_t chunks) {
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= chunks) return;
+    size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
+    Fp4 p = f4_one();
+    for (size_t i = lo; i < hi; ++i) p = f4_mul(p, ld4(io + 4 * i));
+    st4(agg + 4 * ch, p);
+}
+// agg[ch] <- product of all chunks before ch (exclusive scan), one workgroup, log-step scan across threads
+__global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks) {
+    extern __shared__ uint32_t sh[];
+    const uint32_t nt = blockDim.x, tid = threadIdx.x;
+    size_t per = (chunks + nt - 1) / nt;
+    size_t lo = (size_t)tid * per < chunks ? (size_t)tid * per : chunks;
+    size_t hi = lo + per < chunks ? lo + per : chunks;
+    Fp4 mine = f4_one();
+    for (size_t ch = lo; ch < hi; ++ch) mine = f4_mul(mine, ld4(agg + 4 * ch));
+    Fp4 incl = mine;
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        st4(sh + 4 * tid, incl);
+        __syncthreads();
+        if (tid >= d) incl = f4_mul(incl, ld4(sh + 4 * (tid - d)));
+        __syncthreads();
+    }
+    st4(sh + 4 * tid, incl);
+    __syncthreads();
+    Fp4 carry = tid == 0 ? f4_one() : ld4(sh + 4 * (tid - 1));
+    for (size_t ch = lo; ch < hi; ++ch) {
+        Fp4 a = ld4(agg + 4 * ch);
+        st4(agg + 4 * ch, carry);
+        carry = f4_mul(carry, a);
+    }
+}
+__global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint32_t* __restrict__ carry_in, size_t chunks) {
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= chunks) return;
+    size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
+    Fp4 p = ld4(carry_in + 4 * ch);
+    for (size_t i = lo; i < hi; ++i) {
+        p = f4_mul(p, ld4(io + 4 * i));
+        st4(io + 4 * i, p);
+    }
+}
+__global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __restrict__ index, const uint32_t* __restrict__ offsets,
+                               const uint32_t* __restrict__ values, size_t entries, size_t into_len, uint32_t first, uint32_t* __restrict__ bad) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x + first;
+    if (e >= entries) return;
+    uint32_t o = offsets[e];
+    if (o < into_len) {
+        into[o] = values[e];
+    } else {
+        *bad = 1u;
+    }
+}
+
 const char* ensure_scratch(bx_ctx* c, size_t words) {
     if (c->scratch_words >= words) return nullptr;
     if (c->d_scratch) {
@@ -377,5 +434,54 @@ extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4
     hipLaunchKernelGGL(div_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)poly.dptr,
                        size, zz, c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) {
+    if (!c) return "bx_prefix_products: null ctx";
+    BX_REQUIRE(c, io.len % 4 == 0, "prefix_products: buffer must hold AoS ext elements");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t n = io.len / 4;
+    if (n < 2) return nullptr;
+    OpScope op(c, "prefix_products", 8.0 * (double)io.len);
+    size_t chunks = (n + PP_L - 1) / PP_L;
+    BX_TRY(ensure_scratch(c, 4 * chunks + 8));
+    hipLaunchKernelGGL(pp_local_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)io.dptr, n,
+                       c->d_scratch, chunks);
+    BX_LAUNCH_CHECK(c);
+    unsigned nt = chunks >= 1024 ? 1024 : 64;
+    hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(nt), nt * 16, c->stream, c->d_scratch, chunks);
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(pp_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n,
+                       c->d_scratch, chunks);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf offsets, bx_buf values) {
+    if (!c) return "bx_scatter: null ctx";
+    BX_REQUIRE(c, offsets.len == values.len, "scatter: offsets and values must have the same length");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (index.len < 2 || offsets.len == 0) return nullptr;
+    // entries [index[0], index[last]) are written; the per-cycle grouping only orders writes that hit the same offset,
+    // which upstream's circuits never produce, so one pass over the range is equivalent.
+    uint32_t ends[2];
+    BX_HIP(c, hipMemcpyAsync(&ends[0], index.dptr, 4, hipMemcpyDeviceToHost, c->stream));
+    BX_HIP(c, hipMemcpyAsync(&ends[1], (const uint32_t*)index.dptr + (index.len - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_REQUIRE(c, ends[0] <= ends[1] && ends[1] <= offsets.len, "scatter: index range exceeds offsets/values");
+    if (ends[0] == ends[1]) return nullptr;
+    OpScope op(c, "scatter", 12.0 * (double)(ends[1] - ends[0]));
+    BX_TRY(ensure_scratch(c, 8));
+    BX_HIP(c, hipMemsetAsync(c->d_scratch, 0, 4, c->stream));
+    size_t cnt = ends[1] - ends[0];
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)into.dptr,
+                       (const uint32_t*)index.dptr, (const uint32_t*)offsets.dptr, (const uint32_t*)values.dptr, (size_t)ends[1],
+                       into.len, ends[0], c->d_scratch);
+    BX_LAUNCH_CHECK(c);
+    uint32_t bad = 0;
+    BX_HIP(c, hipMemcpyAsync(&bad, c->d_scratch, 4, hipMemcpyDeviceToHost, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_REQUIRE(c, bad == 0, "scatter: an offset is outside the destination buffer");
     return nullptr;
 }

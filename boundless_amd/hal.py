@@ -75,6 +75,8 @@ def load_library():
         "bx_eltwise_sum_extelem": [ctx, BxBuf, BxBuf],
         "bx_gather_sample": [ctx, BxBuf, BxBuf, sz, sz, sz],
         "bx_poly_divide": [ctx, BxBuf, u32p, BxBuf],
+        "bx_prefix_products": [ctx, BxBuf],
+        "bx_scatter": [ctx, BxBuf, BxBuf, BxBuf, BxBuf],
         "bx_timer_start": [ctx],
         "bx_timer_stop": [ctx, C.POINTER(C.c_float)],
         "bx_profile_enable": [ctx, C.c_int],
@@ -262,6 +264,12 @@ class HipHal:
     def poly_divide(self, poly, z, rem_out):
         _, zz = _words(z)
         self._check(self.lib.bx_poly_divide(self.ctx, poly.raw, zz, rem_out.raw))
+
+    def prefix_products(self, io):
+        self._check(self.lib.bx_prefix_products(self.ctx, io.raw))
+
+    def scatter(self, into, index, offsets, values):
+        self._check(self.lib.bx_scatter(self.ctx, into.raw, index.raw, offsets.raw, values.raw))
 
     def poseidon2_set_params(self, rc213, diag24):
         _, r = _words(rc213)

@@ -115,6 +115,12 @@ const char* bx_eltwise_zeroize_elem(bx_ctx* ctx, bx_buf io);
 const char* bx_eltwise_sum_extelem(bx_ctx* ctx, bx_buf out, bx_buf in_ext);
 /* Hal::gather_sample(dst, src, idx, size, stride): dst[i] = src[idx + i*stride] */
 const char* bx_gather_sample(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride);
+/* Hal::prefix_products(io): io[i] = io[i] * io[i-1] over AoS ext elements (inclusive running product; the circuit's
+ * accumulate step uses it for its grand products). */
+const char* bx_prefix_products(bx_ctx* ctx, bx_buf io_ext);
+/* Hal::scatter(into, index, offsets, values): for cycle c < index.len - 1, every entry e in [index[c], index[c+1])
+ * writes into[offsets[e]] = values[e].  All four are device buffers. */
+const char* bx_scatter(bx_ctx* ctx, bx_buf into, bx_buf index_u32, bx_buf offsets_u32, bx_buf values);
 /* DEEP quotient (upstream: core/poly.rs poly_divide, run per combo): in-place synthetic division of the
  * natural-order AoS ext polynomial by (x - z); the remainder (4 words) is written to rem_out_dev. */
 const char* bx_poly_divide(bx_ctx* ctx, bx_buf poly_ext, const uint32_t z[4], bx_buf rem_out_dev);

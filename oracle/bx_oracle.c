@@ -484,3 +484,17 @@ int bxo_poly_divide(uint32_t* poly, size_t size, const uint32_t zw[4], uint32_t 
     if (rem_out) memcpy(rem_out, cur.c, 16);
     return (cur.c[0] | cur.c[1] | cur.c[2] | cur.c[3]) == 0;
 }
+
+/* [EXT] hal/cpu.rs prefix_products: io[i] = io[i] * io[i-1] (inclusive running product of ext elements, AoS) */
+void bxo_prefix_products(uint32_t* io, size_t n) {
+    bxo_init();
+    for (size_t i = 1; i < n; i++) {
+        fp4 r = f4mul(f4load(io + 4 * i), f4load(io + 4 * (i - 1)));
+        memcpy(io + 4 * i, r.c, 16);
+    }
+}
+/* [EXT] hal/cpu.rs scatter: for cycle c, entries index[c] .. index[c+1] write into[offsets[e]] = values[e] */
+void bxo_scatter(uint32_t* into, const uint32_t* index, const uint32_t* offsets, const uint32_t* values, size_t cycles) {
+    for (size_t c = 0; c < cycles; c++)
+        for (uint32_t e = index[c]; e < index[c + 1]; e++) into[offsets[e]] = values[e];
+}

@@ -90,6 +90,9 @@ void bxo_gather_sample(uint32_t* dst, const uint32_t* src, size_t idx, size_t si
  * synthetic division, coefficients in natural order. Returns the remainder-is-zero flag. */
 int bxo_poly_divide(uint32_t* poly_ext, size_t size, const uint32_t z[4], uint32_t rem_out[4]);
 
+void bxo_prefix_products(uint32_t* io_ext, size_t n);
+void bxo_scatter(uint32_t* into, const uint32_t* index, const uint32_t* offsets, const uint32_t* values, size_t cycles);
+
 /* ---- segment-prover pipeline (bx_oracle_prover.c): returns a malloc'ed seal (free with bxo_free) or NULL ---- */
 uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
                             size_t* seal_words, uint32_t roots_out[32]);

@@ -69,6 +69,8 @@ def lib(path=None):
         "bxo_eltwise_zeroize": ([u32p, sz], None),
         "bxo_gather_sample": ([u32p, u32p, sz, sz, sz], None),
         "bxo_poly_divide": ([u32p, sz, u32p, u32p], C.c_int),
+        "bxo_prefix_products": ([u32p, sz], None),
+        "bxo_scatter": ([u32p, u32p, u32p, u32p, sz], None),
         "bxo_prove_segment": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_free": ([C.c_void_p], None),
     }

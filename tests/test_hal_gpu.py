@@ -393,3 +393,64 @@ def test_eltwise_and_gather(hal, oracle):
 
     with pytest.raises(HalError):
         hal.gather_sample(g, hal.copy_from(a), 5, 17, 1000)  # out of range
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4096, 1 << 16, (1 << 18) + 3])
+def test_prefix_products_vs_oracle(hal, oracle, n):
+    x = rnd(n, 4 * n)
+    buf = hal.copy_from(x)
+    hal.prefix_products(buf)
+    ref = x.copy()
+    oracle.bxo_prefix_products(ref, n)
+    assert np.array_equal(buf.view(), ref)
+
+
+def test_scatter_vs_oracle(hal, oracle):
+    rng = np.random.default_rng(4)
+    into_len, cycles = 5000, 40
+    counts = rng.integers(0, 9, cycles)
+    index = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    total = int(index[-1])
+    offsets = rng.permutation(into_len)[:total].astype(np.uint32)  # distinct destinations, as the circuits produce
+    values = rnd(8, total)
+    init = rnd(9, into_len)
+    dst = hal.copy_from(init)
+    hal.scatter(dst, hal.copy_from(index), hal.copy_from(offsets), hal.copy_from(values))
+    ref = init.copy()
+    oracle.bxo_scatter(ref, index, offsets, c(values), cycles)
+    assert np.array_equal(dst.view(), ref)
+    from boundless_amd.hal import HalError
+
+    bad = offsets.copy()
+    bad[3] = into_len + 7
+    with pytest.raises(HalError):
+        hal.scatter(dst, hal.copy_from(index), hal.copy_from(bad), hal.copy_from(values))
+
+
+def test_torch_memory_and_stream_interop(hal, oracle):
+    """bx_buf is a plain (pointer, length) pair and a ctx can adopt an external stream: run the LDE on a torch tensor
+    on torch's current stream (PyTorch is plumbing here: device memory + streams)."""
+    import torch
+
+    n, cols = 1 << 12, 4
+    x = rnd(77, n * cols)
+    t_in = torch.from_numpy(x.view(np.int32)).to("cuda")
+    t_out = torch.empty(4 * n * cols, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        hal.set_stream(stream.cuda_stream)
+        try:
+            a = hal.wrap(t_in.data_ptr(), t_in.numel())
+            b = hal.wrap(t_out.data_ptr(), t_out.numel())
+            hal.batch_interpolate_ntt(a, cols)
+            hal.zk_shift(a, cols)
+            hal.batch_expand_into_evaluate_ntt(b, a, cols, 2)
+        finally:
+            stream.synchronize()
+            hal.set_stream(None)
+    ref = x.copy()
+    oracle.bxo_batch_interpolate_ntt(ref, cols, n)
+    oracle.bxo_zk_shift(ref, cols, n)
+    ref_out = np.zeros(4 * n * cols, np.uint32)
+    oracle.bxo_batch_expand_into_evaluate_ntt(ref_out, ref, cols, n, 2)
+    assert np.array_equal(t_out.cpu().numpy().view(np.uint32), ref_out)

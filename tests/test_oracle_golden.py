@@ -216,3 +216,19 @@ def test_eltwise_gather_zeroize(oracle):
     dst = np.zeros(5, np.uint32)
     oracle.bxo_gather_sample(dst, src, 3, 5, 8)
     assert dst.tolist() == [3, 11, 19, 27, 35]
+
+
+def test_prefix_products_and_scatter(oracle):
+    rng = np.random.default_rng(21)
+    n = 37
+    x = rng.integers(0, P, (n, 4), dtype=np.uint64).tolist()
+    buf = enc(np.array(x, dtype=np.uint64).reshape(-1))
+    oracle.bxo_prefix_products(buf, n)
+    want = [x[0]]
+    for i in range(1, n):
+        want.append(npo.f4_mul(x[i], want[-1]))
+    assert dec(buf.reshape(n, 4)) == want
+    into = np.zeros(10, np.uint32)
+    oracle.bxo_scatter(into, np.array([0, 2, 2, 5], np.uint32), np.array([7, 1, 3, 9, 0], np.uint32),
+                       np.array([11, 22, 33, 44, 55], np.uint32), 3)
+    assert into.tolist() == [55, 22, 0, 33, 0, 0, 0, 11, 0, 44]
