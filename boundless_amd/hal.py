@@ -41,6 +41,17 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 with the same SONAMEs as /opt/rocm's.  Whichever
+    # copy is loaded first serves the whole process; if ours (linked against /opt/rocm) comes first, torch's later HIP
+    # initialisation finds no devices.  Loading torch first makes the order deterministic (measured on the GPU box).
+    if os.environ.get("BX_NO_TORCH") != "1":
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise HalError(f"{LIB_PATH} is missing: run `python -m boundless_amd.build` (hipcc, gfx950). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
