@@ -14,6 +14,7 @@
 namespace bx {
 
 constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
+constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device parameter table
 
 // ---------------------------------------------------------------------------------------------------------------
 // Instruction budget.  Every 32-bit integer VALU op issues at the same rate on gfx950 (profiles/r01_microbench_valu.jsonl),
@@ -116,7 +117,7 @@ __device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
 
 // Device parameter table (round constants Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride
 // in a REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
-// [213,237) internal diagonal (plain Montgomery form, used as a multiplier).
+// [216,240) internal diagonal (plain Montgomery form, used as a multiplier; 16-byte aligned).
 // Input: cells < P (canonical).  Output: canonical.
 __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
     uint64_t y[CELLS];
@@ -144,7 +145,21 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
     // sum_r = sum * 2^32 mod P (canonical) by one reduction (acc < 2^32 * R2 + 22 * R3), and rides in each cell's REDC
     // accumulator together with the next constant (sum_r + rc < 2P fits 32 bits).
-    const uint32_t* diag = prm + 213;
+    // The 24 diagonal words are wave-uniform, but left in SGPRs the compiler reloads them with three s_load + s_waitcnt
+    // stalls in every internal round (a scalar-cache round trip is about as long as half a round's arithmetic).  Keep them
+    // in VGPRs for the whole permutation instead: six 16-byte vector loads through an offset the compiler cannot prove
+    // uniform (an opaque zero), issued once, one wait.
+    uint32_t diag[CELLS];
+    {
+        uint32_t zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        const uint4* dp = reinterpret_cast<const uint4*>(prm + DIAG_OFF + zero);
+#pragma unroll
+        for (int i = 0; i < CELLS / 4; ++i) {
+            const uint4 v = dp[i];
+            diag[4 * i] = v.x; diag[4 * i + 1] = v.y; diag[4 * i + 2] = v.z; diag[4 * i + 3] = v.w;
+        }
+    }
 #pragma unroll 1
     for (int r = 0; r < RP; ++r) {
         s[0] = sbox7_bounded(s[0]);
@@ -275,10 +290,10 @@ __global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restri
 }
 
 const char* poseidon2_upload_params(bx_ctx* c) {
-    uint32_t h[237];
+    uint32_t h[DIAG_OFF + 24] = {0};
     // round constants ride in REDC accumulators: store rc * 2^64 mod P (Montgomery form encoded once more)
     for (int i = 0; i < 213; ++i) h[i] = fp_encode(fp_encode(c->h_rc[i]));
-    for (int i = 0; i < 24; ++i) h[213 + i] = fp_encode(c->h_diag[i]);
+    for (int i = 0; i < 24; ++i) h[DIAG_OFF + i] = fp_encode(c->h_diag[i]);
     if (!c->d_p2) BX_HIP(c, hipMalloc(&c->d_p2, sizeof h));
     BX_HIP(c, hipMemcpyAsync(c->d_p2, h, sizeof h, hipMemcpyHostToDevice, c->stream));
     BX_HIP(c, hipStreamSynchronize(c->stream));
