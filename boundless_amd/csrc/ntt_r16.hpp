@@ -86,6 +86,54 @@ __device__ __forceinline__ void step_compute(uint32_t (&x)[16], const uint32_t* 
     }
 }
 
+// Twiddle prefetch: the (2^K - 1) stage twiddles of each unit, fetched into registers ahead of the LDS regrouping that
+// precedes the step, so the L2 round trip overlaps the barrier / LDS traffic instead of stalling the butterflies.
+// Slot (w, half - 1 + jj) of tw[] holds the twiddle of stage k (half = 2^(k-1)), butterfly jj.
+template <int K, bool S0ZERO, int SKIP>
+__device__ __forceinline__ void tw_load(uint32_t (&tw)[16], const uint32_t* __restrict__ ltw, int s0, int lt, uint32_t tid, uint32_t nt) {
+    constexpr int U = 16 >> K, E = 1 << K;
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        const uint32_t rl = (tid + nt * w) >> lt;
+        const uint32_t lo = S0ZERO ? 0u : (rl & ((1u << s0) - 1u));
+#pragma unroll
+        for (int k = 1; k <= K; ++k) {
+            if (k <= SKIP) continue;
+            const int half = 1 << (k - 1);
+#pragma unroll
+            for (int jj = 0; jj < half; ++jj) {
+                if (S0ZERO && jj == 0) continue;
+                tw[w * E + half - 1 + jj] = ltw[(1u << (s0 + k - 1)) + lo + ((uint32_t)jj << s0)];
+            }
+        }
+    }
+}
+template <int K, bool INV, bool S0ZERO, int SKIP>
+__device__ __forceinline__ void step_compute_tw(uint32_t (&x)[16], const uint32_t (&tw)[16]) {
+    constexpr int U = 16 >> K, E = 1 << K;
+#pragma unroll
+    for (int w = 0; w < U; ++w) {
+        uint32_t* xu = &x[w * E];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int k = INV ? K - kk : kk + 1;
+            if (k <= SKIP) continue;
+            const int half = 1 << (k - 1);
+#pragma unroll
+            for (int jj = 0; jj < half; ++jj) {
+                if (S0ZERO && jj == 0) {
+#pragma unroll
+                    for (int j = 0; j < E; j += 2 * half) bfly_one(xu[j], xu[j + half]);
+                } else {
+                    const uint32_t wv = tw[w * E + half - 1 + jj];
+#pragma unroll
+                    for (int j = jj; j < E; j += 2 * half) bfly_tw<INV>(xu[j], xu[j + half], wv);
+                }
+            }
+        }
+    }
+}
+
 // row/col of register (w, mid) for step (s0, K)
 template <int K>
 __device__ __forceinline__ void unit_coords(int w, int s0, int lt, uint32_t tid, uint32_t nt, uint32_t& base_row, uint32_t& t) {
@@ -224,11 +272,29 @@ __device__ __forceinline__ void glb_put(const uint32_t (&x)[16], const R16Args& 
 }
 
 // Forward (DIT) order: step 0 (s0 = 0, from global, trivial twiddles, optional skipped stages), then the higher steps.
+// `twn` receives the next step's twiddles (prefetched before the regrouping).
+template <int KN>
+__device__ __forceinline__ void prefetch_next(uint32_t (&twn)[16], const uint32_t* ltw, int s0n, int lt, uint32_t tid, uint32_t nt) {
+    tw_load<KN, false, 0>(twn, ltw, s0n, lt, tid, nt);
+}
+__device__ __forceinline__ void prefetch_dispatch(uint32_t (&twn)[16], const uint32_t* ltw, int lr, int s0n, int lt, uint32_t tid,
+                                                  uint32_t nt) {
+    const int kn = lr - s0n < 4 ? lr - s0n : 4;
+    switch (kn) {
+        case 4: prefetch_next<4>(twn, ltw, s0n, lt, tid, nt); break;
+        case 3: prefetch_next<3>(twn, ltw, s0n, lt, tid, nt); break;
+        case 2: prefetch_next<2>(twn, ltw, s0n, lt, tid, nt); break;
+        default: prefetch_next<1>(twn, ltw, s0n, lt, tid, nt); break;
+    }
+}
 template <int K, bool PASS_A, int SKIP>
-__device__ __forceinline__ void fwd_first(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, const uint32_t* src,
-                                          uint32_t* dst, size_t tile_off, bool only, uint32_t tid, uint32_t nt) {
+__device__ __forceinline__ void fwd_first(uint32_t (&x)[16], uint32_t (&twn)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw,
+                                          const uint32_t* src, uint32_t* dst, size_t tile_off, bool only, uint32_t tid, uint32_t nt) {
+    uint32_t tw0[16];
+    tw_load<K, true, SKIP>(tw0, ltw, 0, a.lt, tid, nt);
     glb_get<K, false, PASS_A>(x, a, src, tile_off, 0, tid, nt);
-    step_compute<K, false, true, SKIP>(x, ltw, 0, a.lt, tid, nt);
+    if (!only) prefetch_dispatch(twn, ltw, a.lr, 4, a.lt, tid, nt);
+    step_compute_tw<K, false, true, SKIP>(x, tw0);
     if (only) {
         glb_put<K, false, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
     } else {
@@ -237,24 +303,35 @@ __device__ __forceinline__ void fwd_first(uint32_t (&x)[16], const R16Args& a, u
     }
 }
 template <int K, bool PASS_A>
-__device__ __forceinline__ void fwd_next(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, uint32_t* dst,
-                                         size_t tile_off, int s0, bool last, uint32_t tid, uint32_t nt) {
+__device__ __forceinline__ void fwd_next(uint32_t (&x)[16], uint32_t (&twc)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw,
+                                         uint32_t* dst, size_t tile_off, int s0, bool last, uint32_t tid, uint32_t nt) {
     lds_get<K>(x, s, s0, a.lt, tid, nt);
-    step_compute<K, false, false, 0>(x, ltw, s0, a.lt, tid, nt);
+    uint32_t twn[16];
+    if (!last) prefetch_dispatch(twn, ltw, a.lr, s0 + 4, a.lt, tid, nt);
+    step_compute_tw<K, false, false, 0>(x, twc);
     if (last) {
         glb_put<K, false, PASS_A>(x, a, dst, tile_off, s0, tid, nt);
     } else {
         __syncthreads();  // every thread has finished reading the previous regrouping
         lds_put<K>(x, s, s0, a.lt, tid, nt);
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) twc[i] = twn[i];
     }
 }
 // Inverse (DIF) order: the top step comes from global (twist / scale applied on load), step 0 goes back to global.
 template <int K, bool PASS_A>
-__device__ __forceinline__ void inv_top(uint32_t (&x)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw, const uint32_t* src,
-                                        size_t tile_off, int s0, uint32_t tid, uint32_t nt) {
+__device__ __forceinline__ void inv_top(uint32_t (&x)[16], uint32_t (&twn)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw,
+                                        const uint32_t* src, size_t tile_off, int s0, uint32_t tid, uint32_t nt) {
+    uint32_t tw0[16];
+    tw_load<K, false, 0>(tw0, ltw, s0, a.lt, tid, nt);
     glb_get<K, true, PASS_A>(x, a, src, tile_off, s0, tid, nt);
-    step_compute<K, true, false, 0>(x, ltw, s0, a.lt, tid, nt);
+    if (s0 >= 8) {
+        tw_load<4, false, 0>(twn, ltw, s0 - 4, a.lt, tid, nt);
+    } else {
+        tw_load<4, true, 0>(twn, ltw, 0, a.lt, tid, nt);
+    }
+    step_compute_tw<K, true, false, 0>(x, tw0);
     lds_put<K>(x, s, s0, a.lt, tid, nt);
     __syncthreads();
 }
@@ -282,15 +359,15 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
     const uint32_t* src = a.in + (size_t)col * a.in_col_stride;
     uint32_t* dst = a.out + (size_t)col * a.out_col_stride;
 
-    uint32_t x[16];
+    uint32_t x[16], twc[16];
     const int ns = (a.lr + 3) >> 2;
     if (!INV) {
         const int K0 = a.lr < 4 ? a.lr : 4;
         switch (K0) {
-            case 4: fwd_first<4, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, ns == 1, tid, nt); break;
-            case 3: fwd_first<3, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
-            case 2: fwd_first<2, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
-            default: fwd_first<1, PASS_A, SKIP>(x, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+            case 4: fwd_first<4, PASS_A, SKIP>(x, twc, a, s, ltw, src, dst, tile_off, ns == 1, tid, nt); break;
+            case 3: fwd_first<3, PASS_A, SKIP>(x, twc, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+            case 2: fwd_first<2, PASS_A, SKIP>(x, twc, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
+            default: fwd_first<1, PASS_A, SKIP>(x, twc, a, s, ltw, src, dst, tile_off, true, tid, nt); break;
         }
 #pragma unroll
         for (int si = 1; si < ns; ++si) {
@@ -298,10 +375,10 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
             const int K = a.lr - s0 < 4 ? a.lr - s0 : 4;
             const bool last = si == ns - 1;
             switch (K) {
-                case 4: fwd_next<4, PASS_A>(x, a, s, ltw, dst, tile_off, s0, last, tid, nt); break;
-                case 3: fwd_next<3, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
-                case 2: fwd_next<2, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
-                default: fwd_next<1, PASS_A>(x, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+                case 4: fwd_next<4, PASS_A>(x, twc, a, s, ltw, dst, tile_off, s0, last, tid, nt); break;
+                case 3: fwd_next<3, PASS_A>(x, twc, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+                case 2: fwd_next<2, PASS_A>(x, twc, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
+                default: fwd_next<1, PASS_A>(x, twc, a, s, ltw, dst, tile_off, s0, true, tid, nt); break;
             }
         }
     } else {
@@ -316,21 +393,29 @@ __global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
         }
         const int s_top = 4 * (ns - 1);
         switch (a.lr - s_top) {
-            case 4: inv_top<4, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
-            case 3: inv_top<3, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
-            case 2: inv_top<2, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
-            default: inv_top<1, PASS_A>(x, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            case 4: inv_top<4, PASS_A>(x, twc, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            case 3: inv_top<3, PASS_A>(x, twc, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            case 2: inv_top<2, PASS_A>(x, twc, a, s, ltw, src, tile_off, s_top, tid, nt); break;
+            default: inv_top<1, PASS_A>(x, twc, a, s, ltw, src, tile_off, s_top, tid, nt); break;
         }
 #pragma unroll
         for (int si = ns - 2; si >= 1; --si) {
             lds_get<4>(x, s, 4 * si, a.lt, tid, nt);
-            step_compute<4, true, false, 0>(x, ltw, 4 * si, a.lt, tid, nt);
+            uint32_t twn[16];
+            if (si >= 2) {
+                tw_load<4, false, 0>(twn, ltw, 4 * (si - 1), a.lt, tid, nt);
+            } else {
+                tw_load<4, true, 0>(twn, ltw, 0, a.lt, tid, nt);
+            }
+            step_compute_tw<4, true, false, 0>(x, twc);
             __syncthreads();
             lds_put<4>(x, s, 4 * si, a.lt, tid, nt);
             __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) twc[i] = twn[i];
         }
         lds_get<4>(x, s, 0, a.lt, tid, nt);
-        step_compute<4, true, true, 0>(x, ltw, 0, a.lt, tid, nt);
+        step_compute_tw<4, true, true, 0>(x, twc);
         glb_put<4, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
     }
 }
