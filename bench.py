@@ -13,8 +13,8 @@ data-path collective ("scaling": "weak"); torch.distributed (RCCL) only provides
 Inputs are generated on the device (no host buffers cross PCIe in the timed region except the seal and the
 Fiat-Shamir digests, exactly as in the reference's prover).
 
-By default two segments are in flight per GPU (two provers, two streams, two host threads): the second segment fills the
-latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +15 % throughput; a step is then one
+By default three segments are in flight per GPU (one prover, stream and host thread each): the others fill the
+latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +20 % throughput; a step is then one
 batch of `--inflight` segments per GPU and `value` counts segments.
 
 The JSON line also carries
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--widths", type=str, default="16,256,64")
-    ap.add_argument("--inflight", type=int, default=2, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
+    ap.add_argument("--inflight", type=int, default=3, help="segments proved concurrently per GPU (one prover + stream each); a step = one batch of this many segments per GPU")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE configs[2]: prove this many segments in total, claimed from a shared queue (--steal) instead of --steps per rank")
     ap.add_argument("--steal", action="store_true", help="claim-when-idle ticket queue instead of the static rank split")
     ap.add_argument("--dist-backend", type=str, default=None, help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 path be exercised on a single-GPU box")
