@@ -195,6 +195,33 @@ def main():
         except Exception:
             traffic = None
         dom_name = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        # The dominant entry point (hash_rows: Poseidon2 leaf hashing) is VALU-issue-bound: report its instruction rate
+        # from the committed PMC count of VALU instructions per permutation against the chip's issue peaks
+        # (1024 SIMDs x 2.4 GHz / 2 cycles for the cheap class, / 4 cycles for multiplies, profiles/r01_microbench2_instr_cost.jsonl).
+        dominant = {"kernel": dom_name, **(kernels.get(dom_name, {}) if dom_name else {}),
+                    "note": "Poseidon2 is VALU-issue-bound (no HBM or MFMA roofline applies); see DESIGN.md section 4"}
+        try:
+            src_k = iso_k if iso_k else kernels
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
+            per_perm = [v["valu_insts_per_wave"] for k, v in pmc.items() if "hash_fold_kernel" in k][0]
+            rows4 = 4 << args.po2
+            perms = rows4 * sum((w + 15) // 16 for w in list(widths) + [16])
+            hr = src_k.get("hash_rows", {})
+            if hr.get("ms_per_step"):
+                trees_ms = hr["ms_per_step"] * (1.0 if iso_k else 1.0)
+                # hash_rows calls per segment also include the FRI rounds (64 columns, rows/16): add them
+                s_ = 1 << args.po2
+                while s_ > 256:
+                    perms += (4 * s_ // 16) * 4
+                    s_ //= 16
+                perm_rate = perms / (trees_ms * 1e-3)
+                wave_insts = perm_rate / 64.0 * per_perm
+                dominant.update({"valu_insts_per_permutation": round(per_perm), "permutations_per_s": perm_rate,
+                                 "wave_insts_per_s": wave_insts, "issue_peak_cheap": 1024 * 2.4e9 / 2, "issue_peak_mul": 1024 * 2.4e9 / 4,
+                                 "frac_of_mul_class_peak": round(wave_insts / (1024 * 2.4e9 / 4), 3),
+                                 "measured": "isolated probe" if iso_k else "timed region"})
+        except Exception:
+            pass
         out = {
             "metric": "segment-proofs/sec @ 2^20 cycles",
             "value": proved_total / elapsed,

@@ -105,7 +105,6 @@ def load_library():
     return L
 
 
-HAL_SYMBOLS = None  # filled by tests from include/bx_hal.h
 
 
 def _words(a):
