@@ -243,7 +243,7 @@ def main():
                        "khz_equiv": proved_total * (1 << args.po2) / elapsed / 1e3},
             "seal_words": int(receipt.seal.size),
             "roofline": {
-                "kernel": "batch_expand_into_evaluate_ntt (ntt_block_kernel + ntt_strided_kernel, 4x LDE)",
+                "kernel": "batch_expand_into_evaluate_ntt (ntt_r16_kernel pass A + pass B, 4x LDE)",
                 "bound": "hbm",
                 "achieved": ntt.get("alg_GBps"),
                 "peak": HBM_PEAK_GBPS,
@@ -259,8 +259,7 @@ def main():
                                    "frac": iso_k["batch_expand_into_evaluate_ntt"]["frac_hbm"],
                                    "note": "same entry point with one segment in flight (no stream sharing)",
                                    "kernels": iso_k} if iso_k else None),
-            "roofline_dominant": {"kernel": dom_name, **(kernels.get(dom_name, {}) if dom_name else {}),
-                                  "note": "Poseidon2 is VALU-issue-bound (no HBM or MFMA roofline applies); see DESIGN.md §4"},
+            "roofline_dominant": dominant,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
