@@ -58,3 +58,13 @@ def test_product_never_imports_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
             text = open(path).read()
             assert "bx_oracle" not in text and "from oracle" not in text and "import oracle" not in text, path
+
+
+def test_headers_are_valid_c99():
+    """The boundary is a C ABI: a plain-C translation unit including both headers must compile with gcc."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "c_abi_smoke.c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", f"-I{os.path.join(ROOT, 'include')}", src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -96,3 +96,21 @@ def test_agent_feed_loop_with_the_hip_prover():
         assert a.metrics.ops[("prove", "complete", "success")] == 3
     finally:
         srv.close()
+
+
+def test_plain_c_consumer_of_the_abi(tmp_path):
+    """Build tests/c_abi_smoke.c with gcc, link it against the in-tree library and run it on the GPU."""
+    import os
+    import subprocess
+
+    from boundless_amd.hal import LIB_PATH
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.dirname(LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-O1", f"-I{os.path.join(root, 'include')}", os.path.join(root, "tests", "c_abi_smoke.c"),
+                        f"-L{libdir}", "-lbx_hip_hal", f"-Wl,-rpath,{libdir}", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_abi_smoke ok" in r.stdout
