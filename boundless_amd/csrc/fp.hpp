@@ -6,6 +6,10 @@
 // canonical representative in [0, P).
 #pragma once
 #include <stdint.h>
+#if defined(BX_CHECK_BOUNDS)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -45,6 +49,12 @@ constexpr uint32_t NEG_P_INV = 0x77FFFFFFu;  // -P^-1 mod 2^32
 BX_HD uint32_t fp_mad_lazy(uint32_t a, uint32_t b, uint32_t c) {
     uint64_t ab = (uint64_t)a * (uint64_t)b + c;
     uint32_t m = (uint32_t)ab * NEG_P_INV;
+#if defined(BX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+    if ((((unsigned __int128)a * b + c + (unsigned __int128)m * P) >> 64) != 0) {
+        fprintf(stderr, "fp_mad_lazy: 64-bit overflow (a=%u b=%u c=%u)\n", a, b, c);
+        abort();
+    }
+#endif
     return (uint32_t)((ab + (uint64_t)m * (uint64_t)P) >> 32);
 }
 BX_HD uint32_t fp_mul_lazy(uint32_t a, uint32_t b) { return fp_mad_lazy(a, b, 0u); }

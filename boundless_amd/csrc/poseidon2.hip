@@ -10,6 +10,7 @@
 // round constants fetched through wave-uniform (scalar) loads, loads of the column-major matrix coalesced
 // across the 64 lanes of a wave (lane r reads matrix[c*rows + r]).
 #include "ctx.hpp"
+#include "poseidon2_arith.hpp"
 
 namespace bx {
 
@@ -39,8 +40,6 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 //                                  product B P^2 + 2P < 2.42 P^2;  sum < (1.06 + 23 * 1.8824) P < 2^37, sum_hi < 22;
 //                                  sum_r and the S-box cell are reduced to canonical every round.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
-
 // Pinned v_mad_u64_u32 forms.  Left to itself hipcc rewrites "x*1 + acc" / "x*2 + acc" into v_lshl_add_u64 plus a v_mov
 // that zero-extends the 32-bit operand into a register pair — two instructions on the same issue port instead of one.
 // K is an inline constant (1, 2, 4); the 64-bit addend is a VGPR pair, the literal 0, or an SGPR pair (a wave-uniform
@@ -61,58 +60,6 @@ __device__ __forceinline__ uint64_t mad_vvs(uint32_t a, uint32_t b, uint64_t c_u
     uint64_t r;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform) : "vcc");
     return r;
-}
-
-// x^7 for x < 1.13334 P; returns a value < 1.05423 P congruent to x^7 * 2^(-6*32) (Montgomery).  16 instructions.
-__device__ __forceinline__ uint32_t sbox7_bounded(uint32_t x) {
-    uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
-    uint32_t x3 = fp_mul_lazy(x2, x);
-    uint32_t x4 = fp_mul_lazy(x2, x2);
-    return fp_reduce(fp_mul_lazy(x3, x4));
-}
-
-// y (< 2^38, unreduced linear-layer output) plus a round constant -> 32 bits:  r == y + a (mod P), r < 1.13334 P, where
-// `add_rr` = a * 2^64 mod P (a in the cells' Montgomery representation).
-//   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18,
-// so acc + m*P < 2^64 and r < 268435473 + P.  4 instructions (+2 for the canonical form).
-__device__ __forceinline__ uint32_t red64_lazy(uint64_t y, uint32_t add_rr) {
-    uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
-    acc = mad64((uint32_t)(y >> 32), R2, acc);
-    uint32_t m = (uint32_t)acc * NEG_P_INV;
-    return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
-}
-__device__ __forceinline__ uint32_t red64(uint64_t y, uint32_t add_rr) { return fp_reduce(red64_lazy(y, add_rr)); }
-// the same without a constant (addend literal 0)
-__device__ __forceinline__ uint32_t red64_lazy0(uint64_t y) {
-    uint64_t acc = mad64((uint32_t)(y >> 32), R2, mad64((uint32_t)y, MONT_ONE, 0ull));
-    uint32_t m = (uint32_t)acc * NEG_P_INV;
-    return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
-}
-
-// external layer circ(2*M4, M4, ..., M4) on bounded cells (< 1.05423 P), unreduced 64-bit outputs:
-//   w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B) in mixed width:
-//   t0 = a+b, t1 = c+d (32-bit), t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
-__device__ __forceinline__ void m_ext64(const uint32_t* s, uint64_t* y) {
-#pragma unroll
-    for (int k = 0; k < CELLS; k += 4) {
-        const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
-        const uint32_t t0 = a + b, t1 = c + d;  // < 2.10846 P < 2^32
-        const uint64_t t2 = mad64(2u, b, (uint64_t)t1), t3 = mad64(2u, d, (uint64_t)t0);
-        const uint64_t t4 = mad64(4u, t1, t3), t5 = mad64(4u, t0, t2);
-        y[k] = t3 + t5;
-        y[k + 1] = t5;
-        y[k + 2] = t2 + t4;
-        y[k + 3] = t4;
-    }
-    uint64_t t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        t[j] = y[j];
-#pragma unroll
-        for (int k = 4; k < CELLS; k += 4) t[j] += y[k + j];
-    }
-#pragma unroll
-    for (int i = 0; i < CELLS; ++i) y[i] += t[i & 3];
 }
 
 // Device parameter table (round constants Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride
@@ -166,10 +113,7 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
         uint64_t sum = madk0<1>(s[0]);
 #pragma unroll
         for (int i = 1; i < CELLS; ++i) sum = madk<1>(s[i], sum);
-        uint64_t acc = mad64((uint32_t)sum, R2, 0ull);
-        acc = mad64((uint32_t)(sum >> 32), R3, acc);
-        const uint32_t m = (uint32_t)acc * NEG_P_INV;
-        const uint32_t sum_r = fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
+        const uint32_t sum_r = internal_sum_r(sum);
         if (r < RP - 1) {
             s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));  // next internal constant rides along
 #pragma unroll
