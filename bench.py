@@ -20,7 +20,8 @@ batch of `--inflight` segments per GPU and `value` counts segments.
 The JSON line also carries
   roofline      the NTT/LDE entry point named by BASELINE's metric: algorithmic bytes / HIP-event time on the HAL
                 stream over the timed region, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is
-                VALU-issue-bound); `roofline_isolated` is the same measured with a single segment in flight;
+                VALU-issue-bound); measured by an isolated probe (one segment alone) because concurrent streams stretch the
+                in-region durations; `roofline_in_region` is the concurrent figure;
   kernels       the same for every HAL entry point in the timed region;
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
                 box's host cores on a bounded sample.
@@ -194,6 +195,23 @@ def main():
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / launches
         except Exception:
             traffic = None
+        def ntt_roofline(k, measured):
+            e = k.get("batch_expand_into_evaluate_ntt", {})
+            return {"kernel": "batch_expand_into_evaluate_ntt (ntt_r16_kernel pass A + pass B, 4x LDE)", "bound": "hbm",
+                    "achieved": e.get("alg_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": e.get("frac_hbm"),
+                    "traffic": traffic, "avg_ms_per_launch": e.get("avg_ms"),
+                    "achieved_bytes_per_launch": (e.get("alg_GBps", 0) or 0) * 1e9 * (e.get("avg_ms", 0) or 0) * 1e-3,
+                    "measured": measured,
+                    "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream; traffic = "
+                            "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r01_bench_pmc_traffic.json; "
+                            "the path is VALU-issue-bound (DESIGN.md section 4), see roofline_dominant"}
+
+        # With several segments in flight the per-launch durations of the timed region include time-slicing between the
+        # streams, so the kernel's own roofline comes from the isolated probe (same process, right after the timed region,
+        # HIP events on the HAL stream; agrees with the rocprofv3 summary of `--inflight 1`); the in-region figure (agrees
+        # with the rocprofv3 summary of the default command) is reported beside it.
+        roofline_in_region = ntt_roofline(kernels, "timed region, %d segments in flight" % len(servers))
+        roofline = ntt_roofline(iso_k, "isolated probe: one extra segment proved alone after the timed region") if iso_k else roofline_in_region
         dom_name = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         # The dominant entry point (hash_rows: Poseidon2 leaf hashing) is VALU-issue-bound: report its instruction rate
         # from the committed PMC count of VALU instructions per permutation against the chip's issue peaks
@@ -242,23 +260,8 @@ def main():
                        "parallelism": f"segments sharded over {world} GPU(s), no collective",
                        "khz_equiv": proved_total * (1 << args.po2) / elapsed / 1e3},
             "seal_words": int(receipt.seal.size),
-            "roofline": {
-                "kernel": "batch_expand_into_evaluate_ntt (ntt_r16_kernel pass A + pass B, 4x LDE)",
-                "bound": "hbm",
-                "achieved": ntt.get("alg_GBps"),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": ntt.get("frac_hbm"),
-                "traffic": traffic,
-                "achieved_bytes_per_launch": (ntt.get("alg_GBps", 0) or 0) * 1e9 * (ntt.get("avg_ms", 0) or 0) * 1e-3,
-                "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream; traffic = "
-                        "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r01_bench_pmc_traffic.json",
-            },
-            "roofline_isolated": ({"kernel": "batch_expand_into_evaluate_ntt", "bound": "hbm",
-                                   "achieved": iso_k["batch_expand_into_evaluate_ntt"]["alg_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                   "frac": iso_k["batch_expand_into_evaluate_ntt"]["frac_hbm"],
-                                   "note": "same entry point with one segment in flight (no stream sharing)",
-                                   "kernels": iso_k} if iso_k else None),
+            "roofline": roofline,
+            "roofline_in_region": roofline_in_region,
             "roofline_dominant": dominant,
             "kernels": kernels,
         }
