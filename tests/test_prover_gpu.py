@@ -114,3 +114,32 @@ def test_plain_c_consumer_of_the_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_abi_smoke ok" in r.stdout
+
+
+def test_three_provers_in_flight_on_one_gpu_stay_bit_exact():
+    """bench.py keeps 3 segments in flight per GPU (one prover + stream + host thread each): concurrent provers must not
+    disturb each other (tables, scratch and streams are per ctx)."""
+    import threading
+
+    from boundless_amd.prover import HipProverServer, Segment
+
+    po2, widths = 12, (4, 12, 4)
+    servers = [HipProverServer(0, po2=po2, widths=widths) for _ in range(3)]
+    results = {}
+
+    def work(k):
+        for j in range(3):
+            seg = Segment.synthetic(index=3 * k + j, po2=po2)
+            results[seg.index] = servers[k].prove_segment(seg).seal
+
+    try:
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert sorted(results) == list(range(9))
+        for idx, seal in results.items():
+            want, _ = ol.prove_segment(po2, *widths, Segment.synthetic(idx, po2=po2).seed)
+            assert np.array_equal(seal, want), f"segment {idx}"
+    finally:
+        for s in servers:
+            s.close()
