@@ -241,8 +241,10 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         BX_REQUIRE(c, value >= 10 && value <= 13, "ntt_tile_a_log out of range [10,13]");
         c->ntt_tile_a_log = value;
     } else if (!strcmp(name, "ntt_tile_b_log")) {
-        BX_REQUIRE(c, value >= 10 && value <= 13, "ntt_tile_b_log out of range [10,13]");
+        BX_REQUIRE(c, value >= 10 && value <= 14, "ntt_tile_b_log out of range [10,14]");
         c->ntt_tile_b_log = value;
+    } else if (!strcmp(name, "ntt_tile_b_wide")) {
+        c->ntt_tile_b_wide = value != 0;
     } else if (!strcmp(name, "fold_fuse_below")) {
         BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
         c->fold_fuse_below = value;

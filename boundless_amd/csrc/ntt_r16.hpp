@@ -338,8 +338,8 @@ __device__ __forceinline__ void inv_top(uint32_t (&x)[16], uint32_t (&twn)[16], 
 
 // One workgroup per (tile, column).  blockDim.x = tile elements / 16.  LR/LT > 0 / >= 0 bake the hot geometries in at
 // compile time (stage loops unroll, shifts and LDS strides become immediates); LR = 0 is the generic runtime version.
-template <bool INV, bool PASS_A, int SKIP, int LR, int LT>
-__global__ __launch_bounds__(512) void ntt_r16_kernel(R16Args a) {
+template <bool INV, bool PASS_A, int SKIP, int LR, int LT, int MAXT = 512>
+__global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
     extern __shared__ uint32_t lds[];
     if (LR > 0) {
         a.lr = LR;

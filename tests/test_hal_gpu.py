@@ -88,7 +88,7 @@ def test_ntt_golden_vectors(hal, golden_dir):
 
 @pytest.mark.parametrize("fast,block_log,tile_log,tile_a,tile_b", [
     (0, 12, 14, 12, 13), (0, 13, 14, 12, 13), (0, 11, 13, 12, 13), (0, 10, 12, 12, 13),
-    (1, 12, 14, 12, 13), (1, 13, 14, 13, 13), (1, 11, 14, 12, 12), (1, 10, 14, 11, 13), (1, 12, 14, 13, 11)])
+    (1, 12, 14, 12, 13), (1, 12, 14, 12, 14), (1, 13, 14, 13, 13), (1, 11, 14, 12, 12), (1, 10, 14, 11, 13), (1, 12, 14, 13, 11)])
 def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, fast, block_log, tile_log, tile_a, tile_b):
     """BASELINE size: N = 2^20 rows -> 2^22 LDE, for both kernel families and every pass-split / tile tunable."""
     hal.set_tunable("ntt_fast", fast)

@@ -66,7 +66,7 @@ def main():
     hal = HipHal(0)
     print(json.dumps({"device": hal.device_name()}))
     if a.sweep:
-        for fast, blk, ta, tb in ((0, 12, 12, 13), (1, 12, 12, 13), (1, 12, 12, 12), (1, 12, 13, 13), (1, 13, 13, 13), (1, 13, 13, 12),
+        for fast, blk, ta, tb in ((0, 12, 12, 13), (1, 12, 12, 13), (1, 12, 12, 14), (1, 12, 12, 12), (1, 12, 13, 13), (1, 13, 13, 13), (1, 13, 13, 12),
                                   (1, 11, 12, 13), (1, 11, 11, 13), (1, 10, 12, 13), (1, 12, 12, 11)):
             hal.set_tunable("ntt_fast", fast)
             hal.set_tunable("ntt_block_log", blk)
