@@ -243,6 +243,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
     } else if (!strcmp(name, "ntt_tile_b_log")) {
         BX_REQUIRE(c, value >= 10 && value <= 14, "ntt_tile_b_log out of range [10,14]");
         c->ntt_tile_b_log = value;
+    } else if (!strcmp(name, "ntt_cols_per_wg")) {
+        BX_REQUIRE(c, value >= 1 && value <= 16, "ntt_cols_per_wg out of range [1,16]");
+        c->ntt_cols_per_wg = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
     } else if (!strcmp(name, "fold_fuse_below")) {

@@ -296,9 +296,24 @@ static const char* launch_r16_geom(bx_ctx* c, R16Args a, size_t count) {
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
+template <int SKIP>
+static const char* launch_passA_multi(bx_ctx* c, R16Args a, size_t count, uint32_t cpw) {
+    a.cols = (uint32_t)count;
+    a.cpw = cpw;
+    size_t lds = ((size_t)4096 + 256) * 4;
+    unsigned groups = (unsigned)((count + cpw - 1) / cpw);
+    hipLaunchKernelGGL((ntt_passA_fwd12_multi_kernel<SKIP>), dim3(a.tiles * groups), dim3(256), lds, c->stream, a);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
 // hot geometries (BASELINE sizes 2^20 / 2^22, default tunables) get a compile-time specialisation
 template <bool INV, bool PASS_A, int SKIP>
 static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
+    if (PASS_A && !INV && a.lr == 12 && a.lrows == 12 && a.lt == 0 && c->ntt_cols_per_wg > 1 && count > 1 &&
+        (a.expand == 0 || a.expand == 2)) {
+        if (SKIP == 2) return launch_passA_multi<2>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
+        if (SKIP == 0) return launch_passA_multi<0>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
+    }
     if (PASS_A && a.lr == 12 && a.lt == 0) return launch_r16_geom<INV, PASS_A, SKIP, 12, 0>(c, a, count);
     if (!PASS_A && a.lr == 10 && a.lt == 3) return launch_r16_geom<INV, PASS_A, SKIP, 10, 3>(c, a, count);
     if (!PASS_A && a.lr == 10 && a.lt == 4) return launch_r16_geom<INV, PASS_A, SKIP, 10, 4, 1024>(c, a, count);  // 64-byte rows

@@ -34,6 +34,7 @@ struct R16Args {
     size_t in_col_stride, out_col_stride;
     uint32_t tiles;
     uint32_t cols;  // number of columns (polynomials) in the launch
+    uint32_t cpw;   // columns per workgroup (multi-column pass A)
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t i) { return i + (i >> 4); }
@@ -417,6 +418,58 @@ __global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
         lds_get<4>(x, s, 0, a.lt, tid, nt);
         step_compute_tw<4, true, true, 0>(x, twc);
         glb_put<4, true, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
+    }
+}
+
+// Pass A of the forward transform for the hot geometry (2^12-element tiles, three radix-16 steps), several columns per
+// workgroup: the twist slice of the tile and the twiddles of all three steps depend only on the tile, so they are loaded
+// once and reused for `a.cpw` consecutive columns.  Cuts the twist re-reads (one 2^m-word table per column otherwise:
+// measured 0.9 GB fetched per launch for 0.2 GB of input) and ~60 address/load instructions per column.
+template <int SKIP>
+__global__ __launch_bounds__(256) void ntt_passA_fwd12_multi_kernel(R16Args a) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* s = lds;
+    const uint32_t* __restrict__ ltw = a.tw;
+    const uint32_t tid = threadIdx.x, nt = 256u;
+    a.lr = 12;
+    a.lrows = 12;
+    a.lt = 0;
+    const uint32_t tile = blockIdx.x % a.tiles, colg = blockIdx.x / a.tiles;
+    const size_t tile_off = (size_t)tile << 12;
+    uint32_t tw0[16], tw1[16], tw2[16], f[16];
+    tw_load<4, true, SKIP>(tw0, ltw, 0, 0, tid, nt);
+    tw_load<4, false, 0>(tw1, ltw, 4, 0, tid, nt);
+    tw_load<4, false, 0>(tw2, ltw, 8, 0, tid, nt);
+    const bool has_twist = a.twist != nullptr;
+    if (has_twist) {
+        const uint32_t* tp = a.twist + tile_off;  // last step: thread owns rows tid + 256 * mid
+#pragma unroll
+        for (int mid = 0; mid < 16; ++mid) f[mid] = tp[tid + 256u * mid];
+    }
+    const uint32_t c0 = colg * a.cpw;
+    for (uint32_t c = 0; c < a.cpw && c0 + c < a.cols; ++c) {
+        const uint32_t* src = a.in + (size_t)(c0 + c) * a.in_col_stride;
+        uint32_t* dst = a.out + (size_t)(c0 + c) * a.out_col_stride + tile_off;
+        uint32_t x[16];
+        glb_get<4, false, true>(x, a, src, tile_off, 0, tid, nt);
+        step_compute_tw<4, false, true, SKIP>(x, tw0);
+        if (c) __syncthreads();  // the previous column's last regrouping has been read by everyone
+        lds_put<4>(x, s, 0, 0, tid, nt);
+        __syncthreads();
+        lds_get<4>(x, s, 4, 0, tid, nt);
+        step_compute_tw<4, false, false, 0>(x, tw1);
+        __syncthreads();
+        lds_put<4>(x, s, 4, 0, tid, nt);
+        __syncthreads();
+        lds_get<4>(x, s, 8, 0, tid, nt);
+        step_compute_tw<4, false, false, 0>(x, tw2);
+        if (has_twist) {
+#pragma unroll
+            for (int mid = 0; mid < 16; ++mid) dst[tid + 256u * mid] = fp_mul(x[mid], f[mid]);
+        } else {
+#pragma unroll
+            for (int mid = 0; mid < 16; ++mid) dst[tid + 256u * mid] = x[mid];
+        }
     }
 }
 

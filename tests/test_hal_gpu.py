@@ -143,6 +143,27 @@ def test_ntt_largest_segment_sizes(hal, oracle, bits):
     assert np.array_equal(io.view(), ref)
 
 
+@pytest.mark.parametrize("cpw,count", [(1, 5), (2, 5), (4, 7), (8, 3), (8, 17), (16, 16)])
+def test_lde_columns_per_workgroup(hal, oracle, cpw, count):
+    """Forward pass A shares one load of the tile's twist/twiddles between `cpw` columns: ragged column counts."""
+    hal.set_tunable("ntt_cols_per_wg", cpw)
+    try:
+        n = 1 << 14
+        x = rnd(cpw * 100 + count, n * count)
+        out = hal.alloc(4 * n * count)
+        hal.batch_expand_into_evaluate_ntt(out, hal.copy_from(x), count, 2)
+        ref = np.zeros(4 * n * count, np.uint32)
+        oracle.bxo_batch_expand_into_evaluate_ntt(ref, x, count, n, 2)
+        assert np.array_equal(out.view(), ref)
+        io = hal.copy_from(x)
+        hal.batch_evaluate_ntt(io, count, 0)
+        ref2 = x.copy()
+        oracle.bxo_batch_evaluate_ntt(ref2, count, n, 0)
+        assert np.array_equal(io.view(), ref2)
+    finally:
+        hal.set_tunable("ntt_cols_per_wg", 8)
+
+
 def test_ntt_linearity_full_size(hal):
     n = 1 << 20
     a, b = rnd(1, n), rnd(2, n)
