@@ -189,7 +189,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")))["kernels"]
-            sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k]
+            sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k or "ntt_passA_fwd12_multi_kernel" in k]
             if sel:
                 launches = max(v["launches"] for v in sel)
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / launches
