@@ -50,11 +50,19 @@ def cpu_baseline(po2_sample, widths, po2_full):
     except Exception:
         path = None
     L = ol.lib(path) if path else ol.lib()
-    cores = L.bxo_get_threads()
     ol.prove_segment(10, 2, 4, 2, 1, L)  # warm
-    t0 = time.time()
-    ol.prove_segment(po2_sample, *widths, 0xB0D1E550000, L)
-    dt = time.time() - t0
+    # the oracle's parallel regions are short, so more threads is not always faster: time the sample with all hardware
+    # threads and with 32 / 16, keep the best (that thread count is what `cores` reports)
+    ncpu = os.cpu_count() or 1
+    best = None
+    for threads in sorted({ncpu, min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        L.bxo_set_threads(threads)
+        t0 = time.time()
+        ol.prove_segment(po2_sample, *widths, 0xB0D1E550000, L)
+        dt_try = time.time() - t0
+        if best is None or dt_try < best[0]:
+            best = (dt_try, threads)
+    dt, cores = best
     scale = 1 << (po2_full - po2_sample)
     return {
         "value": 1.0 / (dt * scale),

@@ -79,6 +79,10 @@ def lib(path=None):
         fn.argtypes = args
         fn.restype = res
     L.bxo_init()
+    # The oracle's OpenMP regions are short; on many-core hosts (the GPU box has 128 hardware threads) fork/join overhead
+    # dominates small problems (a 2^12 proof took 15 s with 128 threads vs 0.3 s with 8).  Default to at most 16 threads;
+    # bench.py's cpu_baseline leg picks its own count explicitly.
+    L.bxo_set_threads(min(os.cpu_count() or 1, int(os.environ.get("BXO_THREADS", "16"))))
     if path is None:
         _LIB = L
     return L
