@@ -5,17 +5,20 @@
 // reached from bento/crates/workflow/src/tasks/prove.rs:41-49.  The upstream CPU code is a recursive
 // radix-2 DIF/DIT; the arithmetic is exact, so any factorisation of the same DFT gives identical words.
 //
-// MI355X design (DESIGN.md §3): a size-2^m transform is factored "four-step" as 2^m = 2^m_hi * 2^m_lo.
-//   pass A  (ntt_block_kernel)   : 2^m_lo contiguous blocks of 2^m_hi elements, each transformed entirely in LDS
-//                                  with perfectly coalesced loads/stores; the inter-pass twist w_M^(j_lo*k2)
-//                                  (and the 1/M scale for the inverse) comes from a precomputed table that is
-//                                  streamed in the same order as the data.
-//   pass B  (ntt_strided_kernel) : 2^m_lo-point transforms across the blocks (stride 2^m_hi), T adjacent
-//                                  positions per workgroup so every row access is a T*4-byte contiguous segment.
+// MI355X design (DESIGN.md §4): a size-2^m transform is factored "four-step" as 2^m = 2^m_hi * 2^m_lo.
+//   pass A : 2^m_lo contiguous blocks of 2^m_hi elements, transformed with perfectly coalesced loads/stores; the
+//            inter-pass twist w_M^(j_lo*k2) (and the 1/M scale for the inverse) comes from a precomputed table that is
+//            streamed in the same order as the data.
+//   pass B : 2^m_lo-point transforms across the blocks (stride 2^m_hi), T adjacent positions per workgroup so every
+//            row access is a T*4-byte contiguous segment.
 // Forward (evaluate) = A then B, bit-reversed coefficients -> natural evaluations; the zero-padding "expand" is
 // folded into pass A's load (out[i] = in[i >> bits]; the first `bits` stages are skipped exactly like upstream).
-// Inverse (interpolate) = B then A.  Each pass moves every element HBM->LDS->HBM once: 2 reads + 2 writes per
-// element for m <= 26 instead of m reads/writes.  Sizes with m <= m_hi need pass A only.
+// Inverse (interpolate) = B then A.  Each pass moves every element through HBM once: 2 reads + 2 writes per element
+// instead of m.  Sizes with m <= m_hi need pass A only.
+// Two kernel families implement the passes:
+//   ntt_r16.hpp  (default) register-resident radix-16 steps, LDS only for regrouping — the fast path for tiles >= 2^10;
+//   this file    ntt_block_kernel / ntt_strided_kernel: one radix-2 stage per LDS round trip — the general fallback for
+//                small or unaligned shapes and unusual expand_bits (tunable ntt_fast = 0 forces it; both are tested).
 #include "ctx.hpp"
 #include "ntt_r16.hpp"
 

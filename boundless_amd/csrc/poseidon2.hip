@@ -18,16 +18,20 @@ constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
 constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device parameter table
 
 // ---------------------------------------------------------------------------------------------------------------
-// Instruction budget.  Every 32-bit integer VALU op issues at the same rate on gfx950 (profiles/r01_microbench_valu.jsonl),
-// a canonical modular add is 3 instructions and a canonical Montgomery product 5, so the permutation is organised to
-// minimise instruction count, not multiplications:
+// Instruction budget.  The kernel is VALU-issue-bound and on gfx950 a 32-bit multiply-class op (v_mad_u64_u32,
+// v_mul_lo/hi_u32, v_min_u32, v_lshl_add_u64) costs ~4 cycles per wave and a plain add/sub/and/mov ~2
+// (profiles/r01_microbench2_instr_cost.jsonl): a canonical modular add is 2 cheap + 1 expensive instructions, a lazy
+// Montgomery product 3 expensive ones (+ v_sub, v_min for the canonical form).  The permutation is organised to minimise
+// that weighted instruction count, not multiplications (bounds are verified on the host by tests/host_arith_check.cpp,
+// which compiles poseidon2_arith.hpp with every bound asserted):
 //   * linear layers run UNREDUCED in 64 bits: v_mad_u64_u32 multiplies by the small matrix entries and accumulates in
 //     one instruction (external layer outputs < 2^38, internal-layer sum < 2^37);
 //   * the return to 32 bits is one Montgomery reduction per cell, and the next round constant rides in its
 //     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [mod P, REDC = * 2^-32];
 //   * cells are kept only BOUNDED, not canonical, between rounds; a conditional subtraction is spent only where a
 //     bound would otherwise break.  Results are congruent mod P at every step and the words that leave the permutation
-//     are canonical, so the output is bit-identical to the reduce-everywhere form (~8 k instead of ~14.5 k instructions).
+//     are canonical, so the output is bit-identical to the reduce-everywhere form (9.1 k VALU instructions per permutation
+//     measured by PMC, down from ~14.5 k).
 //
 // Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
 //   red64_lazy output                  < M1 + 18 + P                       < 1.13334 P          (M1 = 2^32 mod P)
@@ -42,8 +46,9 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 // ---------------------------------------------------------------------------------------------------------------
 // Pinned v_mad_u64_u32 forms.  Left to itself hipcc rewrites "x*1 + acc" / "x*2 + acc" into v_lshl_add_u64 plus a v_mov
 // that zero-extends the 32-bit operand into a register pair — two instructions on the same issue port instead of one.
-// K is an inline constant (1, 2, 4); the 64-bit addend is a VGPR pair, the literal 0, or an SGPR pair (a wave-uniform
-// round constant zero-extended on the scalar unit, which costs no VALU slot).  vcc receives the (unused) carry-out.
+// K is an inline constant; the 64-bit addend is a VGPR pair or the literal 0.  vcc receives the (unused) carry-out.
+// Only the internal-round sum uses them: pinning the external layer the same way raised VGPR pressure (150, 3 waves per
+// SIMD) and measured slower than the compiler's v_lshl_add_u64 form.
 template <int K>
 __device__ __forceinline__ uint64_t madk(uint32_t a, uint64_t acc) {
     uint64_t r;
@@ -54,11 +59,6 @@ template <int K>
 __device__ __forceinline__ uint64_t madk0(uint32_t a) {
     uint64_t r;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "n"(K) : "vcc");
-    return r;
-}
-__device__ __forceinline__ uint64_t mad_vvs(uint32_t a, uint32_t b, uint64_t c_uniform) {
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform) : "vcc");
     return r;
 }
 
