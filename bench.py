@@ -218,8 +218,24 @@ def main():
         # streams, so the kernel's own roofline comes from the isolated probe (same process, right after the timed region,
         # HIP events on the HAL stream; agrees with the rocprofv3 summary of `--inflight 1`); the in-region figure (agrees
         # with the rocprofv3 summary of the default command) is reported beside it.
+        def ntt_valu_view(r):
+            # VALU-issue view of the same launch: wave-instructions per output element of the two LDE kernels from the
+            # committed PMC counts (pass A multi-column: 8192 elements per wave, pass B: 1024 elements per wave)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
+                a = [v["valu_insts_per_wave"] for k, v in pmc.items() if "ntt_passA_fwd12_multi_kernel" in k][0] / 8192.0
+                b = [v["valu_insts_per_wave"] for k, v in pmc.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0] / 1024.0
+                out_elems = r["achieved_bytes_per_launch"] / 4.0 / 1.25
+                rate = out_elems * (a + b) / (r["avg_ms_per_launch"] * 1e-3)
+                r["valu_view"] = {"wave_insts_per_output_element": round(a + b, 4), "wave_insts_per_s": rate,
+                                  "issue_peak_mul": 1024 * 2.4e9 / 4, "issue_peak_cheap": 1024 * 2.4e9 / 2,
+                                  "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3)}
+            except Exception:
+                pass
+            return r
+
         roofline_in_region = ntt_roofline(kernels, "timed region, %d segments in flight" % len(servers))
-        roofline = ntt_roofline(iso_k, "isolated probe: one extra segment proved alone after the timed region") if iso_k else roofline_in_region
+        roofline = ntt_valu_view(ntt_roofline(iso_k, "isolated probe: one extra segment proved alone after the timed region")) if iso_k else roofline_in_region
         dom_name = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         # The dominant entry point (hash_rows: Poseidon2 leaf hashing) is VALU-issue-bound: report its instruction rate
         # from the committed PMC count of VALU instructions per permutation against the chip's issue peaks
