@@ -75,6 +75,38 @@ def cpu_baseline(po2_sample, widths, po2_full):
     }
 
 
+def agent_mode(args, widths, device, lanes):
+    """Segments/s through the native prove agent (include/bx_agent.h) over the in-memory hot store and task db."""
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment
+
+    out = {}
+    for verify in (True, False):
+        a = ag.Agent(prover=None, device=device, inflight=lanes, widths=widths, poll_time=0.001, verify=verify)
+        try:
+            def enqueue(job, n):
+                for i in range(n):
+                    a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
+                    a.taskdb.create_task(job, f"prove-{i}", {"Prove": {"index": i}})
+
+            enqueue("warm", lanes)
+            a.poll_work(max_idle_polls=1)
+            n = max(2, args.steps) * lanes
+            enqueue("timed", n)
+            t0 = time.perf_counter()
+            done = a.poll_work(max_idle_polls=1)
+            dt = time.perf_counter() - t0
+            if done != n:
+                raise RuntimeError(f"agent completed {done} of {n} tasks")
+            out["verify_on" if verify else "verify_off"] = {"segment_proofs_per_s": n / dt, "segments": n, "seconds": dt}
+        finally:
+            a.close()
+    out["lanes"] = lanes
+    out["note"] = ("untimed extra: tasks claimed from the in-memory task db by bx_agent_poll_work; verify_on includes the CPU "
+                   "seal verification the reference runs after every prove (prove.rs:53-55)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +120,7 @@ def main():
     ap.add_argument("--dist-backend", type=str, default=None, help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 path be exercised on a single-GPU box")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index for every rank (testing only; default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
     ap.add_argument("--cpu-sample-po2", type=int, default=16)
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
@@ -294,9 +327,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_po2, args.po2), widths, args.po2)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(out))
     for sv in servers:
         sv.close()
+    if rank == 0:
+        if world == 1 and not args.no_agent_mode:
+            # Untimed extra (never `value`): the same workload claimed through the native feed loop (bx_agent_poll_work:
+            # hot-store GET -> prove -> CPU verify -> SETEX -> UNLINK -> update_task_done) with the same number of lanes.
+            try:
+                out["agent_mode"] = agent_mode(args, widths, local_rank, max(1, args.inflight))
+            except Exception as e:  # reported, never required for the GPU number
+                out["agent_mode"] = {"error": str(e)}
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

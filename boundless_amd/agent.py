@@ -1,266 +1,272 @@
-"""Agent-equivalent feed loop for the prove stream.
+"""Prove-stream agent — ctypes binding of the native feed loop (boundless_amd/csrc/agent.cpp, include/bx_agent.h).
 
-Mirrors, for the `prove` task stream only, what a Bento agent process does around the hot path:
-  * `tasks::prove::prover`      bento/crates/workflow/src/tasks/prove.rs:18-135  -> `prove_task`
-  * key scheme                  bento/crates/workflow/src/tasks/mod.rs:23-29     -> SEGMENTS_PATH / RECUR_RECEIPT_PATH
-  * task JSON                   bento/crates/workflow-common/src/lib.rs:88-92,160-178 (`{"Prove":{"index":n}}`)
-  * poll / process / retry      bento/crates/workflow/src/lib.rs:369-438,445-530 (claim -> run -> done | retry | failed)
-  * metrics                     bento/crates/workflow-common/src/metrics.rs:108-117,323-335
-    (`task_operations_total`, `task_duration_seconds{task_name,operation_type,status}`)
-The reference's stores (Redis hot store, Postgres taskdb) are control plane and out of scope; they appear here only as
-the minimal in-process interfaces the loop needs (`HotStore`, `TaskStream`).  The `lift` step (recursion circuit) is not
-reproducible offline, so the verified segment receipt itself is stored under the recursion-receipt key.
+What it mirrors, for the `prove` task stream only (all logic is C++; this file marshals and adapts Python callables):
+  * `Agent::poll_work` / `process_work`   bento/crates/workflow/src/lib.rs:279-442, 445-530
+  * `tasks::prove::prover`                bento/crates/workflow/src/tasks/prove.rs:18-135
+  * key scheme                            bento/crates/workflow/src/tasks/mod.rs:23-29
+  * task JSON                             bento/crates/workflow-common/src/lib.rs:88-92,160-178 (`{"Prove":{"index":n}}`)
+  * metrics                               bento/crates/workflow-common/src/metrics.rs:61-70,108-117,288-335
+The reference's Redis/Postgres clients are out of scope; the library's in-memory `HotStore` / `TaskDb` stand in for them.
 """
+import ctypes as C
 import json
 import struct
-import threading
-import time
-from dataclasses import dataclass, field
 
 import numpy as np
 
+from .hal import HalError, load_library
 from .prover import Segment, SegmentReceipt
 
 RECUR_RECEIPT_PATH = "recursion_receipts"
 SEGMENTS_PATH = "segments"
-RECEIPT_PATH = "receipts"
-_DURATION_BUCKETS = (0.1, 0.5, 1.0, 2.5, 5.0, 10.0, 25.0, 50.0, 100.0, 250.0, 500.0)
+TASK_STATES = ("ready", "running", "done", "failed")
+
+
+class _HotStoreOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("get", C.c_void_p), ("free_value", C.c_void_p), ("set_ex", C.c_void_p),
+                ("unlink", C.c_void_p)]
+
+
+class _TaskDbOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("request_work", C.c_void_p), ("update_task_done", C.c_void_p),
+                ("update_task_failed", C.c_void_p), ("update_task_retry", C.c_void_p), ("current_retries", C.c_void_p)]
+
+
+_SEAL_WORDS_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32)
+_PROVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32),
+                        C.c_size_t, C.POINTER(C.c_size_t))
+
+
+class _ProverOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("seal_words", _SEAL_WORDS_FN), ("prove_segment", _PROVE_FN)]
+
+
+class _ReadyTask(C.Structure):
+    _fields_ = [("job_id", C.c_char * 40), ("task_id", C.c_char * 128), ("task_def", C.c_char * 1024),
+                ("max_retries", C.c_int32)]
+
+
+class _TaskInfo(C.Structure):
+    _fields_ = [("state", C.c_int32), ("retries", C.c_int32), ("max_retries", C.c_int32), ("error", C.c_char * 1100),
+                ("output", C.c_char * 256)]
+
+
+class _AgentConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("inflight", C.c_uint32), ("w_code", C.c_uint32), ("w_data", C.c_uint32),
+                ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("verify", C.c_int32),
+                ("task_stream", C.c_char * 64)]
+
+
+def _lib():
+    lib = load_library()
+    if getattr(lib, "_bx_agent_declared", False):
+        return lib
+    vp, cp, sz = C.c_void_p, C.c_char_p, C.c_size_t
+    sigs = {
+        "bx_mem_store_create": ([C.POINTER(vp)], cp), "bx_mem_store_destroy": ([vp], None),
+        "bx_mem_store_ops": ([vp], _HotStoreOps), "bx_mem_store_key_count": ([vp], sz),
+        "bx_mem_store_keys": ([vp, cp, sz], cp),
+        "bx_mem_taskdb_create": ([C.POINTER(vp)], cp), "bx_mem_taskdb_destroy": ([vp], None),
+        "bx_mem_taskdb_ops": ([vp], _TaskDbOps),
+        "bx_mem_taskdb_create_task": ([vp, cp, cp, cp, cp, C.c_int32], cp),
+        "bx_mem_taskdb_task_info": ([vp, cp, cp, C.POINTER(_TaskInfo)], cp), "bx_mem_taskdb_count": ([vp, C.c_int32], sz),
+        "bx_segment_encode": ([C.c_uint64, C.c_uint32, C.c_uint64, vp], None),
+        "bx_segment_decode": ([vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)], cp),
+        "bx_agent_create": ([C.POINTER(_AgentConfig), C.POINTER(_HotStoreOps), C.POINTER(_TaskDbOps), vp, C.POINTER(vp)], cp),
+        "bx_agent_destroy": ([vp], cp), "bx_agent_poll_work": ([vp, C.c_int64, C.POINTER(C.c_uint64)], cp),
+        "bx_agent_stop": ([vp], None), "bx_agent_process_one": ([vp, C.POINTER(_ReadyTask), C.POINTER(C.c_int)], cp),
+        "bx_agent_metrics": ([vp, cp, sz], sz),
+    }
+    for name, (args, res) in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    lib._bx_agent_declared = True
+    return lib
+
+
+def _check(msg):
+    if msg:
+        raise HalError(msg.decode())
 
 
 # ---------------------------------------------------------------------------------------------------------------- wire
 def serialize_segment(seg: Segment) -> bytes:
-    """Stand-in for `bincode(risc0_zkvm::Segment)` (tasks/mod.rs:40-47): index u64 | po2 u32 | seed u64, little endian."""
-    return struct.pack("<QIQ", seg.index, seg.po2, seg.seed & (2**64 - 1))
+    """Stand-in for `bincode(risc0_zkvm::Segment)` (tasks/mod.rs:40-47): bx_segment_encode."""
+    out = (C.c_uint8 * 20)()
+    _lib().bx_segment_encode(seg.index, seg.po2, seg.seed & (2**64 - 1), out)
+    return bytes(out)
 
 
 def deserialize_segment(blob: bytes) -> Segment:
-    try:
-        index, po2, seed = struct.unpack("<QIQ", blob)
-    except struct.error as e:
-        raise ValueError("Failed to deserialize segment data from redis") from e
-    return Segment(index=index, po2=po2, seed=seed)
-
-
-def serialize_receipt(r: SegmentReceipt) -> bytes:
-    head = struct.pack("<QII", r.index, r.po2, r.seal.size)
-    return head + np.ascontiguousarray(r.seal, dtype="<u4").tobytes()
+    i, p, s = C.c_uint64(), C.c_uint32(), C.c_uint64()
+    buf = (C.c_uint8 * max(len(blob), 1)).from_buffer_copy(blob or b"\0")
+    msg = _lib().bx_segment_decode(buf, len(blob), C.byref(i), C.byref(p), C.byref(s))
+    if msg:
+        raise ValueError(msg.decode())
+    return Segment(index=i.value, po2=p.value, seed=s.value)
 
 
 def deserialize_receipt(blob: bytes) -> SegmentReceipt:
+    """index u64 | po2 u32 | seal_words u32 | seal (include/bx_agent.h)"""
     index, po2, n = struct.unpack_from("<QII", blob)
-    seal = np.frombuffer(blob, dtype="<u4", count=n, offset=16).copy()
-    return SegmentReceipt(seal=seal, index=index, po2=po2)
+    return SegmentReceipt(seal=np.frombuffer(blob, dtype="<u4", count=n, offset=16).copy(), index=index, po2=po2)
 
 
-def parse_task(task_def: str):
-    """`serde_json::from_value::<TaskType>` for the variants this agent serves."""
-    d = json.loads(task_def) if isinstance(task_def, str) else task_def
-    if not isinstance(d, dict) or len(d) != 1:
-        raise ValueError("Invalid task_def")
-    (kind, body), = d.items()
-    if kind == "Prove":
-        return "prove", ProveReq(index=int(body["index"]))
-    raise ValueError(f"task type {kind} is not served by the prove agent")
-
-
-def job_type_str(kind):
-    return {"prove": "prove-lift"}[kind]  # TaskType::to_job_type_str
-
-
-@dataclass
-class ProveReq:
-    index: int
-
-
-# ---------------------------------------------------------------------------------------------------------------- stores
+# -------------------------------------------------------------------------------------------------------------- stores
 class HotStore:
-    """The four Redis operations the prove task uses (workflow/src/redis.rs:19-63): GET, SETEX, UNLINK (+ SET)."""
+    """The library's in-memory hot store (GET / SETEX / UNLINK, workflow/src/redis.rs:19-63)."""
 
     def __init__(self):
-        self._d = {}
-        self._lock = threading.Lock()
+        self._lib = _lib()
+        self._h = C.c_void_p()
+        _check(self._lib.bx_mem_store_create(C.byref(self._h)))
+        self.ops = self._lib.bx_mem_store_ops(self._h)
+        self._get = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                C.c_char_p, C.c_size_t)(self.ops.get)
+        self._free = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))(self.ops.free_value)
+        self._set = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_char_p,
+                                C.c_size_t)(self.ops.set_ex)
+        self._unlink = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t)(self.ops.unlink)
 
     def get(self, key):
-        with self._lock:
-            v = self._d.get(key)
-            if v is None:
-                raise KeyError(key)
-            value, expires = v
-            if expires is not None and expires < time.monotonic():
-                del self._d[key]
-                raise KeyError(key)
-            return value
+        v, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._get(self._h, key.encode(), C.byref(v), C.byref(n), None, 0)
+        if rc != 0:
+            raise KeyError(key)
+        out = C.string_at(v, n.value)
+        self._free(self._h, v)
+        return out
 
     def set_key_with_expiry(self, key, value, ttl_secs=None):
-        with self._lock:
-            self._d[key] = (bytes(value), None if ttl_secs is None else time.monotonic() + ttl_secs)
+        self._set(self._h, key.encode(), bytes(value), len(value), int(ttl_secs or 0), None, 0)
 
     def unlink(self, key):
-        with self._lock:
-            self._d.pop(key, None)
+        self._unlink(self._h, key.encode(), None, 0)
 
     def keys(self):
-        with self._lock:
-            return sorted(self._d)
+        buf = C.create_string_buffer(1 << 16)
+        _check(self._lib.bx_mem_store_keys(self._h, buf, len(buf)))
+        return [k for k in buf.value.decode().split("\n") if k]
+
+    def __del__(self):
+        try:
+            self._lib.bx_mem_store_destroy(self._h)
+        except Exception:
+            pass
 
 
-@dataclass
-class _TaskRow:
-    job_id: str
-    task_id: str
-    task_def: str
-    max_retries: int = 3
-    retries: int = 0
-    state: str = "ready"  # ready | running | done | failed
-    error: str = ""
+class TaskRow:
+    def __init__(self, job_id, task_id, info):
+        self.job_id, self.task_id = job_id, task_id
+        self.state = TASK_STATES[info.state]
+        self.retries, self.max_retries = info.retries, info.max_retries
+        self.error, self.output = info.error.decode(), info.output.decode()
 
 
-class TaskStream:
-    """Claim-when-idle task stream with retry bookkeeping (the `request_work` / `update_task_*` calls of lib.rs:369-438)."""
+class TaskDb:
+    """The library's in-memory task table: request_work / update_task_done|failed|retry with the state transitions of
+    bento/crates/taskdb/migrations/1_taskdb.sql:308-391."""
 
     def __init__(self):
-        self._rows = []
-        self._lock = threading.Lock()
+        self._lib = _lib()
+        self._h = C.c_void_p()
+        _check(self._lib.bx_mem_taskdb_create(C.byref(self._h)))
+        self.ops = self._lib.bx_mem_taskdb_ops(self._h)
+        self._ids = []
 
-    def create_task(self, job_id, task_id, task_def, max_retries=3):
-        with self._lock:
-            self._rows.append(_TaskRow(str(job_id), str(task_id), json.dumps(task_def) if not isinstance(task_def, str) else task_def,
-                                       max_retries))
+    def create_task(self, job_id, task_id, task_def, max_retries=3, stream="prove"):
+        d = task_def if isinstance(task_def, str) else json.dumps(task_def)
+        _check(self._lib.bx_mem_taskdb_create_task(self._h, stream.encode(), str(job_id).encode(), str(task_id).encode(),
+                                                   d.encode(), max_retries))
+        self._ids.append((str(job_id), str(task_id)))
 
-    def request_work(self):
-        with self._lock:
-            for r in self._rows:
-                if r.state == "ready":
-                    r.state = "running"
-                    return r
-        return None
-
-    def update_task_done(self, row):
-        with self._lock:
-            row.state = "done"
-
-    def update_task_retry(self, row, err):
-        """Returns True if the task was requeued, False if it ran out of retries and was failed."""
-        with self._lock:
-            row.error = err
-            if row.retries < row.max_retries:
-                row.retries += 1
-                row.state = "ready"
-                return True
-            row.state = "failed"
-            return False
+    def task(self, job_id, task_id):
+        info = _TaskInfo()
+        _check(self._lib.bx_mem_taskdb_task_info(self._h, str(job_id).encode(), str(task_id).encode(), C.byref(info)))
+        return TaskRow(str(job_id), str(task_id), info)
 
     def rows(self):
-        with self._lock:
-            return list(self._rows)
+        return [self.task(j, t) for j, t in self._ids]
+
+    def count(self, state):
+        return self._lib.bx_mem_taskdb_count(self._h, TASK_STATES.index(state))
+
+    def __del__(self):
+        try:
+            self._lib.bx_mem_taskdb_destroy(self._h)
+        except Exception:
+            pass
 
 
-# ---------------------------------------------------------------------------------------------------------------- metrics
-class Metrics:
-    """`task_operations_total` + `task_duration_seconds` with the reference's labels and buckets."""
-
-    def __init__(self):
-        self.ops = {}
-        self.hist = {}
-        self._lock = threading.Lock()
-
-    def record_task_operation(self, task_name, operation_type, status, seconds):
-        key = (task_name, operation_type, status)
-        with self._lock:
-            self.ops[key] = self.ops.get(key, 0) + 1
-            h = self.hist.setdefault(key, {"buckets": [0] * len(_DURATION_BUCKETS), "sum": 0.0, "count": 0})
-            for i, le in enumerate(_DURATION_BUCKETS):
-                if seconds <= le:
-                    h["buckets"][i] += 1
-            h["sum"] += seconds
-            h["count"] += 1
-
-    record_task = record_task_operation
-
-    def exposition(self):
-        """Prometheus text format (what the agent's exporter serves on PROMETHEUS_METRICS_ADDR)."""
-        out = ["# TYPE task_operations_total counter"]
-        lab = lambda k: f'task_name="{k[0]}",operation_type="{k[1]}",status="{k[2]}"'
-        for k, v in sorted(self.ops.items()):
-            out.append(f"task_operations_total{{{lab(k)}}} {v}")
-        out.append("# TYPE task_duration_seconds histogram")
-        for k, h in sorted(self.hist.items()):
-            for le, n in zip(_DURATION_BUCKETS, h["buckets"]):
-                out.append(f'task_duration_seconds_bucket{{{lab(k)},le="{le}"}} {n}')
-            out.append(f'task_duration_seconds_bucket{{{lab(k)},le="+Inf"}} {h["count"]}')
-            out.append(f"task_duration_seconds_sum{{{lab(k)}}} {h['sum']:.6f}")
-            out.append(f"task_duration_seconds_count{{{lab(k)}}} {h['count']}")
-        return "\n".join(out) + "\n"
-
-
-# ---------------------------------------------------------------------------------------------------------------- agent
-@dataclass
+# --------------------------------------------------------------------------------------------------------------- agent
 class Agent:
-    """One per process / GPU (lib.rs:180-195): holds the prover object for the process lifetime."""
+    """One per process / GPU (lib.rs:180-195).  `prover=None` = the HIP segment prover on `device` with `inflight` lanes;
+    a Python object with `prove_segment(Segment) -> SegmentReceipt` may be injected instead (tests, no GPU)."""
 
-    prover: object  # anything with prove_segment(Segment) -> SegmentReceipt (HipProverServer in production)
-    store: HotStore = field(default_factory=HotStore)
-    stream: TaskStream = field(default_factory=TaskStream)
-    metrics: Metrics = field(default_factory=Metrics)
-    redis_ttl: int = 8 * 60 * 60
-    verify: bool = True
-    poll_time: float = 1.0
+    def __init__(self, prover=None, device=0, inflight=None, widths=(16, 256, 64), redis_ttl=8 * 60 * 60, poll_time=1.0,
+                 verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20):
+        self._lib = _lib()
+        self.store = store or HotStore()
+        self.taskdb = taskdb or TaskDb()
+        self.prover = prover
+        cfg = _AgentConfig(device=device, inflight=inflight or (1 if prover is not None else 3), w_code=widths[0],
+                           w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, verify=int(verify),
+                           task_stream=task_stream.encode())
+        self._errs = {}
+        ops_ptr = None
+        if prover is not None:
+            def seal_words(_user, _lane, _po2):
+                return seal_cap
 
+            def prove(_user, lane, index, po2, seed, seal_out, cap, words):
+                try:
+                    r = prover.prove_segment(Segment(index=index, po2=po2, seed=seed))
+                    seal = np.ascontiguousarray(r.seal, dtype=np.uint32)
+                    if seal.size > cap:
+                        raise HalError("seal does not fit")
+                    C.memmove(seal_out, seal.ctypes.data, seal.nbytes)
+                    words[0] = seal.size
+                    return None
+                except Exception as e:  # noqa: BLE001 - the error crosses the ABI as a string, like the HIP prover's
+                    self._errs[lane] = C.create_string_buffer(f"{e}".encode())
+                    return C.cast(self._errs[lane], C.c_void_p).value
 
-def prove_task(agent: Agent, job_id, task_id, request: ProveReq):
-    """`tasks::prove::prover` (prove.rs:18-135): fetch -> deserialize -> prove -> verify -> store -> cleanup."""
-    start = time.perf_counter()
-    job_prefix = f"job:{job_id}"
-    segment_key = f"{job_prefix}:{SEGMENTS_PATH}:{request.index}"
-    try:
-        blob = agent.store.get(segment_key)
-    except KeyError as e:
-        raise RuntimeError(f"segment data not found for segment key: {segment_key}") from e
-    segment = deserialize_segment(blob)
-    if agent.prover is None:
-        raise RuntimeError("[BENTO-PROVE-002] Missing prover from prove task")
-    t0 = time.perf_counter()
-    receipt = agent.prover.prove_segment(segment)
-    dt = time.perf_counter() - t0
-    agent.metrics.record_task_operation("prove", "prove_segment", "success", dt)
-    if agent.verify:
+            self._ops = _ProverOps(None, _SEAL_WORDS_FN(seal_words), _PROVE_FN(prove))
+            ops_ptr = C.cast(C.pointer(self._ops), C.c_void_p)
+        self._h = C.c_void_p()
+        _check(self._lib.bx_agent_create(C.byref(cfg), C.byref(self.store.ops), C.byref(self.taskdb.ops), ops_ptr,
+                                         C.byref(self._h)))
+
+    def poll_work(self, max_idle_polls=None):
+        """`Agent::poll_work`: returns the number of tasks completed; raises only when the task db itself fails."""
+        done = C.c_uint64()
+        _check(self._lib.bx_agent_poll_work(self._h, -1 if max_idle_polls is None else max_idle_polls, C.byref(done)))
+        return done.value
+
+    def stop(self):
+        self._lib.bx_agent_stop(self._h)
+
+    def process_one(self, job_id, task_id, task_def, max_retries=0):
+        """process_work + poll_work's error bookkeeping for one claimed task; returns True when the task succeeded."""
+        d = task_def if isinstance(task_def, str) else json.dumps(task_def)
+        t = _ReadyTask(str(job_id).encode(), str(task_id).encode(), d.encode(), max_retries)
+        ok = C.c_int()
+        _check(self._lib.bx_agent_process_one(self._h, C.byref(t), C.byref(ok)))
+        return bool(ok.value)
+
+    def metrics_text(self):
+        n = self._lib.bx_agent_metrics(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._lib.bx_agent_metrics(self._h, buf, n)
+        return buf.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bx_agent_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
         try:
-            receipt.verify_integrity()
-        except Exception as e:
-            raise RuntimeError(f"[BENTO-PROVE-004] Failed to verify segment receipt integrity: {e}") from e
-    agent.metrics.record_task("prove", "prove_segment", "success", dt)
-    output_key = f"{job_prefix}:{RECUR_RECEIPT_PATH}:{task_id}"
-    agent.store.set_key_with_expiry(output_key, serialize_receipt(receipt), agent.redis_ttl)
-    agent.store.unlink(segment_key)
-    agent.metrics.record_task_operation("prove", "complete", "success", time.perf_counter() - start)
-
-
-def process_work(agent: Agent, row):
-    """`Agent::process_work` (lib.rs:445-530) for the prove stream."""
-    kind, req = parse_task(row.task_def)
-    if kind == "prove":
-        prove_task(agent, row.job_id, row.task_id, req)
-    agent.stream.update_task_done(row)
-
-
-def poll_work(agent: Agent, stop=None, max_idle_polls=None):
-    """`Agent::poll_work` (lib.rs:279-442): claim, run, mark done; on error retry up to max_retries, then fail the task.
-    A failing task never takes the agent down.  Returns the number of tasks completed."""
-    done = 0
-    idle = 0
-    while stop is None or not stop.is_set():
-        row = agent.stream.request_work()
-        if row is None:
-            idle += 1
-            if max_idle_polls is not None and idle >= max_idle_polls:
-                break
-            time.sleep(agent.poll_time)
-            continue
-        idle = 0
-        try:
-            process_work(agent, row)
-            done += 1
-        except Exception as e:  # noqa: BLE001 - mirrors the agent's catch-all around process_work
-            requeued = agent.stream.update_task_retry(row, f"{type(e).__name__}: {e}")
-            agent.metrics.record_task_operation("prove", "complete", "retry" if requeued else "failed", 0.0)
-    return done
+            self.close()
+        except Exception:
+            pass

@@ -3,7 +3,7 @@
     python -m boundless_amd.build [--force]
 
 One object per translation unit (rebuilt only when its sources change), linked into a single shared library whose
-exported symbols are exactly the `extern "C"` entry points of include/bx_hal.h and include/bx_prover.h.
+exported symbols are exactly the `extern "C"` entry points of include/bx_hal.h, bx_prover.h and bx_agent.h.
 """
 import os
 import subprocess

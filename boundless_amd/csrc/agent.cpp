@@ -1,0 +1,928 @@
+// Prove-stream feed loop: the native host runtime between the task queue and bx_prove_segment.
+//
+// Restates, for the `prove` task stream only:
+//   Agent::poll_work      bento/crates/workflow/src/lib.rs:279-442   (claim, run, retry / fail bookkeeping, SIGTERM flag)
+//   Agent::process_work   bento/crates/workflow/src/lib.rs:445-530   (TaskType dispatch, update_task_done)
+//   tasks::prove::prover  bento/crates/workflow/src/tasks/prove.rs:18-135 (fetch -> prove -> verify -> store -> cleanup)
+//   redis helpers         bento/crates/workflow/src/redis.rs:19-63   (operation names + redis_operations metrics)
+//   metric definitions    bento/crates/workflow-common/src/metrics.rs:61-70,108-117
+// Redis/Postgres themselves are out of scope; they are the callback tables of include/bx_agent.h.  The `lift` step needs the
+// recursion circuit (not available offline), so the verified segment receipt itself is what gets stored under
+// the recursion-receipt key.
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bx_agent.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+double secs_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+thread_local std::string tl_err;
+const char* fail(const std::string& m) {
+    tl_err = m;
+    return tl_err.c_str();
+}
+
+// ------------------------------------------------------------------------------------------------------ tiny JSON ----
+// Enough of JSON to read an externally tagged serde enum: {"Variant": {...fields...}}.
+struct JVal {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    bool is_uint = false;
+    uint64_t u = 0;
+    std::string s;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* find(const char* k) const {
+        for (auto& kv : obj)
+            if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p;
+    const char* end;
+    bool ok = true;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+    }
+    bool lit(const char* t) {
+        size_t n = strlen(t);
+        if ((size_t)(end - p) >= n && memcmp(p, t, n) == 0) {
+            p += n;
+            return true;
+        }
+        return false;
+    }
+    std::string str() {
+        std::string out;
+        ++p;  // opening quote
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u':  // keep \uXXXX escapes verbatim: no key or value this agent reads contains one
+                        out += "\\u";
+                        break;
+                    default: out += *p;
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) {
+            ok = false;
+            return out;
+        }
+        ++p;
+        return out;
+    }
+    JVal value(int depth = 0) {
+        JVal v;
+        ws();
+        if (p >= end || depth > 32) {
+            ok = false;
+            return v;
+        }
+        if (*p == '{') {
+            v.kind = JVal::Obj;
+            ++p;
+            ws();
+            if (p < end && *p == '}') {
+                ++p;
+                return v;
+            }
+            while (ok) {
+                ws();
+                if (p >= end || *p != '"') {
+                    ok = false;
+                    break;
+                }
+                std::string k = str();
+                ws();
+                if (p >= end || *p != ':') {
+                    ok = false;
+                    break;
+                }
+                ++p;
+                v.obj.emplace_back(std::move(k), value(depth + 1));
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == '}') {
+                    ++p;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (*p == '[') {
+            v.kind = JVal::Arr;
+            ++p;
+            ws();
+            if (p < end && *p == ']') {
+                ++p;
+                return v;
+            }
+            while (ok) {
+                v.arr.push_back(value(depth + 1));
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == ']') {
+                    ++p;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (*p == '"') {
+            v.kind = JVal::Str;
+            v.s = str();
+        } else if (lit("true")) {
+            v.kind = JVal::Bool;
+            v.b = true;
+        } else if (lit("false")) {
+            v.kind = JVal::Bool;
+        } else if (lit("null")) {
+            v.kind = JVal::Null;
+        } else {
+            v.kind = JVal::Num;
+            const char* s = p;
+            bool integral = true;
+            if (p < end && *p == '-') {
+                integral = false;
+                ++p;
+            }
+            while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) {
+                if (*p < '0' || *p > '9') integral = false;
+                ++p;
+            }
+            if (p == s) {
+                ok = false;
+                return v;
+            }
+            v.s.assign(s, p);
+            if (integral && v.s.size() <= 20) {
+                errno = 0;
+                v.u = strtoull(v.s.c_str(), nullptr, 10);
+                v.is_uint = errno == 0;
+            }
+        }
+        return v;
+    }
+};
+
+bool parse_json(const char* text, JVal* out) {
+    JParser jp{text, text + strlen(text)};
+    *out = jp.value();
+    jp.ws();
+    return jp.ok && jp.p == jp.end;
+}
+
+// ---------------------------------------------------------------------------------------------------------- metrics ----
+const double TASK_BUCKETS[] = {0.1, 0.5, 1.0, 2.5, 5.0, 10.0, 25.0, 50.0, 100.0, 250.0, 500.0};  // metrics.rs:108-112
+const double REDIS_BUCKETS[] = {0.001, 0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1.0};            // metrics.rs:66-70
+
+struct Hist {
+    std::vector<uint64_t> buckets;
+    double sum = 0;
+    uint64_t count = 0;
+};
+
+struct Family {
+    const char* counter_name;
+    const char* hist_name;
+    const char* counter_help;
+    const char* hist_help;
+    std::vector<const char*> labels;
+    const double* bounds;
+    size_t n_bounds;
+    std::map<std::vector<std::string>, Hist> series;
+
+    void observe(std::vector<std::string> key, double v) {
+        Hist& h = series[std::move(key)];
+        if (h.buckets.empty()) h.buckets.assign(n_bounds, 0);
+        for (size_t i = 0; i < n_bounds; ++i)
+            if (v <= bounds[i]) h.buckets[i]++;
+        h.sum += v;
+        h.count++;
+    }
+    std::string labels_of(const std::vector<std::string>& key) const {
+        std::string s;
+        for (size_t i = 0; i < labels.size(); ++i) {
+            if (i) s += ",";
+            s += labels[i];
+            s += "=\"" + key[i] + "\"";
+        }
+        return s;
+    }
+    void render(std::string& out) const {
+        char buf[96];
+        out += std::string("# HELP ") + counter_name + " " + counter_help + "\n# TYPE " + counter_name + " counter\n";
+        for (auto& kv : series) {
+            snprintf(buf, sizeof buf, "} %llu\n", (unsigned long long)kv.second.count);
+            out += std::string(counter_name) + "{" + labels_of(kv.first) + buf;
+        }
+        out += std::string("# HELP ") + hist_name + " " + hist_help + "\n# TYPE " + hist_name + " histogram\n";
+        for (auto& kv : series) {
+            std::string l = labels_of(kv.first);
+            for (size_t i = 0; i < n_bounds; ++i) {
+                snprintf(buf, sizeof buf, ",le=\"%g\"} %llu\n", bounds[i], (unsigned long long)kv.second.buckets[i]);
+                out += std::string(hist_name) + "_bucket{" + l + buf;
+            }
+            snprintf(buf, sizeof buf, ",le=\"+Inf\"} %llu\n", (unsigned long long)kv.second.count);
+            out += std::string(hist_name) + "_bucket{" + l + buf;
+            snprintf(buf, sizeof buf, "} %.6f\n", kv.second.sum);
+            out += std::string(hist_name) + "_sum{" + l + buf;
+            snprintf(buf, sizeof buf, "} %llu\n", (unsigned long long)kv.second.count);
+            out += std::string(hist_name) + "_count{" + l + buf;
+        }
+    }
+};
+
+struct Metrics {
+    std::mutex mu;
+    Family task{"task_operations_total", "task_duration_seconds", "Total number of task operations by type and status",
+                "Duration of task execution", {"task_name", "operation_type", "status"}, TASK_BUCKETS,
+                sizeof TASK_BUCKETS / sizeof *TASK_BUCKETS, {}};
+    Family redis{"redis_operations_total", "redis_operation_duration_seconds", "Total number of Redis operations by type",
+                 "Duration of Redis operations", {"operation_type", "status"}, REDIS_BUCKETS,
+                 sizeof REDIS_BUCKETS / sizeof *REDIS_BUCKETS, {}};
+    // helpers::record_task_operation / record_task (metrics.rs:298-300,323-335)
+    void record_task_operation(const char* task_name, const char* op, const char* status, double s) {
+        std::lock_guard<std::mutex> g(mu);
+        task.observe({task_name, op, status}, s);
+    }
+    void record_redis_operation(const char* op, const char* status, double s) {
+        std::lock_guard<std::mutex> g(mu);
+        redis.observe({op, status}, s);
+    }
+    std::string exposition() {
+        std::lock_guard<std::mutex> g(mu);
+        std::string out;
+        task.render(out);
+        redis.render(out);
+        return out;
+    }
+};
+
+void put_le(uint8_t* p, uint64_t v, int n) {
+    for (int i = 0; i < n; ++i) p[i] = (uint8_t)(v >> (8 * i));
+}
+uint64_t get_le(const uint8_t* p, int n) {
+    uint64_t v = 0;
+    for (int i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ in-memory stores ----
+struct bx_mem_store {
+    std::mutex mu;
+    struct Val {
+        std::vector<uint8_t> bytes;
+        bool expires = false;
+        Clock::time_point deadline;
+    };
+    std::map<std::string, Val> kv;
+    void sweep_locked() {
+        auto now = Clock::now();
+        for (auto it = kv.begin(); it != kv.end();) it = (it->second.expires && it->second.deadline < now) ? kv.erase(it) : ++it;
+    }
+};
+
+static int mem_get(void* user, const char* key, uint8_t** value, size_t* len, char*, size_t) {
+    auto* s = (bx_mem_store*)user;
+    std::lock_guard<std::mutex> g(s->mu);
+    auto it = s->kv.find(key);
+    if (it == s->kv.end()) return 1;
+    if (it->second.expires && it->second.deadline < Clock::now()) {
+        s->kv.erase(it);
+        return 1;
+    }
+    *len = it->second.bytes.size();
+    *value = (uint8_t*)malloc(*len ? *len : 1);
+    if (!*value) return -1;
+    memcpy(*value, it->second.bytes.data(), *len);
+    return 0;
+}
+static void mem_free_value(void*, uint8_t* v) { free(v); }
+static int mem_set_ex(void* user, const char* key, const uint8_t* value, size_t len, uint64_t ttl, char*, size_t) {
+    auto* s = (bx_mem_store*)user;
+    std::lock_guard<std::mutex> g(s->mu);
+    bx_mem_store::Val v;
+    v.bytes.assign(value, value + len);
+    v.expires = ttl != 0;
+    if (ttl) v.deadline = Clock::now() + std::chrono::seconds(ttl);
+    s->kv[key] = std::move(v);
+    return 0;
+}
+static int mem_unlink(void* user, const char* key, char*, size_t) {
+    auto* s = (bx_mem_store*)user;
+    std::lock_guard<std::mutex> g(s->mu);
+    s->kv.erase(key);
+    return 0;
+}
+
+struct bx_mem_taskdb {
+    std::mutex mu;
+    struct Row {
+        std::string stream, job, task, def, error, output;
+        int32_t max_retries = 0, retries = 0, state = BX_TASK_READY;
+    };
+    std::vector<Row> rows;  // creation order = claim order
+    Row* find_locked(const char* job, const char* task) {
+        for (auto& r : rows)
+            if (r.job == job && r.task == task) return &r;
+        return nullptr;
+    }
+    // 1_taskdb.sql:308-338 (the job row is not modelled)
+    int fail_locked(Row* r, const char* error) {
+        if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
+        r->state = BX_TASK_FAILED;
+        r->error = error;
+        return 1;
+    }
+};
+
+static int tdb_request_work(void* user, const char* stream, bx_ready_task* out, char* errbuf, size_t cap) {
+    auto* t = (bx_mem_taskdb*)user;
+    std::lock_guard<std::mutex> g(t->mu);
+    for (auto& r : t->rows) {
+        if (r.state != BX_TASK_READY || r.stream != stream) continue;
+        if (r.job.size() >= sizeof out->job_id || r.task.size() >= sizeof out->task_id || r.def.size() >= sizeof out->task_def) {
+            snprintf(errbuf, cap, "task %s:%s does not fit bx_ready_task", r.job.c_str(), r.task.c_str());
+            return -1;
+        }
+        r.state = BX_TASK_RUNNING;
+        memset(out, 0, sizeof *out);
+        memcpy(out->job_id, r.job.c_str(), r.job.size());
+        memcpy(out->task_id, r.task.c_str(), r.task.size());
+        memcpy(out->task_def, r.def.c_str(), r.def.size());
+        out->max_retries = r.max_retries;
+        return 1;
+    }
+    return 0;
+}
+static int tdb_done(void* user, const char* job, const char* task, const char* output, char*, size_t) {
+    auto* t = (bx_mem_taskdb*)user;
+    std::lock_guard<std::mutex> g(t->mu);
+    auto* r = t->find_locked(job, task);
+    if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
+    r->state = BX_TASK_DONE;
+    r->output = output ? output : "null";
+    return 1;
+}
+static int tdb_failed(void* user, const char* job, const char* task, const char* error, char*, size_t) {
+    auto* t = (bx_mem_taskdb*)user;
+    std::lock_guard<std::mutex> g(t->mu);
+    return t->fail_locked(t->find_locked(job, task), error);
+}
+// 1_taskdb.sql:361-391
+static int tdb_retry(void* user, const char* job, const char* task, char*, size_t) {
+    auto* t = (bx_mem_taskdb*)user;
+    std::lock_guard<std::mutex> g(t->mu);
+    auto* r = t->find_locked(job, task);
+    if (!r || r->state != BX_TASK_RUNNING) return 0;
+    r->retries += 1;
+    r->state = BX_TASK_READY;
+    r->error.clear();
+    if (r->retries > r->max_retries) {
+        t->fail_locked(r, "retry max hit");
+        return 0;
+    }
+    return 1;
+}
+static int tdb_current_retries(void* user, const char* job, const char* task, int32_t* retries, char*, size_t) {
+    auto* t = (bx_mem_taskdb*)user;
+    std::lock_guard<std::mutex> g(t->mu);
+    auto* r = t->find_locked(job, task);
+    if (!r || r->state != BX_TASK_RUNNING) return 0;
+    *retries = r->retries;
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------ agent ----
+namespace {
+struct Lane {
+    bx_ctx* ctx = nullptr;
+    std::map<uint32_t, bx_prover*> provers;  // one per segment size seen (buffers are allocated once per shape)
+};
+
+// a proved segment on its way through the host half of the task
+struct Pending {
+    bx_ready_task task;
+    Clock::time_point start;
+    std::string job_prefix, segment_key;
+    uint64_t seg_index = 0;
+    uint32_t po2 = 0;
+    std::vector<uint32_t> seal;
+    size_t words = 0;
+    double prove_s = 0;
+    std::vector<uint8_t> wire;
+};
+
+// one-slot mailbox between a lane and its finisher thread
+struct Finisher {
+    std::mutex mu;
+    std::condition_variable cv;
+    Pending* slot = nullptr;
+    bool busy = false, quitting = false;
+    void post(Pending* p) {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return !busy; });
+        slot = p;
+        busy = true;
+        cv.notify_all();
+    }
+    Pending* take() {  // finisher side; nullptr = quit
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return slot || quitting; });
+        Pending* p = slot;
+        slot = nullptr;
+        return p;
+    }
+    void release() {
+        std::lock_guard<std::mutex> l(mu);
+        busy = false;
+        cv.notify_all();
+    }
+    bool wait_idle() {  // returns true when something was pending
+        std::unique_lock<std::mutex> l(mu);
+        bool was = busy;
+        cv.wait(l, [&] { return !busy; });
+        return was;
+    }
+    void quit() {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return !busy; });
+        quitting = true;
+        cv.notify_all();
+    }
+};
+}  // namespace
+
+struct bx_agent {
+    bx_agent_config cfg;
+    bx_hot_store_ops store;
+    bx_taskdb_ops taskdb;
+    bx_segment_prover_ops prover;
+    bool hip = false;
+    std::vector<Lane> lanes;
+    Metrics metrics;
+    std::atomic<int> stop{0};
+    std::mutex create_mu;  // device buffer allocation of a new shape is serialised across lanes
+
+    // ---- default prover ops: the HIP segment prover, one ctx per lane ----
+    const char* hip_prover_for(uint32_t lane_idx, uint32_t po2, bx_prover** out) {
+        Lane& lane = lanes[lane_idx];
+        auto it = lane.provers.find(po2);
+        if (it != lane.provers.end()) {
+            *out = it->second;
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> g(create_mu);
+        if (!lane.ctx) {
+            if (const char* e = bx_init(cfg.device, &lane.ctx)) return e;
+        }
+        bx_segment_params shape{po2, cfg.w_code, cfg.w_data, cfg.w_accum};
+        bx_prover* p = nullptr;
+        if (const char* e = bx_prover_create(lane.ctx, &shape, &p)) return e;
+        lane.provers[po2] = p;
+        *out = p;
+        return nullptr;
+    }
+    static size_t hip_seal_words(void* user, uint32_t lane, uint32_t po2) {
+        auto* a = (bx_agent*)user;
+        bx_prover* p = nullptr;
+        if (a->hip_prover_for(lane, po2, &p)) return 0;
+        return bx_prover_seal_words(p);
+    }
+    static const char* hip_prove(void* user, uint32_t lane, uint64_t, uint32_t po2, uint64_t seed, uint32_t* seal, size_t cap,
+                                 size_t* words) {
+        auto* a = (bx_agent*)user;
+        bx_prover* p = nullptr;
+        if (const char* e = a->hip_prover_for(lane, po2, &p)) return e;
+        return bx_prove_segment(p, seed, seal, cap, words);
+    }
+
+    // ---- redis.rs helpers with their metrics ----
+    // returns "" on success, otherwise the error text
+    std::string store_get(const std::string& key, std::vector<uint8_t>* out) {
+        auto t0 = Clock::now();
+        char eb[256] = {0};
+        uint8_t* v = nullptr;
+        size_t n = 0;
+        int rc = store.get(store.user, key.c_str(), &v, &n, eb, sizeof eb);
+        std::string err;
+        if (rc == 0) {
+            out->assign(v, v + n);
+            if (store.free_value) store.free_value(store.user, v);
+        } else if (rc == 1) {
+            err = "Key not found (nil response): " + key;  // redis.rs:51-55
+        } else {
+            err = eb[0] ? eb : "hot store get failed";
+        }
+        metrics.record_redis_operation("get", rc == 0 ? "success" : "error", secs_since(t0));
+        return err;
+    }
+    std::string store_set(const std::string& key, const std::vector<uint8_t>& val, uint64_t ttl) {
+        auto t0 = Clock::now();
+        char eb[256] = {0};
+        int rc = store.set_ex(store.user, key.c_str(), val.data(), val.size(), ttl, eb, sizeof eb);
+        metrics.record_redis_operation(ttl ? "set_ex" : "set", rc == 0 ? "success" : "error", secs_since(t0));
+        return rc == 0 ? "" : (eb[0] ? eb : "hot store set failed");
+    }
+    std::string store_unlink(const std::string& key) {
+        auto t0 = Clock::now();
+        char eb[256] = {0};
+        int rc = store.unlink(store.user, key.c_str(), eb, sizeof eb);
+        metrics.record_redis_operation("unlink", rc == 0 ? "success" : "error", secs_since(t0));
+        return rc == 0 ? "" : (eb[0] ? eb : "hot store unlink failed");
+    }
+
+    // tasks::prove::prover (prove.rs:18-135) in two halves so the host-side half of one segment (verify, store, cleanup,
+    // update_task_done) can overlap the device half of the lane's next segment.  Each returns "" or the error chain
+    // ("outer: inner", anyhow's `{:#}` form).
+    //   first half: fetch -> deserialize -> prove_segment
+    std::string prove_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t index, Pending* out) {
+        out->start = Clock::now();
+        out->task = task;
+        out->job_prefix = std::string("job:") + task.job_id;
+        out->segment_key = out->job_prefix + ":segments:" + std::to_string(index);  // SEGMENTS_PATH, tasks/mod.rs:25
+        std::vector<uint8_t> blob;
+        std::string e = store_get(out->segment_key, &blob);
+        if (!e.empty()) return "segment data not found for segment key: " + out->segment_key + ": " + e;
+        uint64_t seed = 0;
+        if (const char* de = bx_segment_decode(blob.data(), blob.size(), &out->seg_index, &out->po2, &seed)) return de;
+
+        auto prove_start = Clock::now();
+        if (!prover.prove_segment) return "[BENTO-PROVE-002] Missing prover from prove task";
+        size_t cap = prover.seal_words(prover.user, lane_idx, out->po2);
+        if (cap == 0) return "prove_segment: no prover for a segment of po2 " + std::to_string(out->po2);
+        if (out->seal.size() < cap) out->seal.resize(cap);
+        out->words = 0;
+        if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->seg_index, out->po2, seed, out->seal.data(), cap,
+                                                  &out->words))
+            return pe;
+        out->prove_s = secs_since(prove_start);
+        metrics.record_task_operation("prove", "prove_segment", "success", out->prove_s);
+        return "";
+    }
+    //   second half: verify -> store under the recursion-receipt key -> unlink the segment
+    std::string finish_stage(Pending* p) {
+        if (cfg.verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
+            if (const char* ve = bx_verify_segment(p->seal.data(), p->words))
+                return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
+        }
+        metrics.record_task_operation("prove", "prove_segment", "success", p->prove_s);  // helpers::record_task, prove.rs:57
+
+        std::string output_key = p->job_prefix + ":recursion_receipts:" + p->task.task_id;  // RECUR_RECEIPT_PATH, tasks/mod.rs:23
+        p->wire.resize(BX_RECEIPT_HEADER_BYTES + 4 * p->words);
+        put_le(p->wire.data(), p->seg_index, 8);
+        put_le(p->wire.data() + 8, p->po2, 4);
+        put_le(p->wire.data() + 12, p->words, 4);
+        for (size_t i = 0; i < p->words; ++i) put_le(p->wire.data() + BX_RECEIPT_HEADER_BYTES + 4 * i, p->seal[i], 4);
+        std::string e = store_set(output_key, p->wire, cfg.redis_ttl);
+        if (!e.empty()) return "Failed to set receipt key with expiry: " + e;
+
+        e = store_unlink(p->segment_key);
+        if (!e.empty()) return "Failed to delete segment key: " + e;
+        metrics.record_task_operation("prove", "complete", "success", secs_since(p->start));
+        return "";
+    }
+
+    // Agent::process_work (lib.rs:445-530), first half: TaskType dispatch + the device half of the prove task.
+    std::string dispatch(uint32_t lane, const bx_ready_task& task, Pending* out) {
+        JVal def;
+        std::string bad = std::string("Invalid task_def: ") + task.job_id + ":" + task.task_id;
+        if (!parse_json(task.task_def, &def) || def.kind != JVal::Obj || def.obj.size() != 1) return bad;
+        const std::string& variant = def.obj[0].first;
+        const JVal& body = def.obj[0].second;
+        if (variant == "Prove") {
+            const JVal* idx = body.kind == JVal::Obj ? body.find("index") : nullptr;
+            if (!idx || idx->kind != JVal::Num || !idx->is_uint) return bad;
+            std::string e = prove_stage(lane, task, idx->u, out);
+            if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
+            return "";
+        }
+        static const char* others[] = {"Executor", "Join", "Resolve", "Finalize", "Snark", "Keccak", "Union"};
+        for (const char* o : others)
+            if (variant == o) return "task type " + variant + " reached a prove-stream agent (not served: DESIGN.md §2)";
+        return bad;
+    }
+    // second half: host half of the prove task + update_task_done.  `fatal` is set when the task-db call itself failed.
+    std::string complete(Pending* p, bool* fatal) {
+        std::string e = finish_stage(p);
+        if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
+        char eb[256] = {0};
+        int rc = taskdb.update_task_done(taskdb.user, p->task.job_id, p->task.task_id, "null", eb, sizeof eb);  // prover returns ()
+        if (rc < 0) {
+            *fatal = true;
+            return std::string("[BENTO-WF-133] Failed to report task done: ") + eb;
+        }
+        return "";
+    }
+
+    // the error arm of poll_work (lib.rs:381-436); returns "" or a fatal task-db error
+    std::string handle_failure(const bx_ready_task& task, std::string err) {
+        char eb[256] = {0};
+        if (task.max_retries > 0) {
+            int32_t cur = 0;
+            int found = taskdb.current_retries(taskdb.user, task.job_id, task.task_id, &cur, eb, sizeof eb);
+            if (found < 0) return std::string("[BENTO-WF-109] Failed to read current retries: ") + eb;
+            if (found == 1 && cur + 1 > task.max_retries) {
+                if (err.size() > 1024) err.resize(1024);
+                std::string final_err = err.empty() ? "retry max hit" : "retry max hit: " + err;
+                if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, final_err.c_str(), eb, sizeof eb) < 0)
+                    return std::string("[BENTO-WF-110] Failed to report task failure: ") + eb;
+                return "";
+            }
+            int rc = taskdb.update_task_retry(taskdb.user, task.job_id, task.task_id, eb, sizeof eb);
+            if (rc < 0) return std::string("[BENTO-WF-111] Failed to update task retries: ") + eb;
+        } else {
+            if (err.size() > 1024) err.resize(1024);
+            if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, err.c_str(), eb, sizeof eb) < 0)
+                return std::string("[BENTO-WF-112] Failed to report task failure: ") + eb;
+        }
+        return "";
+    }
+
+    // One lane of poll_work's main loop (lib.rs:369-438).  The lane thread claims and runs the device half; its finisher
+    // thread runs the host half of the previous segment meanwhile (one segment of look-ahead per lane, two seal buffers).
+    void lane_loop(uint32_t lane, int64_t max_idle_polls, std::atomic<uint64_t>* done, std::string* fatal_out) {
+        Finisher fin;
+        std::mutex fatal_mu;
+        auto set_fatal = [&](const std::string& m) {
+            std::lock_guard<std::mutex> g(fatal_mu);
+            if (fatal_out->empty()) *fatal_out = m;
+            stop.store(1);
+        };
+        std::thread finisher([&] {
+            while (Pending* p = fin.take()) {
+                bool fatal = false;
+                std::string err = complete(p, &fatal);
+                if (err.empty()) {
+                    done->fetch_add(1);
+                } else if (fatal) {
+                    set_fatal(err);
+                } else {
+                    std::string f = handle_failure(p->task, err);
+                    if (!f.empty()) set_fatal(f);
+                }
+                fin.release();
+            }
+        });
+        Pending slots[2];
+        int cur = 0;
+        int64_t idle = 0;
+        while (!stop.load(std::memory_order_relaxed)) {
+            bx_ready_task task;
+            char eb[256] = {0};
+            int rc = taskdb.request_work(taskdb.user, cfg.task_stream, &task, eb, sizeof eb);
+            if (rc < 0) {
+                set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + eb);
+                break;
+            }
+            if (rc == 0) {
+                // a finish still in flight may requeue its task (retry): only a poll made with nothing pending counts as idle
+                if (fin.wait_idle()) continue;
+                if (max_idle_polls >= 0 && ++idle >= max_idle_polls) break;
+                // sleep poll_time in slices so a stop request is honoured promptly
+                auto until = Clock::now() + std::chrono::duration<double>(cfg.poll_time);
+                while (!stop.load(std::memory_order_relaxed) && Clock::now() < until)
+                    std::this_thread::sleep_for(std::chrono::duration<double>(std::min(cfg.poll_time, 0.05)));
+                continue;
+            }
+            idle = 0;
+            Pending* p = &slots[cur];
+            std::string err = dispatch(lane, task, p);
+            if (!err.empty()) {
+                std::string f = handle_failure(task, err);
+                if (!f.empty()) {
+                    set_fatal(f);
+                    break;
+                }
+                continue;
+            }
+            fin.post(p);  // blocks while the previous segment's host half is still running
+            cur ^= 1;
+        }
+        fin.quit();
+        finisher.join();
+    }
+};
+
+extern "C" {
+
+// ---- mem store / taskdb ----
+const char* bx_mem_store_create(bx_mem_store** out) {
+    if (!out) return "bx_mem_store_create: out is NULL";
+    *out = new (std::nothrow) bx_mem_store();
+    return *out ? nullptr : "bx_mem_store_create: out of memory";
+}
+void bx_mem_store_destroy(bx_mem_store* s) { delete s; }
+bx_hot_store_ops bx_mem_store_ops(bx_mem_store* s) { return bx_hot_store_ops{s, mem_get, mem_free_value, mem_set_ex, mem_unlink}; }
+size_t bx_mem_store_key_count(bx_mem_store* s) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> g(s->mu);
+    s->sweep_locked();
+    return s->kv.size();
+}
+const char* bx_mem_store_keys(bx_mem_store* s, char* out, size_t cap) {
+    if (!s || !out || cap == 0) return "bx_mem_store_keys: NULL argument";
+    std::lock_guard<std::mutex> g(s->mu);
+    s->sweep_locked();
+    std::string all;
+    for (auto& kv : s->kv) {
+        if (!all.empty()) all += "\n";
+        all += kv.first;
+    }
+    snprintf(out, cap, "%s", all.c_str());
+    return nullptr;
+}
+
+const char* bx_mem_taskdb_create(bx_mem_taskdb** out) {
+    if (!out) return "bx_mem_taskdb_create: out is NULL";
+    *out = new (std::nothrow) bx_mem_taskdb();
+    return *out ? nullptr : "bx_mem_taskdb_create: out of memory";
+}
+void bx_mem_taskdb_destroy(bx_mem_taskdb* t) { delete t; }
+bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t) {
+    return bx_taskdb_ops{t, tdb_request_work, tdb_done, tdb_failed, tdb_retry, tdb_current_retries};
+}
+const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
+                                      int32_t max_retries) {
+    if (!t || !stream || !job || !task || !def) return "bx_mem_taskdb_create_task: NULL argument";
+    std::lock_guard<std::mutex> g(t->mu);
+    if (t->find_locked(job, task)) return fail(std::string("task already exists: ") + job + ":" + task);
+    bx_mem_taskdb::Row r;
+    r.stream = stream;
+    r.job = job;
+    r.task = task;
+    r.def = def;
+    r.max_retries = max_retries;
+    t->rows.push_back(std::move(r));
+    return nullptr;
+}
+const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const char* task, bx_task_info* out) {
+    if (!t || !job || !task || !out) return "bx_mem_taskdb_task_info: NULL argument";
+    std::lock_guard<std::mutex> g(t->mu);
+    auto* r = t->find_locked(job, task);
+    if (!r) return fail(std::string("no such task: ") + job + ":" + task);
+    out->state = r->state;
+    out->retries = r->retries;
+    out->max_retries = r->max_retries;
+    snprintf(out->error, sizeof out->error, "%s", r->error.c_str());
+    snprintf(out->output, sizeof out->output, "%s", r->output.c_str());
+    return nullptr;
+}
+size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state) {
+    if (!t) return 0;
+    std::lock_guard<std::mutex> g(t->mu);
+    size_t n = 0;
+    for (auto& r : t->rows) n += r.state == state;
+    return n;
+}
+
+// ---- wire ----
+void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]) {
+    put_le(out, index, 8);
+    put_le(out + 8, po2, 4);
+    put_le(out + 12, seed, 8);
+}
+const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed) {
+    if (!blob || len != BX_SEGMENT_WIRE_BYTES) return "Failed to deserialize segment data from redis";
+    if (index) *index = get_le(blob, 8);
+    if (po2) *po2 = (uint32_t)get_le(blob + 8, 4);
+    if (seed) *seed = get_le(blob + 12, 8);
+    return nullptr;
+}
+
+// ---- agent ----
+const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* store, const bx_taskdb_ops* taskdb,
+                            const bx_segment_prover_ops* prover, bx_agent** out) {
+    if (!cfg || !store || !taskdb || !out) return "bx_agent_create: NULL argument";
+    if (!store->get || !store->set_ex || !store->unlink) return "bx_agent_create: hot store ops incomplete";
+    if (!taskdb->request_work || !taskdb->update_task_done || !taskdb->update_task_failed || !taskdb->update_task_retry ||
+        !taskdb->current_retries)
+        return "bx_agent_create: task db ops incomplete";
+    if (prover && (!prover->prove_segment || !prover->seal_words)) return "bx_agent_create: prover ops incomplete";
+    auto* a = new (std::nothrow) bx_agent();
+    if (!a) return "bx_agent_create: out of memory";
+    a->cfg = *cfg;
+    a->cfg.task_stream[sizeof a->cfg.task_stream - 1] = 0;
+    if (!a->cfg.task_stream[0]) snprintf(a->cfg.task_stream, sizeof a->cfg.task_stream, "prove");
+    if (a->cfg.inflight == 0) a->cfg.inflight = 3;
+    if (a->cfg.inflight > 16) {
+        delete a;
+        return "bx_agent_create: inflight must be <= 16";
+    }
+    if (!a->cfg.w_code) a->cfg.w_code = 16;
+    if (!a->cfg.w_data) a->cfg.w_data = 256;
+    if (!a->cfg.w_accum) a->cfg.w_accum = 64;
+    if (!a->cfg.redis_ttl) a->cfg.redis_ttl = 8 * 60 * 60;
+    if (!(a->cfg.poll_time > 0)) a->cfg.poll_time = 1.0;
+    a->store = *store;
+    a->taskdb = *taskdb;
+    a->lanes.resize(a->cfg.inflight);
+    if (prover) {
+        a->prover = *prover;
+    } else {
+        a->hip = true;
+        a->prover = bx_segment_prover_ops{a, bx_agent::hip_seal_words, bx_agent::hip_prove};
+        // like Agent::new (lib.rs:241-252) the device context is created up front so a missing GPU fails here, loudly
+        if (const char* e = bx_init(a->cfg.device, &a->lanes[0].ctx)) {
+            std::string m = std::string("bx_agent_create: ") + e;
+            delete a;
+            return fail(m);
+        }
+    }
+    *out = a;
+    return nullptr;
+}
+
+const char* bx_agent_destroy(bx_agent* a) {
+    if (!a) return nullptr;
+    const char* first = nullptr;
+    for (auto& lane : a->lanes) {
+        for (auto& kv : lane.provers)
+            if (const char* e = bx_prover_destroy(kv.second))
+                if (!first) first = fail(e);
+        if (lane.ctx)
+            if (const char* e = bx_free(lane.ctx))
+                if (!first) first = fail(e);
+    }
+    delete a;
+    return first;
+}
+
+void bx_agent_stop(bx_agent* a) {
+    if (a) a->stop.store(1, std::memory_order_relaxed);
+}
+
+const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* tasks_done) {
+    if (!a) return "bx_agent_poll_work: NULL agent";
+    std::atomic<uint64_t> done{0};
+    std::vector<std::string> fatal(a->lanes.size());
+    std::vector<std::thread> threads;
+    try {
+        for (uint32_t l = 1; l < a->lanes.size(); ++l)
+            threads.emplace_back([a, l, max_idle_polls, &done, &fatal] { a->lane_loop(l, max_idle_polls, &done, &fatal[l]); });
+    } catch (...) {
+        a->stop.store(1);
+        for (auto& t : threads) t.join();
+        return "bx_agent_poll_work: could not start lane threads";
+    }
+    a->lane_loop(0, max_idle_polls, &done, &fatal[0]);
+    for (auto& t : threads) t.join();
+    if (tasks_done) *tasks_done = done.load();
+    for (auto& f : fatal)
+        if (!f.empty()) return fail(f);
+    return nullptr;
+}
+
+const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok) {
+    if (!a || !task) return "bx_agent_process_one: NULL argument";
+    Pending p;
+    bool fatal = false;
+    std::string err = a->dispatch(0, *task, &p);
+    if (err.empty()) err = a->complete(&p, &fatal);
+    if (ok) *ok = err.empty();
+    if (err.empty()) return nullptr;
+    if (fatal) return fail(err);
+    std::string f = a->handle_failure(*task, err);
+    return f.empty() ? nullptr : fail(f);
+}
+
+size_t bx_agent_metrics(bx_agent* a, char* out, size_t cap) {
+    if (!a) return 0;
+    std::string s = a->metrics.exposition();
+    if (out && cap) snprintf(out, cap, "%s", s.c_str());
+    return s.size() + 1;
+}
+
+}  // extern "C"

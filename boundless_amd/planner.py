@@ -1,30 +1,35 @@
-"""Join-tree planner: which segment proofs get joined with which, as segments stream out of the executor.
+"""Join-tree planner — ctypes binding of the native planner (boundless_amd/csrc/planner.cpp, include/bx_agent.h).
 
-Behavioural restatement of `taskdb::planner::Planner` (bento/crates/taskdb/src/planner/mod.rs:20-252, tasks
-planner/task.rs:8-81), the component that turns "segment i is ready" events into Prove/Join/Finalize tasks for the queue
-the prove agents pull from.  The shape is a binary counter over "peaks": a new leaf merges with
-the smallest peak while their heights are equal, `finish` folds the remaining peaks from the smallest upwards and appends
-the Finalize task.  Keccak leaves form a second, independent forest of Union nodes that Finalize also depends on.
-Task numbers, heights and dependency lists match the reference's unit tests (mod.rs:254-453) one for one.
+Mirrors `taskdb::planner::Planner` (bento/crates/taskdb/src/planner/mod.rs:20-252): method names, return values and error
+text are the reference's, so tests/test_planner_agent_cpu.py restates its unit tests (mod.rs:254-453) one for one.
+All logic is in C++; this file only marshals.
 """
+import ctypes as C
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import List
+
+from .hal import load_library
 
 SEGMENT, KECCAK, JOIN, UNION, FINALIZE = "Segment", "Keccak", "Join", "Union", "Finalize"
+_COMMANDS = (SEGMENT, KECCAK, JOIN, UNION, FINALIZE)
 
 
 class PlannerError(Exception):
     pass
 
 
-class PlanNotStarted(PlannerError):
-    def __init__(self):
-        super().__init__("Planning not yet started")  # PlannerErr::PlanNotStartedString
+class PlanNotStarted(PlannerError):  # PlannerErr::PlanNotStartedString
+    pass
 
 
-class PlanFinalized(PlannerError):
-    def __init__(self):
-        super().__init__("Cannot add segment to finished plan")  # PlannerErr::PlanFinalized
+class PlanFinalized(PlannerError):  # PlannerErr::PlanFinalized
+    pass
+
+
+class _PlanTask(C.Structure):
+    _fields_ = [("task_number", C.c_uint64), ("task_height", C.c_uint32), ("command", C.c_uint32),
+                ("n_depends_on", C.c_uint32), ("n_keccak_depends_on", C.c_uint32),
+                ("depends_on", C.c_uint64 * 2), ("keccak_depends_on", C.c_uint64 * 2)]
 
 
 @dataclass
@@ -36,80 +41,92 @@ class Task:
     keccak_depends_on: List[int] = field(default_factory=list)
 
 
+def _declare(lib):
+    if getattr(lib, "_bx_planner_declared", False):
+        return
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    for name, args in {
+        "bx_planner_create": [C.POINTER(C.c_void_p)],
+        "bx_planner_enqueue_segment": [vp, u64p],
+        "bx_planner_enqueue_keccak": [vp, u64p],
+        "bx_planner_finish": [vp, u64p],
+        "bx_planner_next_task": [vp, C.POINTER(_PlanTask), C.POINTER(C.c_int)],
+        "bx_planner_get_task": [vp, C.c_uint64, C.POINTER(_PlanTask)],
+    }.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p
+    lib.bx_planner_destroy.argtypes = [vp]
+    lib.bx_planner_destroy.restype = None
+    lib.bx_planner_task_count.argtypes = [vp]
+    lib.bx_planner_task_count.restype = C.c_size_t
+    lib._bx_planner_declared = True
+
+
+def _raise(msg):
+    text = msg.decode()
+    if text == "Planning not yet started":
+        raise PlanNotStarted(text)
+    if text == "Cannot add segment to finished plan":
+        raise PlanFinalized(text)
+    raise PlannerError(text)
+
+
+def _export(t):
+    return Task(t.task_number, t.task_height, _COMMANDS[t.command], list(t.depends_on[: t.n_depends_on]),
+                list(t.keccak_depends_on[: t.n_keccak_depends_on]))
+
+
 class Planner:
     def __init__(self):
-        self.tasks: List[Task] = []
-        self._peaks: List[int] = []         # Segment/Join roots nobody depends on yet, tallest first
-        self._keccak_peaks: List[int] = []  # same for Keccak/Union
-        self._cursor = 0
-        self._last: Optional[int] = None
+        self._lib = load_library()
+        _declare(self._lib)
+        h = C.c_void_p()
+        msg = self._lib.bx_planner_create(C.byref(h))
+        if msg:
+            _raise(msg)
+        self._h = h
 
-    # -- building -----------------------------------------------------------------------------------------------
-    def _push(self, command, height=0, deps=(), kdeps=()):
-        t = Task(len(self.tasks), height, command, list(deps), list(kdeps))
-        self.tasks.append(t)
-        return t.task_number
-
-    def _merge(self, forest, leaf, node_command):
-        """binary-counter carry: absorb equal-height peaks, smallest first"""
-        top = leaf
-        while forest and self.tasks[forest[-1]].task_height == self.tasks[top].task_height:
-            left = forest.pop()
-            height = 1 + max(self.tasks[left].task_height, self.tasks[top].task_height)
-            if node_command == JOIN:
-                top = self._push(JOIN, height, deps=(left, top))
-            else:
-                top = self._push(UNION, height, kdeps=(left, top))
-        forest.append(top)
+    def _call(self, fn):
+        n = C.c_uint64()
+        msg = fn(self._h, C.byref(n))
+        if msg:
+            _raise(msg)
+        return n.value
 
     def enqueue_segment(self):
-        if self._last is not None:
-            raise PlanFinalized()
-        n = self._push(SEGMENT)
-        self._merge(self._peaks, n, JOIN)
-        return n
+        return self._call(self._lib.bx_planner_enqueue_segment)
 
     def enqueue_keccak(self):
-        if self._last is not None:
-            raise PlanFinalized()
-        n = self._push(KECCAK)
-        self._merge(self._keccak_peaks, n, UNION)
-        return n
+        return self._call(self._lib.bx_planner_enqueue_keccak)
 
     def finish(self):
-        if not self._peaks:
-            raise PlanNotStarted()
-        # unions: fold from the tallest pair downwards (the reference pops from the front of its deque)
-        kdeps = []
-        if self._keccak_peaks:
-            while len(self._keccak_peaks) >= 2:
-                p0, p1 = self._keccak_peaks.pop(0), self._keccak_peaks.pop(0)
-                h = 1 + max(self.tasks[p0].task_height, self.tasks[p1].task_height)
-                self._keccak_peaks.insert(0, self._push(UNION, h, kdeps=(p1, p0)))
-            kdeps = [self._keccak_peaks[0]]
-        if self._last is None:
-            while len(self._peaks) >= 2:  # joins: fold from the smallest pair upwards
-                p0, p1 = self._peaks.pop(), self._peaks.pop()
-                h = 1 + max(self.tasks[p0].task_height, self.tasks[p1].task_height)
-                self._peaks.append(self._push(JOIN, h, deps=(p1, p0)))
-            height = 1 + self.tasks[self._peaks[0]].task_height
-            if kdeps:
-                height = max(height, 1 + self.tasks[max(kdeps)].task_height)
-            self._last = self._push(FINALIZE, height, deps=(self._peaks[0],), kdeps=kdeps)
-        return self._last
+        return self._call(self._lib.bx_planner_finish)
 
-    # -- consuming ----------------------------------------------------------------------------------------------
     def task_count(self):
-        return len(self.tasks)
+        return self._lib.bx_planner_task_count(self._h)
 
     def get_task(self, task_number):
-        if not 0 <= task_number < len(self.tasks):
-            raise IndexError(f"Invalid task number {task_number}")
-        return self.tasks[task_number]
+        t = _PlanTask()
+        if self._lib.bx_planner_get_task(self._h, task_number, C.byref(t)):
+            raise IndexError(f"Invalid task number {task_number}")  # the reference panics with this text
+        return _export(t)
 
     def next_task(self):
-        if self._cursor < len(self.tasks):
-            t = self.tasks[self._cursor]
-            self._cursor += 1
-            return t
-        return None
+        t, has = _PlanTask(), C.c_int()
+        msg = self._lib.bx_planner_next_task(self._h, C.byref(t), C.byref(has))
+        if msg:
+            _raise(msg)
+        return _export(t) if has.value else None
+
+    @property
+    def tasks(self):
+        return [self.get_task(i) for i in range(self.task_count())]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.bx_planner_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,172 @@
+/*
+ * bx_agent.h — C ABI of the native (C++) host runtime around the segment prover: the prove-stream feed loop and the
+ * join-tree planner.  Host code only; lives in the same libbx_hip_hal.so.
+ *
+ * Reference interfaces restated here
+ * ----------------------------------
+ *   Agent::poll_work              bento/crates/workflow/src/lib.rs:279-442   claim -> run -> done | retry | failed
+ *   Agent::process_work           bento/crates/workflow/src/lib.rs:445-530   TaskType dispatch ("Invalid task_def", WF-115)
+ *   tasks::prove::prover          bento/crates/workflow/src/tasks/prove.rs:18-135
+ *   key scheme                    bento/crates/workflow/src/tasks/mod.rs:23-29 (job:{id}:segments:{i}, ...:recursion_receipts:{task})
+ *   hot-store calls               bento/crates/workflow/src/redis.rs:19-63   (GET / SETEX / UNLINK + redis_operations metrics)
+ *   task db calls                 bento/crates/taskdb/src/lib.rs:236-326     request_work / update_task_done|failed|retry
+ *                                 bento/crates/taskdb/migrations/1_taskdb.sql:308-391 (state transitions those functions make)
+ *   metrics                       bento/crates/workflow-common/src/metrics.rs:61-70,108-117,288-335
+ *   Planner                       bento/crates/taskdb/src/planner/mod.rs:20-252, planner/task.rs:8-81
+ *
+ * The reference's Redis and Postgres clients are control plane and out of scope: they enter only as two
+ * small tables of callbacks (`bx_hot_store_ops`, `bx_taskdb_ops`) a deployment fills with its own clients.  The library
+ * ships in-memory implementations of both for tests, the bench's queue mode and single-box runs.
+ *
+ * The agent owns the device context(s) for the process lifetime, like `Agent.prover` (lib.rs:192,241-252).  Unlike the
+ * reference (one task in flight per process, several agent processes per GPU to overlap), one bx_agent runs
+ * `inflight` prover lanes on its GPU — each lane a host thread with its own bx_ctx/stream/prover claiming tasks
+ * independently — because the segment prover is VALU-issue-bound with latency-bound tails and 3 lanes fill the chip
+ * (DESIGN.md §5).  Every callback may therefore be invoked from several threads at once and must be thread-safe.
+ *
+ * Conventions as in bx_hal.h: every call returns NULL on success or a message owned by the object it was called on
+ * (valid until the next call on that object from the same thread); nothing aborts, no exception crosses the ABI.
+ */
+#ifndef BX_AGENT_H
+#define BX_AGENT_H
+#include "bx_prover.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------ planner ---- */
+typedef struct bx_planner bx_planner;
+enum bx_plan_command { BX_PLAN_SEGMENT = 0, BX_PLAN_KECCAK = 1, BX_PLAN_JOIN = 2, BX_PLAN_UNION = 3, BX_PLAN_FINALIZE = 4 };
+typedef struct bx_plan_task { /* planner/task.rs:8-26 */
+    uint64_t task_number;
+    uint32_t task_height;
+    uint32_t command; /* enum bx_plan_command */
+    uint32_t n_depends_on;
+    uint32_t n_keccak_depends_on;
+    uint64_t depends_on[2];
+    uint64_t keccak_depends_on[2];
+} bx_plan_task;
+
+const char* bx_planner_create(bx_planner** out);
+void bx_planner_destroy(bx_planner* p);
+/* Planner::enqueue_segment / enqueue_keccak: errors "Cannot add segment to finished plan" after finish(). */
+const char* bx_planner_enqueue_segment(bx_planner* p, uint64_t* task_number);
+const char* bx_planner_enqueue_keccak(bx_planner* p, uint64_t* task_number);
+/* Planner::finish: error "Planning not yet started" when no segment was enqueued; idempotent afterwards. */
+const char* bx_planner_finish(bx_planner* p, uint64_t* task_number);
+/* Planner::next_task: *has = 0 when every planned task has been handed out. */
+const char* bx_planner_next_task(bx_planner* p, bx_plan_task* out, int* has);
+size_t bx_planner_task_count(const bx_planner* p);
+const char* bx_planner_get_task(bx_planner* p, uint64_t task_number, bx_plan_task* out);
+
+/* ------------------------------------------------------------------------------------- stores (callbacks) ---- */
+/* Hot store = the three Redis operations the prove task issues.  Return 0 = ok, 1 = key not found (get only),
+ * negative = transport error; on error `errbuf` (cap bytes) may be filled with a message. */
+typedef struct bx_hot_store_ops {
+    void* user;
+    int (*get)(void* user, const char* key, uint8_t** value, size_t* len, char* errbuf, size_t cap);
+    void (*free_value)(void* user, uint8_t* value);
+    int (*set_ex)(void* user, const char* key, const uint8_t* value, size_t len, uint64_t ttl_secs /* 0 = no expiry */,
+                  char* errbuf, size_t cap);
+    int (*unlink)(void* user, const char* key, char* errbuf, size_t cap);
+} bx_hot_store_ops;
+
+typedef struct bx_ready_task { /* taskdb::ReadyTask, bento/crates/taskdb/src/lib.rs:58-64 */
+    char job_id[40];            /* uuid text */
+    char task_id[128];
+    char task_def[1024];        /* JSON TaskType, e.g. {"Prove":{"index":3}} */
+    int32_t max_retries;
+} bx_ready_task;
+
+/* Task db = the calls poll_work makes.  request_work: 1 = task claimed (now 'running'), 0 = none ready, <0 error.
+ * current_retries: 1 = found a running row and wrote *retries, 0 = no such running row, <0 error.
+ * update_*: 1 = row updated, 0 = not found / not in a state the update applies to, <0 error. */
+typedef struct bx_taskdb_ops {
+    void* user;
+    int (*request_work)(void* user, const char* task_stream, bx_ready_task* out, char* errbuf, size_t cap);
+    int (*update_task_done)(void* user, const char* job_id, const char* task_id, const char* output_json, char* errbuf,
+                            size_t cap);
+    int (*update_task_failed)(void* user, const char* job_id, const char* task_id, const char* error, char* errbuf,
+                              size_t cap);
+    int (*update_task_retry)(void* user, const char* job_id, const char* task_id, char* errbuf, size_t cap);
+    int (*current_retries)(void* user, const char* job_id, const char* task_id, int32_t* retries, char* errbuf,
+                           size_t cap);
+} bx_taskdb_ops;
+
+/* In-memory implementations (thread-safe). The returned ops borrow the object; destroy it after the agent. */
+typedef struct bx_mem_store bx_mem_store;
+const char* bx_mem_store_create(bx_mem_store** out);
+void bx_mem_store_destroy(bx_mem_store* s);
+bx_hot_store_ops bx_mem_store_ops(bx_mem_store* s);
+size_t bx_mem_store_key_count(bx_mem_store* s);
+/* Writes the sorted keys separated by '\n' (NUL-terminated, truncated to cap). */
+const char* bx_mem_store_keys(bx_mem_store* s, char* out, size_t cap);
+
+typedef struct bx_mem_taskdb bx_mem_taskdb;
+enum bx_task_state { BX_TASK_READY = 0, BX_TASK_RUNNING = 1, BX_TASK_DONE = 2, BX_TASK_FAILED = 3 };
+typedef struct bx_task_info {
+    int32_t state; /* enum bx_task_state */
+    int32_t retries;
+    int32_t max_retries;
+    char error[1100];
+    char output[256];
+} bx_task_info;
+const char* bx_mem_taskdb_create(bx_mem_taskdb** out);
+void bx_mem_taskdb_destroy(bx_mem_taskdb* t);
+bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t);
+/* taskdb::create_task for a task with no prerequisites (it is 'ready' at once). */
+const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
+                                      const char* task_def_json, int32_t max_retries);
+const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const char* task_id, bx_task_info* out);
+size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
+
+/* ---------------------------------------------------------------------------------- segment / receipt wire ---- */
+/* Stand-ins for bincode(risc0_zkvm::Segment) / bincode(receipt) (tasks/mod.rs:40-47), which need risc0's type layouts:
+ *   segment  = index u64 | po2 u32 | seed u64                      (20 bytes, little endian)
+ *   receipt  = index u64 | po2 u32 | seal_words u32 | seal u32[]   (16 + 4*n bytes, little endian) */
+#define BX_SEGMENT_WIRE_BYTES 20
+#define BX_RECEIPT_HEADER_BYTES 16
+void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]);
+/* error: "Failed to deserialize segment data from redis" */
+const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed);
+
+/* ------------------------------------------------------------------------------------------------- agent ---- */
+/* The prover a lane calls.  NULL ops in bx_agent_create = the HIP prover (bx_prove_segment on the lane's own ctx).
+ * A custom table lets tests inject failures without a GPU.  prove returns NULL or an error message. */
+typedef struct bx_segment_prover_ops {
+    void* user;
+    size_t (*seal_words)(void* user, uint32_t lane, uint32_t po2); /* seal capacity in words, 0 = unsupported shape */
+    const char* (*prove_segment)(void* user, uint32_t lane, uint64_t index, uint32_t po2, uint64_t seed, uint32_t* seal_out,
+                                 size_t seal_cap, size_t* seal_words);
+} bx_segment_prover_ops;
+
+typedef struct bx_agent_config {
+    int32_t device;          /* HIP device ordinal (after HIP_VISIBLE_DEVICES), ignored with custom prover ops */
+    uint32_t inflight;       /* prover lanes on this GPU; 0 = default (3) */
+    uint32_t w_code, w_data, w_accum; /* synthetic segment group widths; 0 = BASELINE config (16/256/64) */
+    uint64_t redis_ttl;      /* seconds; 0 = 8 h (the reference's default `redis_ttl`) */
+    double poll_time;        /* idle sleep between empty claims, seconds; <= 0 = 1 s (`poll_time`) */
+    int32_t verify;          /* verify each seal before storing it (prove.rs:53-55); default on = 1 */
+    char task_stream[64];    /* worker type passed to request_work; "" = "prove" */
+} bx_agent_config;
+
+typedef struct bx_agent bx_agent;
+const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* store, const bx_taskdb_ops* taskdb,
+                            const bx_segment_prover_ops* prover /* NULL = HIP */, bx_agent** out);
+const char* bx_agent_destroy(bx_agent* a);
+/* Agent::poll_work: runs the lanes until bx_agent_stop, or until every lane has seen `max_idle_polls` consecutive empty
+ * claims (max_idle_polls < 0 = run until stopped).  Blocks.  Task failures are reported to the task db and never end
+ * the loop; a failing task-db call does (the reference `?`-returns there: WF-107, WF-109..112, WF-133). */
+const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* tasks_done);
+/* The SIGTERM flag of create_sig_monitor (lib.rs:266-270): async-signal-safe, may be called from a signal handler. */
+void bx_agent_stop(bx_agent* a);
+/* Run one already-claimed task on lane 0 (process_work + the error bookkeeping of poll_work). *ok = 1 when it succeeded. */
+const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok);
+/* Prometheus text exposition of task_operations_total, task_duration_seconds, redis_operations_total and
+ * redis_operation_duration_seconds with the reference's labels and buckets; returns the needed size. */
+size_t bx_agent_metrics(bx_agent* a, char* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

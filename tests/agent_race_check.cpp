@@ -1,0 +1,84 @@
+// Race / leak check of the native feed loop (boundless_amd/csrc/agent.cpp): built by tests/test_agent_sanitizers_cpu.py with
+// -fsanitize=thread (and again with address,undefined) from agent.cpp + planner.cpp + this file, no GPU and no HIP runtime.
+// 6 lanes x 2 threads each hammer the in-memory hot store / task db with a prover that fails at random; every task must end
+// `done` exactly once or `failed` after its retries, and the sanitizer must stay silent.
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "bx_agent.h"
+
+// Link stubs for the device entry points the default (HIP) prover ops reference; this test injects its own prover ops, so
+// none of them is ever called.
+extern "C" {
+const char* bx_init(int, bx_ctx**) { return "stub"; }
+const char* bx_free(bx_ctx*) { return "stub"; }
+const char* bx_prover_create(bx_ctx*, const bx_segment_params*, bx_prover**) { return "stub"; }
+const char* bx_prover_destroy(bx_prover*) { return "stub"; }
+size_t bx_prover_seal_words(const bx_prover*) { return 0; }
+const char* bx_prove_segment(bx_prover*, uint64_t, uint32_t*, size_t, size_t*) { return "stub"; }
+const char* bx_verify_segment(const uint32_t* seal, size_t words) { return (words == 64 && seal[0] == 7u) ? nullptr : "bad seal"; }
+}
+
+static std::atomic<uint64_t> g_calls{0};
+static size_t seal_words(void*, uint32_t, uint32_t) { return 64; }
+static const char* prove(void*, uint32_t lane, uint64_t index, uint32_t, uint64_t seed, uint32_t* seal, size_t cap, size_t* words) {
+    uint64_t n = g_calls.fetch_add(1);
+    if (cap < 64) return "cap";
+    if ((n * 2654435761u >> 7) % 5 == 0) return "hipErrorLaunchFailure (injected)";
+    for (uint32_t i = 0; i < 64; ++i) seal[i] = (uint32_t)(seed + index + i + lane * 0);
+    seal[0] = ((n >> 3) % 7 == 0) ? 9u : 7u;  // some seals fail verification -> retried from the finisher thread
+    *words = 64;
+    return nullptr;
+}
+
+int main() {
+    bx_mem_store* store = nullptr;
+    bx_mem_taskdb* db = nullptr;
+    if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;
+    bx_hot_store_ops sops = bx_mem_store_ops(store);
+    bx_taskdb_ops tops = bx_mem_taskdb_ops(db);
+    const int N = 600;
+    for (int i = 0; i < N; ++i) {
+        uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+        bx_segment_encode((uint64_t)i, 10, 1000 + (uint64_t)i, wire);
+        std::string key = "job:race:segments:" + std::to_string(i), task = "p" + std::to_string(i);
+        std::string def = "{\"Prove\":{\"index\":" + std::to_string(i) + "}}";
+        if (i % 97 != 13 && sops.set_ex(sops.user, key.c_str(), wire, sizeof wire, 0, nullptr, 0) != 0) return 1;  // a few blobs are missing
+        if (bx_mem_taskdb_create_task(db, "prove", "race", task.c_str(), def.c_str(), 4)) return 1;
+    }
+    bx_agent_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.inflight = 6;
+    cfg.poll_time = 0.001;
+    cfg.verify = 1;
+    bx_segment_prover_ops pops{nullptr, seal_words, prove};
+    bx_agent* agent = nullptr;
+    if (const char* e = bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) {
+        fprintf(stderr, "create: %s\n", e);
+        return 1;
+    }
+    uint64_t done = 0;
+    if (const char* e = bx_agent_poll_work(agent, 3, &done)) {
+        fprintf(stderr, "poll: %s\n", e);
+        return 1;
+    }
+    size_t n_done = bx_mem_taskdb_count(db, BX_TASK_DONE), n_failed = bx_mem_taskdb_count(db, BX_TASK_FAILED);
+    size_t n_other = bx_mem_taskdb_count(db, BX_TASK_READY) + bx_mem_taskdb_count(db, BX_TASK_RUNNING);
+    char metrics[1 << 15];
+    bx_agent_metrics(agent, metrics, sizeof metrics);
+    if (bx_agent_destroy(agent)) return 1;
+    // every stored receipt has its segment unlinked; failed tasks keep (or never had) their segment blob
+    size_t keys = bx_mem_store_key_count(store);
+    bx_mem_taskdb_destroy(db);
+    bx_mem_store_destroy(store);
+    if (done != n_done || n_done + n_failed != (size_t)N || n_other != 0 || n_done < 500 || n_failed < 6) {
+        fprintf(stderr, "done=%llu n_done=%zu n_failed=%zu other=%zu keys=%zu\n", (unsigned long long)done, n_done, n_failed, n_other, keys);
+        return 1;
+    }
+    if (!strstr(metrics, "task_operations_total{task_name=\"prove\",operation_type=\"complete\",status=\"success\"}")) return 1;
+    printf("agent_race_check ok: done %zu failed %zu prove calls %llu keys %zu\n", n_done, n_failed,
+           (unsigned long long)g_calls.load(), keys);
+    return 0;
+}

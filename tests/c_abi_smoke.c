@@ -7,6 +7,7 @@
 
 #include "bx_hal.h"
 #include "bx_prover.h"
+#include "bx_agent.h"
 
 #define CHECK(expr)                                              \
     do {                                                         \
@@ -58,6 +59,40 @@ int main(void) {
     }
     CHECK(bx_prover_destroy(prover));
     CHECK(bx_free(ctx));
+    /* the native prove agent: 4 segments through the in-memory hot store / task db, 2 prover lanes */
+    bx_mem_store* store = NULL;
+    bx_mem_taskdb* db = NULL;
+    CHECK(bx_mem_store_create(&store));
+    CHECK(bx_mem_taskdb_create(&db));
+    bx_hot_store_ops sops = bx_mem_store_ops(store);
+    bx_taskdb_ops tops = bx_mem_taskdb_ops(db);
+    for (int i = 0; i < 4; ++i) {
+        uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+        char key[64], task[32], def[64];
+        bx_segment_encode((uint64_t)i, 10, 0xB0D1E550000ull + (uint64_t)i, wire);
+        snprintf(key, sizeof key, "job:c-smoke:segments:%d", i);
+        snprintf(task, sizeof task, "prove-%d", i);
+        snprintf(def, sizeof def, "{\"Prove\":{\"index\":%d}}", i);
+        if (sops.set_ex(sops.user, key, wire, sizeof wire, 600, NULL, 0) != 0) return 1;
+        CHECK(bx_mem_taskdb_create_task(db, "prove", "c-smoke", task, def, 3));
+    }
+    bx_agent_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.inflight = 2;
+    cfg.w_code = 4, cfg.w_data = 8, cfg.w_accum = 4;
+    cfg.poll_time = 0.01;
+    cfg.verify = 1;
+    bx_agent* agent = NULL;
+    CHECK(bx_agent_create(&cfg, &sops, &tops, NULL, &agent));
+    uint64_t done = 0;
+    CHECK(bx_agent_poll_work(agent, 2, &done));
+    if (done != 4 || bx_mem_taskdb_count(db, BX_TASK_DONE) != 4 || bx_mem_store_key_count(store) != 4) {
+        fprintf(stderr, "agent: done=%llu\n", (unsigned long long)done);
+        return 1;
+    }
+    CHECK(bx_agent_destroy(agent));
+    bx_mem_taskdb_destroy(db);
+    bx_mem_store_destroy(store);
     printf("c_abi_smoke ok: seal words %zu\n", n);
     free(host);
     free(back);

@@ -68,3 +68,20 @@ def test_headers_are_valid_c99():
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", f"-I{os.path.join(ROOT, 'include')}", src],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", f"-I{os.path.join(ROOT, 'include')}",
+                        "-x", "c", "-"], input='#include "bx_agent.h"\nint main(void){bx_agent_config c; (void)c; return 0;}\n',
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_native_agent_fails_loudly_without_gpu(libpath):
+    """The agent's default prover is the HIP one; with no GPU it must refuse to start (no CPU fallback)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from boundless_amd import agent as ag
+    from boundless_amd.hal import HalError
+
+    with pytest.raises(HalError, match="bx_agent_create"):
+        ag.Agent(prover=None)

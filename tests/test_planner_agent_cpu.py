@@ -1,4 +1,4 @@
-"""CPU: planner known-answer tests restated from the reference's unit tests, and the prove-agent feed loop."""
+"""CPU: planner known-answer tests restated from the reference's unit tests, and the native prove-agent feed loop."""
 import json
 
 import numpy as np
@@ -100,79 +100,163 @@ def test_join_tree_is_log_depth_for_64_segments():
 
 
 # ---------------------------------------------------------------------------------------------------------- agent
+# The feed loop is native code (boundless_amd/csrc/agent.cpp); a Python prover is injected through the prover-ops callbacks so
+# the control flow can be exercised without a GPU.
 class FakeProver:
-    def __init__(self, fail_times=0, bad_seal=False):
+    def __init__(self, fail_times=0):
         self.calls = 0
         self.fail_times = fail_times
-        self.bad_seal = bad_seal
 
     def prove_segment(self, seg):
         self.calls += 1
         if self.calls <= self.fail_times:
             raise RuntimeError("hipErrorLaunchFailure (injected)")
-        r = SegmentReceipt(seal=np.arange(10, dtype=np.uint32) + seg.seed % 7, index=seg.index, po2=seg.po2)
-        if not self.bad_seal:
-            r.verify_integrity = lambda: None
-        return r
+        return SegmentReceipt(seal=np.arange(10, dtype=np.uint32) + seg.seed % 7, index=seg.index, po2=seg.po2)
 
 
-def test_task_json_and_keys_roundtrip():
-    assert ag.parse_task('{"Prove":{"index":7}}') == ("prove", ag.ProveReq(7))
-    assert ag.job_type_str("prove") == "prove-lift"
-    with pytest.raises(ValueError):
-        ag.parse_task('{"Join":{"idx":1,"left":2,"right":3}}')
+def test_task_json_and_wire_roundtrip():
     seg = Segment.synthetic(5, po2=20)
-    assert ag.deserialize_segment(ag.serialize_segment(seg)) == seg
-    r = SegmentReceipt(seal=np.arange(33, dtype=np.uint32), index=5, po2=20)
-    r2 = ag.deserialize_receipt(ag.serialize_receipt(r))
-    assert np.array_equal(r2.seal, r.seal) and (r2.index, r2.po2) == (5, 20)
+    blob = ag.serialize_segment(seg)
+    assert len(blob) == 20 and ag.deserialize_segment(blob) == seg
+    with pytest.raises(ValueError, match="Failed to deserialize segment data from redis"):
+        ag.deserialize_segment(blob[:-1])
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
+    # serde's externally tagged TaskType (workflow-common/src/lib.rs:160-178): anything but one known variant is invalid
+    for bad in ('{"Prove":{"idx":7}}', '{"Prove":{"index":-1}}', '{"Prove":{"index":1.5}}', '[]', '{"Prove":{"index":1},"x":{}}',
+                '{"Nope":{}}', '{"Prove":{"index":1}', ''):
+        a.taskdb.create_task("jj", f"t{bad}", {"Prove": {"index": 0}}, max_retries=0)
+        assert a.process_one("jj", f"t{bad}", bad, max_retries=0) is False
+        assert a.taskdb.task("jj", f"t{bad}").error == f"Invalid task_def: jj:t{bad}"  # lib.rs:446-447
+    assert a.taskdb.count("failed") == 8  # update_task_failed applies to ready rows too (1_taskdb.sql:324)
+    a.close()
 
 
 def test_prove_task_key_scheme_cleanup_and_metrics():
-    a = ag.Agent(prover=FakeProver(), poll_time=0.0)
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
     job = "0b1e55-job"
     a.store.set_key_with_expiry(f"job:{job}:segments:3", ag.serialize_segment(Segment.synthetic(3, po2=12)), 60)
-    ag.prove_task(a, job, "task-3", ag.ProveReq(index=3))
+    a.taskdb.create_task(job, "task-3", {"Prove": {"index": 3}})
+    assert a.poll_work(max_idle_polls=1) == 1
     assert a.store.keys() == [f"job:{job}:recursion_receipts:task-3"]  # receipt stored, segment unlinked
     rec = ag.deserialize_receipt(a.store.get(f"job:{job}:recursion_receipts:task-3"))
-    assert rec.index == 3 and rec.po2 == 12
-    assert a.metrics.ops[("prove", "prove_segment", "success")] == 2  # record_task_operation + record_task, like the reference
-    assert a.metrics.ops[("prove", "complete", "success")] == 1
-    text = a.metrics.exposition()
+    assert rec.index == 3 and rec.po2 == 12 and np.array_equal(rec.seal, np.arange(10, dtype=np.uint32) + Segment.synthetic(3).seed % 7)
+    row = a.taskdb.task(job, "task-3")
+    assert (row.state, row.retries, row.output) == ("done", 0, "null")
+    text = a.metrics_text()
+    # record_task_operation + record_task both count the prove (prove.rs:50-51,57)
+    assert 'task_operations_total{task_name="prove",operation_type="prove_segment",status="success"} 2' in text
     assert 'task_operations_total{task_name="prove",operation_type="complete",status="success"} 1' in text
     assert 'task_duration_seconds_bucket{task_name="prove",operation_type="prove_segment",status="success",le="0.1"} 2' in text
-    with pytest.raises(RuntimeError, match="segment data not found for segment key: job:x:segments:9"):
-        ag.prove_task(a, "x", "t", ag.ProveReq(index=9))
+    assert 'task_duration_seconds_bucket{task_name="prove",operation_type="complete",status="success",le="+Inf"} 1' in text
+    for op in ("get", "set_ex", "unlink"):
+        assert f'redis_operations_total{{operation_type="{op}",status="success"}} 1' in text
+    assert 'redis_operation_duration_seconds_bucket{operation_type="get",status="success",le="0.001"}' in text
+    a.close()
+
+
+def test_missing_segment_blob_error_chain_and_no_retries():
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
+    a.taskdb.create_task("x", "t", {"Prove": {"index": 9}}, max_retries=0)
+    assert a.poll_work(max_idle_polls=1) == 0
+    row = a.taskdb.task("x", "t")
+    assert row.state == "failed" and row.retries == 0
+    # anyhow `{:#}` chain: WF-115 context, prove.rs:30-33 context, redis.rs:51-55 nil error
+    assert row.error == ("[BENTO-WF-115] Prove failed: segment data not found for segment key: job:x:segments:9: "
+                         "Key not found (nil response): job:x:segments:9")
+    assert 'redis_operations_total{operation_type="get",status="error"} 1' in a.metrics_text()
+    a.close()
 
 
 def test_poll_loop_retries_then_succeeds_and_fails_after_max_retries():
-    a = ag.Agent(prover=FakeProver(fail_times=2), poll_time=0.0)
+    a = ag.Agent(prover=FakeProver(fail_times=2), verify=False, poll_time=0.01)
     a.store.set_key_with_expiry("job:j:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)))
-    a.stream.create_task("j", "t0", {"Prove": {"index": 0}}, max_retries=3)
-    assert ag.poll_work(a, max_idle_polls=1) == 1
-    row = a.stream.rows()[0]
-    assert row.state == "done" and row.retries == 2 and "injected" in row.error
-    # a task whose segment blob is missing exhausts its retries and is failed; the agent survives and serves the next task
-    a2 = ag.Agent(prover=FakeProver(), poll_time=0.0)
-    a2.stream.create_task("j", "missing", {"Prove": {"index": 5}}, max_retries=1)
+    a.taskdb.create_task("j", "t0", {"Prove": {"index": 0}}, max_retries=3)
+    assert a.poll_work(max_idle_polls=1) == 1
+    row = a.taskdb.rows()[0]
+    assert row.state == "done" and row.retries == 2
+    a.close()
+    # a task whose segment blob is missing exhausts its retries and is failed with "retry max hit: ..." (lib.rs:395-413);
+    # the agent survives and serves the next task
+    a2 = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
+    a2.taskdb.create_task("j", "missing", {"Prove": {"index": 5}}, max_retries=1)
     a2.store.set_key_with_expiry("job:j:segments:6", ag.serialize_segment(Segment.synthetic(6, po2=10)))
-    a2.stream.create_task("j", "ok", {"Prove": {"index": 6}})
-    assert ag.poll_work(a2, max_idle_polls=1) == 1
-    states = {r.task_id: (r.state, r.retries) for r in a2.stream.rows()}
+    a2.taskdb.create_task("j", "ok", {"Prove": {"index": 6}})
+    assert a2.poll_work(max_idle_polls=1) == 1
+    states = {r.task_id: (r.state, r.retries) for r in a2.taskdb.rows()}
     assert states == {"missing": ("failed", 1), "ok": ("done", 0)}
-    assert a2.metrics.ops[("prove", "complete", "failed")] == 1
+    err = a2.taskdb.task("j", "missing").error
+    assert err.startswith("retry max hit: [BENTO-WF-115] Prove failed: segment data not found for segment key: job:j:segments:5")
+    a2.close()
+
+
+def test_long_errors_are_truncated_before_reaching_the_db():
+    class Noisy:
+        def prove_segment(self, seg):
+            raise RuntimeError("x" * 5000)
+
+    a = ag.Agent(prover=Noisy(), verify=False, poll_time=0.01)
+    a.store.set_key_with_expiry("job:j:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)))
+    a.taskdb.create_task("j", "t", {"Prove": {"index": 0}}, max_retries=0)
+    assert a.poll_work(max_idle_polls=1) == 0
+    assert len(a.taskdb.task("j", "t").error) == 1024  # err_str.truncate(1024), lib.rs:424
+    a.close()
 
 
 def test_receipt_that_fails_verification_is_not_stored():
-    a = ag.Agent(prover=FakeProver(bad_seal=True), poll_time=0.0)
+    a = ag.Agent(prover=FakeProver(), verify=True, poll_time=0.01)  # arange(10) is not a seal the verifier accepts
     a.store.set_key_with_expiry("job:j:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)))
-    with pytest.raises(RuntimeError, match=r"\[BENTO-PROVE-004\]"):
-        ag.prove_task(a, "j", "t", ag.ProveReq(0))
-    assert a.store.keys() == ["job:j:segments:0"]  # nothing written, segment kept for the retry
+    a.taskdb.create_task("j", "t", {"Prove": {"index": 0}}, max_retries=0)
+    assert a.poll_work(max_idle_polls=1) == 0
+    assert "[BENTO-PROVE-004] Failed to verify segment receipt integrity" in a.taskdb.task("j", "t").error
+    assert a.store.keys() == ["job:j:segments:0"]  # nothing written, segment kept for a retry
+    a.close()
 
 
-def test_hot_store_expiry():
+def test_verification_failure_found_by_the_finisher_thread_is_retried_up_to_the_limit():
+    p = FakeProver()
+    a = ag.Agent(prover=p, verify=True, poll_time=0.01)
+    a.store.set_key_with_expiry("job:j:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)))
+    a.taskdb.create_task("j", "t", {"Prove": {"index": 0}}, max_retries=2)
+    assert a.poll_work(max_idle_polls=1) == 0
+    row = a.taskdb.task("j", "t")
+    assert (row.state, row.retries, p.calls) == ("failed", 2, 3)
+    assert row.error.startswith("retry max hit: [BENTO-WF-115] Prove failed: [BENTO-PROVE-004]")
+    a.close()
+
+
+def test_other_task_streams_are_left_alone_and_stop_flag_ends_the_loop():
+    import threading
+    import time
+
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.02)
+    a.taskdb.create_task("j", "join-1", {"Join": {"idx": 1, "left": 2, "right": 3}}, stream="join")
+    t0 = time.time()
+    th = threading.Thread(target=lambda: a.poll_work(max_idle_polls=None))
+    th.start()
+    time.sleep(0.2)
+    a.stop()  # the SIGTERM flag
+    th.join(timeout=5)
+    assert not th.is_alive() and time.time() - t0 < 5
+    assert a.taskdb.task("j", "join-1").state == "ready"
+    a.close()
+
+
+def test_hot_store_expiry_and_several_lanes():
+    import time
+
     s = ag.HotStore()
-    s.set_key_with_expiry("k", b"v", ttl_secs=-1)
+    s.set_key_with_expiry("k", b"v", ttl_secs=1)
+    assert s.get("k") == b"v"
+    time.sleep(1.1)
     with pytest.raises(KeyError):
         s.get("k")
+    # 4 lanes claim 32 tasks between them; every task is done exactly once
+    p = FakeProver()
+    a = ag.Agent(prover=p, verify=False, poll_time=0.01, inflight=4)
+    for i in range(32):
+        a.store.set_key_with_expiry(f"job:m:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=10)))
+        a.taskdb.create_task("m", f"p{i}", {"Prove": {"index": i}})
+    assert a.poll_work(max_idle_polls=2) == 32
+    assert a.taskdb.count("done") == 32 and p.calls == 32
+    assert a.store.keys() == sorted(f"job:m:recursion_receipts:p{i}" for i in range(32))
+    a.close()

@@ -75,27 +75,36 @@ def test_full_size_properties(po2):
 
 
 def test_agent_feed_loop_with_the_hip_prover():
-    """tasks/prove.rs flow end to end on the GPU: segment blob in the hot store -> prove -> verify -> receipt stored."""
+    """tasks/prove.rs flow end to end through the native agent (bx_agent_poll_work) with two prover lanes on the GPU:
+    segment blob in the hot store -> prove -> verify -> receipt stored -> segment unlinked -> task done."""
     from boundless_amd import agent as ag
-    from boundless_amd.prover import HipProverServer, Segment, verify_seal
+    from boundless_amd.prover import Segment, verify_seal
 
-    srv = HipProverServer(0, po2=12, widths=(4, 12, 4))
+    a = ag.Agent(prover=None, device=0, inflight=2, widths=(4, 12, 4), poll_time=0.01)
     try:
-        a = ag.Agent(prover=srv, poll_time=0.0)
-        for i in range(3):
+        n = 6
+        for i in range(n):
             a.store.set_key_with_expiry(f"job:J:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=12)), 600)
-            a.stream.create_task("J", f"prove-{i}", {"Prove": {"index": i}})
-        assert ag.poll_work(a, max_idle_polls=1) == 3
-        assert a.store.keys() == [f"job:J:recursion_receipts:prove-{i}" for i in range(3)]
-        for i in range(3):
+            a.taskdb.create_task("J", f"prove-{i}", {"Prove": {"index": i}})
+        assert a.poll_work(max_idle_polls=2) == n
+        assert a.store.keys() == [f"job:J:recursion_receipts:prove-{i}" for i in range(n)]
+        for i in range(n):
             rec = ag.deserialize_receipt(a.store.get(f"job:J:recursion_receipts:prove-{i}"))
-            assert rec.index == i
+            assert rec.index == i and rec.po2 == 12
             verify_seal(rec.seal)
             want, _ = ol.prove_segment(12, 4, 12, 4, Segment.synthetic(i, po2=12).seed)
             assert np.array_equal(rec.seal, want)
-        assert a.metrics.ops[("prove", "complete", "success")] == 3
+        assert a.taskdb.count("done") == n
+        assert f'task_operations_total{{task_name="prove",operation_type="complete",status="success"}} {n}' in a.metrics_text()
+        # a second segment size on the same agent allocates a second prover per lane, lazily
+        a.store.set_key_with_expiry("job:K:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)), 600)
+        a.taskdb.create_task("K", "p", {"Prove": {"index": 0}})
+        assert a.poll_work(max_idle_polls=2) == 1
+        rec = ag.deserialize_receipt(a.store.get("job:K:recursion_receipts:p"))
+        want, _ = ol.prove_segment(10, 4, 12, 4, Segment.synthetic(0, po2=10).seed)
+        assert np.array_equal(rec.seal, want)
     finally:
-        srv.close()
+        a.close()
 
 
 def test_plain_c_consumer_of_the_abi(tmp_path):
