@@ -35,10 +35,11 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 //
 // Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
 //   red64_lazy output                  < M1 + 18 + P                       < 1.13334 P          (M1 = 2^32 mod P)
-//   sbox7_bounded(x < 1.13334 P):  x2 = lazy(x,x) < 1.60209 P -> reduce -> x2r < P
+//   sbox7_wide(x < 1.13334 P):     x2 = lazy(x,x) < 1.60209 P -> reduce -> x2r < P
 //                                  x3 = lazy(x2r,x) < 1.53125 P,  x4 = lazy(x2r,x2r) < 1.46875 P
-//                                  x7 = lazy(x3,x4): product 2.24902 P^2 (ok), x7 < 2.05423 P < 2^32 -> one subtract -> < 1.05423 P
-//   m_ext64(cells < 1.05423 P):    32-bit pair sums < 2.10846 P < 2^32; rows sum to <= 16 so w < 16.87 P, y < 118.1 P < 2^38, y_hi < 56
+//                                  x7 = lazy(x3,x4): product 2.24902 P^2 (ok), x7 < 2.05423 P < 2^32, left as it is
+//                                  (sbox7_bounded, used for the single internal-round S-box, subtracts once: < 1.05423 P)
+//   m_ext64w(cells < 2.05423 P):   pair sums in 64 bits; rows sum to <= 16 so w < 32.87 P, y < 230.1 P < 2^39, y_hi < 108
 //   internal rounds:               cell i >= 1: lazy(d_i, s_i, sum_r) with s_i < B P gives < (rho B + 1) P: B grows from 1.13334
 //                                  towards the fixed point 1/(1 - rho) = 1.88235 and never passes it (< 2^32 / P = 2.1333);
 //                                  product B P^2 + 2P < 2.42 P^2;  sum < (1.06 + 23 * 1.8824) P < 2^37, sum_hi < 22;
@@ -47,8 +48,9 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 // Pinned v_mad_u64_u32 forms.  Left to itself hipcc rewrites "x*1 + acc" / "x*2 + acc" into v_lshl_add_u64 plus a v_mov
 // that zero-extends the 32-bit operand into a register pair — two instructions on the same issue port instead of one.
 // K is an inline constant; the 64-bit addend is a VGPR pair or the literal 0.  vcc receives the (unused) carry-out.
-// Only the internal-round sum uses them: pinning the external layer the same way raised VGPR pressure (150, 3 waves per
-// SIMD) and measured slower than the compiler's v_lshl_add_u64 form.
+// Only the internal-round sum uses them: pinning the external layer the same way removes ~35 instructions per round (the
+// v_mov pairs that zero-extend each cell) but measures no faster than the compiler's v_lshl_add_u64 form (3.83 vs 3.80 ms
+// for hash_rows at 2^22 x 64), so the external layer stays plain C shared with the host checker.
 template <int K>
 __device__ __forceinline__ uint64_t madk(uint32_t a, uint64_t acc) {
     uint64_t r;
@@ -62,6 +64,15 @@ __device__ __forceinline__ uint64_t madk0(uint32_t a) {
     return r;
 }
 
+// Loop-carried cells must stay 32-bit values.  Without this hipcc widens the 24 loop phis of the external rounds to i64
+// (every use is a zero-extension into a 64-bit multiply-add), loses track of the zero high words across the back edge and
+// emits full 64x32 / 64x64-bit products for the first two S-box multiplications: 5 extra instructions per cell and round
+// (~10 % of the permutation).  An empty asm with a 32-bit register constraint costs nothing and pins the width.
+__device__ __forceinline__ void pin32(uint32_t* s) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) asm("" : "+v"(s[i]));
+}
+
 // Device parameter table (round constants Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride
 // in a REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
 // [216,240) internal diagonal (plain Montgomery form, used as a multiplier; 16-byte aligned).
@@ -69,16 +80,17 @@ __device__ __forceinline__ uint64_t madk0(uint32_t a) {
 __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
     uint64_t y[CELLS];
     // initial external layer; round-0 constants ride in the reduction
-    m_ext64(s, y);
+    m_ext64w(s, y);
 #pragma unroll
     for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
     // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
     // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
+        pin32(s);
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_wide(s[i]);
+        m_ext64w(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + (r + 1) * CELLS;
 #pragma unroll
@@ -127,9 +139,10 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
     // external rounds 4..7
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
+        pin32(s);
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_wide(s[i]);
+        m_ext64w(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
 #pragma unroll

@@ -25,8 +25,9 @@ namespace bx {
 
 constexpr int P2_CELLS = 24;
 // bounds as integers (floor of the real bound, see poseidon2.hip)
-constexpr uint64_t B_RED64 = 2281701392ull;    // red64_lazy output: ((2^32-1) M1 + 63 R2 + P-1)/2^32 + P  (1.13334 P)
-constexpr uint64_t B_SBOX_OUT = 2122444806ull;  // sbox7_bounded output (1.05423 P); 2 * this < 2^32, 112 * this < 2^38
+constexpr uint64_t B_RED64 = 2281701410ull;    // red64_lazy output: ((2^32-1) M1 + 127 R2 + P-1)/2^32 + P  (1.13334 P)
+constexpr uint64_t B_SBOX_OUT = 2122444806ull;  // sbox7_bounded output (1.05423 P), the internal rounds' S-box cell
+constexpr uint64_t B_SBOX_WIDE = 4135710731ull; // sbox7_wide output (2.05423 P < 2^32); 112 * this < 2^39
 constexpr uint64_t B_INT_CELL = 3789677028ull;  // internal-round cells: fixed point of B -> ((P-1) B + 2P)/2^32 + P  (1.88235 P)
 
 BX_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
@@ -43,15 +44,27 @@ BX_HD uint32_t sbox7_bounded(uint32_t x) {
     return r;
 }
 
-// y (< 2^38, unreduced linear-layer output) plus a round constant -> 32 bits:  r == y + a (mod P), r < 1.13334 P, where
+// x^7 without the final subtraction: x < 1.13334 P -> value < 2.05423 P (still a u32) congruent to x^7 * 2^(-6*32).
+// The external layer that follows (m_ext64w) forms its pair sums in 64 bits instead; 14 instructions.
+BX_HD uint32_t sbox7_wide(uint32_t x) {
+    BX_ASSERT_BOUND(x <= B_RED64, "sbox input");
+    uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
+    uint32_t x3 = fp_mul_lazy(x2, x);
+    uint32_t x4 = fp_mul_lazy(x2, x2);
+    const uint32_t x7 = fp_mul_lazy(x3, x4);
+    BX_ASSERT_BOUND(x7 <= B_SBOX_WIDE, "wide sbox output");
+    return x7;
+}
+
+// y (< 2^39, unreduced linear-layer output) plus a round constant -> 32 bits:  r == y + a (mod P), r < 1.13334 P, where
 // `add_rr` = a * 2^64 mod P (a in the cells' Montgomery representation).
-//   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 64 * 1172168163 + P < 1.16e18,
-// so acc + m*P < 2^64 and r < 268435473 + P.  4 instructions (+2 for the canonical form).
+//   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 128 * 1172168163 + P < 1.16e18,
+// so acc + m*P < 2^64 and r < 268435490 + P.  4 instructions (+2 for the canonical form).
 BX_HD uint32_t red64_lazy(uint64_t y, uint32_t add_rr) {
     uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
     acc = mad64((uint32_t)(y >> 32), R2, acc);
     uint32_t m = (uint32_t)acc * NEG_P_INV;
-    BX_ASSERT_BOUND((y >> 38) == 0, "red64 input < 2^38");
+    BX_ASSERT_BOUND((y >> 39) == 0, "red64 input < 2^39");
     const uint32_t r = (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
     BX_ASSERT_BOUND(r <= B_RED64, "red64 output");
     return r;
@@ -64,17 +77,18 @@ BX_HD uint32_t red64_lazy0(uint64_t y) {
     return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
 }
 
-// external layer circ(2*M4, M4, ..., M4) on bounded cells (< 1.05423 P), unreduced 64-bit outputs:
-//   w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B) in mixed width:
-//   t0 = a+b, t1 = c+d (32-bit), t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
-BX_HD void m_ext64(const uint32_t* s, uint64_t* y) {
+// external layer circ(2*M4, M4, ..., M4) on cells < 2.05423 P (sbox7_wide outputs or canonical inputs), unreduced 64-bit
+// outputs:  w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B):
+//   t0 = a+b, t1 = c+d, t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
+// The pair sums do not fit 32 bits and are formed in 64; 4*t + u is one shift-add; y < 230.1 P < 2^39.
+BX_HD void m_ext64w(const uint32_t* s, uint64_t* y) {
 #pragma unroll
     for (int k = 0; k < P2_CELLS; k += 4) {
         const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
-        BX_ASSERT_BOUND(a <= B_SBOX_OUT && b <= B_SBOX_OUT && c <= B_SBOX_OUT && d <= B_SBOX_OUT, "m_ext64 input");
-        const uint32_t t0 = a + b, t1 = c + d;  // < 2.10846 P < 2^32
-        const uint64_t t2 = mad64(2u, b, (uint64_t)t1), t3 = mad64(2u, d, (uint64_t)t0);
-        const uint64_t t4 = mad64(4u, t1, t3), t5 = mad64(4u, t0, t2);
+        BX_ASSERT_BOUND(a <= B_SBOX_WIDE && b <= B_SBOX_WIDE && c <= B_SBOX_WIDE && d <= B_SBOX_WIDE, "m_ext64w input");
+        const uint64_t t0 = (uint64_t)a + b, t1 = (uint64_t)c + d;
+        const uint64_t t2 = mad64(2u, b, t1), t3 = mad64(2u, d, t0);
+        const uint64_t t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
         y[k] = t3 + t5;
         y[k + 1] = t5;
         y[k + 2] = t2 + t4;
@@ -91,7 +105,6 @@ BX_HD void m_ext64(const uint32_t* s, uint64_t* y) {
     for (int i = 0; i < P2_CELLS; ++i) y[i] += t[i & 3];
 }
 
-
 // internal round helpers (host + device): sum (< 2^37) -> sum * 2^32 mod P, canonical
 BX_HD uint32_t internal_sum_r(uint64_t sum) {
     BX_ASSERT_BOUND((sum >> 37) == 0, "internal sum < 2^37");
@@ -107,11 +120,11 @@ BX_HD uint32_t internal_sum_r(uint64_t sum) {
 template <int DIAG>
 BX_HD void poseidon2_mix_bounded(uint32_t* s, const uint32_t* prm) {
     uint64_t y[P2_CELLS];
-    m_ext64(s, y);
+    m_ext64w(s, y);
     for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
+        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
+        m_ext64w(s, y);
         if (r < 3) {
             for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[(r + 1) * P2_CELLS + i]);
         } else {
@@ -136,8 +149,8 @@ BX_HD void poseidon2_mix_bounded(uint32_t* s, const uint32_t* prm) {
         }
     }
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_bounded(s[i]);
-        m_ext64(s, y);
+        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
+        m_ext64w(s, y);
         if (r < 3) {
             for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
         } else {

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbx_hip_hal.so")
+LIB_PATH = os.environ.get("BX_HAL_LIB") or os.path.join(_HERE, "lib", "libbx_hip_hal.so")  # BX_HAL_LIB: A/B builds of the same ABI
 
 P = 2013265921
 DIGEST_WORDS = 8

@@ -71,8 +71,19 @@ int main() {
         for (int k = 0; k < 6; ++k) e = (u128)redc_exact(e * xr);
         REQUIRE(r % P == (uint32_t)e);
     }
-    // ---- red64 over y < 2^38 incl. the edges ----
-    const uint64_t ys[] = {0, 1, P, 0xffffffffull, 0x100000000ull, ((uint64_t)1 << 38) - 1, 112ull * B_SBOX_OUT};
+    // ---- the S-box without its final subtraction (external rounds): same residue, documented wide bound ----
+    for (uint64_t x : sb_in) {
+        uint32_t r = sbox7_wide((uint32_t)x);
+        REQUIRE(r % P == sbox7_bounded((uint32_t)x) % P && r <= B_SBOX_WIDE);
+    }
+    for (int i = 0; i < 500000; ++i) {
+        uint32_t x = (uint32_t)(rnd64() % (B_RED64 + 1));
+        uint32_t r = sbox7_wide(x);
+        REQUIRE(r % P == sbox7_bounded(x) % P && r <= B_SBOX_WIDE);
+    }
+    // ---- red64 over y < 2^39 incl. the edges ----
+    const uint64_t ys[] = {0, 1, P, 0xffffffffull, 0x100000000ull, ((uint64_t)1 << 38) - 1, 112ull * B_SBOX_OUT,
+                           ((uint64_t)1 << 39) - 1, 112ull * B_SBOX_WIDE};
     for (uint64_t y : ys)
         for (uint32_t add : edge) {
             // REDC(y_lo*2^32 + y_hi*2^64 + add_rr) = y + add_rr * 2^-32: the table stores (Montgomery rc) * 2^32
@@ -82,29 +93,22 @@ int main() {
             REQUIRE(red64(y, add) == r % P);
         }
     for (int i = 0; i < 500000; ++i) {
-        uint64_t y = rnd64() >> 26;
+        uint64_t y = rnd64() >> 25;
         uint32_t add = (uint32_t)(rnd64() % P);
         REQUIRE(red64_lazy(y, add) % P == (uint32_t)((y % P + redc_exact(add)) % P));
     }
-    // ---- external layer at the extreme admissible cells ----
+    // ---- the external layer (cells up to 2.05423 P) at its extremes ----
     {
         uint32_t s[24];
         uint64_t y[24];
-        for (int i = 0; i < 24; ++i) s[i] = (uint32_t)B_SBOX_OUT;
-        m_ext64(s, y);
         const int M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
-        for (int i = 0; i < 24; ++i) {
-            u128 want = 0;
-            for (int j = 0; j < 24; ++j) want += (u128)M4[i & 3][j & 3] * (i / 4 == j / 4 ? 2 : 1) * s[j];
-            REQUIRE((u128)y[i] == want && (y[i] >> 38) == 0);
-        }
-        for (int t = 0; t < 20000; ++t) {
-            for (int i = 0; i < 24; ++i) s[i] = (uint32_t)(rnd64() % (B_SBOX_OUT + 1));
-            m_ext64(s, y);
+        for (int t = 0; t < 20001; ++t) {
+            for (int i = 0; i < 24; ++i) s[i] = t == 0 ? (uint32_t)B_SBOX_WIDE : (uint32_t)(rnd64() % (B_SBOX_WIDE + 1));
+            m_ext64w(s, y);
             for (int i = 0; i < 24; ++i) {
                 u128 want = 0;
                 for (int j = 0; j < 24; ++j) want += (u128)M4[i & 3][j & 3] * (i / 4 == j / 4 ? 2 : 1) * s[j];
-                REQUIRE((u128)y[i] == want);
+                REQUIRE((u128)y[i] == want && (y[i] >> 39) == 0);
             }
         }
     }
