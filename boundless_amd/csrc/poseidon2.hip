@@ -30,7 +30,7 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 //     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [mod P, REDC = * 2^-32];
 //   * cells are kept only BOUNDED, not canonical, between rounds; a conditional subtraction is spent only where a
 //     bound would otherwise break.  Results are congruent mod P at every step and the words that leave the permutation
-//     are canonical, so the output is bit-identical to the reduce-everywhere form (9.1 k VALU instructions per permutation
+//     are canonical, so the output is bit-identical to the reduce-everywhere form (8.2 k VALU instructions per permutation
 //     measured by PMC, down from ~14.5 k).
 //
 // Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
