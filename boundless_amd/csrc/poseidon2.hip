@@ -26,15 +26,19 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 // which compiles poseidon2_arith.hpp with every bound asserted):
 //   * linear layers run UNREDUCED in 64 bits: v_mad_u64_u32 multiplies by the small matrix entries and accumulates in
 //     one instruction (external layer outputs < 2^38, internal-layer sum < 2^37);
-//   * the return to 32 bits is one Montgomery reduction per cell, and the next round constant rides in its
-//     accumulator:  x = (y + rc) mod P = REDC(y_lo * 2^32 + y_hi * 2^64 + rc * 2^32)   [mod P, REDC = * 2^-32];
+//   * the return to 32 bits is one bare REDC per cell with the next round constant in its accumulator:
+//     x = REDC(y + rc') [REDC = * 2^-32 mod P].  The factor 2^-32 is not compensated: the cells of a round share a known
+//     representation factor R^e that the (homogeneous) linear layers carry along and the S-box maps to R^(7e-6); the round
+//     constants are stored pre-scaled, and only the two layers that must hand back Montgomery form (before the internal
+//     rounds, and at the end) multiply by a correction constant (poseidon2_arith.hpp: representation tracking);
 //   * cells are kept only BOUNDED, not canonical, between rounds; a conditional subtraction is spent only where a
 //     bound would otherwise break.  Results are congruent mod P at every step and the words that leave the permutation
 //     are canonical, so the output is bit-identical to the reduce-everywhere form (8.2 k VALU instructions per permutation
 //     measured by PMC, down from ~14.5 k).
 //
 // Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
-//   red64_lazy output                  < M1 + 18 + P                       < 1.13334 P          (M1 = 2^32 mod P)
+//   redc64 output                      < (2^39 + P)/2^32 + P                < P + 129
+//   red64k<MID> / <END> output         < K1 + 61 + P                        < 1.126 P / 1.055 P  (K1 = R^2801, R^400 mod P)
 //   sbox7_wide(x < 1.13334 P):     x2 = lazy(x,x) < 1.60209 P -> reduce -> x2r < P
 //                                  x3 = lazy(x2r,x) < 1.53125 P,  x4 = lazy(x2r,x2r) < 1.46875 P
 //                                  x7 = lazy(x3,x4): product 2.24902 P^2 (ok), x7 < 2.05423 P < 2^32, left as it is
@@ -73,8 +77,8 @@ __device__ __forceinline__ void pin32(uint32_t* s) {
     for (int i = 0; i < 24; ++i) asm("" : "+v"(s[i]));
 }
 
-// Device parameter table (round constants Montgomery-encoded once more, i.e. value * 2^64 mod P, so that they can ride
-// in a REDC accumulator): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
+// Device parameter table (round constants scaled by p2_rc_scale(i) so that they can ride in a REDC accumulator of the
+// round's representation): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
 // [216,240) internal diagonal (plain Montgomery form, used as a multiplier; 16-byte aligned).
 // Input: cells < P (canonical).  Output: canonical.
 __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
@@ -82,7 +86,7 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
     // initial external layer; round-0 constants ride in the reduction
     m_ext64w(s, y);
 #pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
+    for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], prm[i]);
     // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
     // the first internal round's)
 #pragma unroll 1
@@ -94,11 +98,11 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
-        } else {
-            s[0] = red64_lazy(y[0], prm[96]);
+            for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], rc[i]);
+        } else {  // back to the Montgomery representation for the internal rounds
+            s[0] = red64k_lazy<K1_MID, K2_MID>(y[0], prm[96]);
 #pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = red64_lazy(y[i], 0u);
+            for (int i = 1; i < CELLS; ++i) s[i] = red64k_lazy<K1_MID, K2_MID, false>(y[i], 0u);
         }
     }
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
@@ -146,10 +150,10 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64_lazy(y[i], rc[i]);
+            for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], rc[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = red64(y[i], 0u);  // canonical words leave the permutation
+            for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(red64k_lazy<K1_END, K2_END, false>(y[i], 0u));  // canonical Montgomery words leave the permutation
         }
     }
 }
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restri
 
 const char* poseidon2_upload_params(bx_ctx* c) {
     uint32_t h[DIAG_OFF + 24] = {0};
-    // round constants ride in REDC accumulators: store rc * 2^64 mod P (Montgomery form encoded once more)
-    for (int i = 0; i < 213; ++i) h[i] = fp_encode(fp_encode(c->h_rc[i]));
+    // round constants ride in REDC accumulators, pre-scaled to the representation of the round they are added in
+    for (int i = 0; i < 213; ++i) h[i] = (uint32_t)((uint64_t)(c->h_rc[i] % P) * p2_rc_scale(i) % P);
     for (int i = 0; i < 24; ++i) h[DIAG_OFF + i] = fp_encode(c->h_diag[i]);
     if (!c->d_p2) BX_HIP(c, hipMalloc(&c->d_p2, sizeof h));
     BX_HIP(c, hipMemcpyAsync(c->d_p2, h, sizeof h, hipMemcpyHostToDevice, c->stream));

@@ -24,17 +24,50 @@
 namespace bx {
 
 constexpr int P2_CELLS = 24;
+
+// ---- representation tracking ------------------------------------------------------------------------------------------
+// A cell holds v * c mod P for a per-round constant factor c = R^e (R = 2^32 mod P), not always the Montgomery factor R:
+// the external linear layers are homogeneous, so their return to 32 bits can be a bare REDC (factor * R^-1, 2 multiply-class
+// instructions) instead of a factor-preserving one (4), and the S-box maps R^e to R^(7e - 6).  With canonical Montgomery
+// input (e = 1) the exponents entering the S-boxes of external rounds 0..3 are 0, -7, -56, -399; the layer after round 3
+// multiplies by K1_MID = R^2801 to hand the internal rounds (which need one common factor for all cells, i.e. e = 1) the
+// standard form back; rounds 4..7 see 1, 0, -7, -56 and the last layer restores e = 1 with K1_END = R^400.  Round
+// constants are stored pre-scaled to the representation of the point where they are added (p2_rc_scale).
+constexpr uint32_t cx_mul(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)a * b % P); }
+constexpr uint32_t cx_pow(uint32_t b, uint64_t e) {
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = cx_mul(r, b);
+        b = cx_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+constexpr uint32_t cx_rpow(int64_t e) { return cx_pow(MONT_ONE, e >= 0 ? (uint64_t)e : (uint64_t)((int64_t)(P - 1) + e)); }
+constexpr uint32_t K1_MID = cx_rpow(2801), K2_MID = cx_mul(K1_MID, MONT_ONE);
+constexpr uint32_t K1_END = cx_rpow(400), K2_END = cx_mul(K1_END, MONT_ONE);
+// factor (power of R) a canonical round constant is multiplied by in the device table; index as in the 213-word layout
+// 4x24 external | 21 internal | 4x24 external.  Constants added inside a REDC accumulator carry one extra R.
+constexpr uint32_t p2_rc_scale(int i) {
+    return i < 24 ? cx_rpow(1) : i < 48 ? cx_rpow(-6) : i < 72 ? cx_rpow(-55) : i < 96 ? cx_rpow(-398)
+         : i < 141 ? cx_rpow(2) /* internal rounds and external round 4: added to Montgomery-form cells inside a REDC */
+         : i < 165 ? cx_rpow(1) : i < 189 ? cx_rpow(-6) : cx_rpow(-55);
+}
+
 // bounds as integers (floor of the real bound, see poseidon2.hip)
-constexpr uint64_t B_RED64 = 2281701410ull;    // red64_lazy output: ((2^32-1) M1 + 127 R2 + P-1)/2^32 + P  (1.13334 P)
+constexpr uint64_t B_REDC = (uint64_t)P + 129;  // redc64 output: (2^39 + P) / 2^32 + P
+constexpr uint64_t B_RED64 = (((uint64_t)0xffffffffu * K1_MID + 127ull * K2_MID + 2ull * P) >> 32) + P;  // red64k<MID> output (1.126 P)
+constexpr uint64_t B_END = (((uint64_t)0xffffffffu * K1_END + 127ull * K2_END + 2ull * P) >> 32) + P;    // red64k<END> output (1.055 P)
 constexpr uint64_t B_SBOX_OUT = 2122444806ull;  // sbox7_bounded output (1.05423 P), the internal rounds' S-box cell
-constexpr uint64_t B_SBOX_WIDE = 4135710731ull; // sbox7_wide output (2.05423 P < 2^32); 112 * this < 2^39
+constexpr uint64_t B_SBOX_WIDE = 4135710731ull; // sbox7_wide output bound for inputs < 1.13334 P (2.05423 P < 2^32); 112 * this < 2^39
 constexpr uint64_t B_INT_CELL = 3789677028ull;  // internal-round cells: fixed point of B -> ((P-1) B + 2P)/2^32 + P  (1.88235 P)
+static_assert(B_RED64 < 2281701410ull && B_END < 2ull * P && B_REDC < B_RED64, "representation constants moved the bounds");
 
 BX_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
 
 // x^7 for x < 1.13334 P; returns a value < 1.05423 P congruent to x^7 * 2^(-6*32) (Montgomery).  16 instructions.
 BX_HD uint32_t sbox7_bounded(uint32_t x) {
-    BX_ASSERT_BOUND(x <= B_RED64, "sbox input");
+    BX_ASSERT_BOUND(x <= 2281701410ull, "sbox input");
     uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
     uint32_t x3 = fp_mul_lazy(x2, x);
     uint32_t x4 = fp_mul_lazy(x2, x2);
@@ -47,7 +80,7 @@ BX_HD uint32_t sbox7_bounded(uint32_t x) {
 // x^7 without the final subtraction: x < 1.13334 P -> value < 2.05423 P (still a u32) congruent to x^7 * 2^(-6*32).
 // The external layer that follows (m_ext64w) forms its pair sums in 64 bits instead; 14 instructions.
 BX_HD uint32_t sbox7_wide(uint32_t x) {
-    BX_ASSERT_BOUND(x <= B_RED64, "sbox input");
+    BX_ASSERT_BOUND(x <= 2281701410ull, "sbox input");
     uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
     uint32_t x3 = fp_mul_lazy(x2, x);
     uint32_t x4 = fp_mul_lazy(x2, x2);
@@ -56,24 +89,44 @@ BX_HD uint32_t sbox7_wide(uint32_t x) {
     return x7;
 }
 
-// y (< 2^39, unreduced linear-layer output) plus a round constant -> 32 bits:  r == y + a (mod P), r < 1.13334 P, where
-// `add_rr` = a * 2^64 mod P (a in the cells' Montgomery representation).
-//   acc = y_lo*(2^32 mod P) + y_hi*(2^64 mod P) + add_rr < 2^32 * 268435454 + 128 * 1172168163 + P < 1.16e18,
-// so acc + m*P < 2^64 and r < 268435490 + P.  4 instructions (+2 for the canonical form).
-BX_HD uint32_t red64_lazy(uint64_t y, uint32_t add_rr) {
-    uint64_t acc = mad64((uint32_t)y, MONT_ONE, add_rr);
-    acc = mad64((uint32_t)(y >> 32), R2, acc);
-    uint32_t m = (uint32_t)acc * NEG_P_INV;
-    BX_ASSERT_BOUND((y >> 39) == 0, "red64 input < 2^39");
+// Bare REDC of an unreduced linear-layer output plus a pre-scaled round constant:  r == (y + rc) * 2^-32 (mod P),
+// r < (2^39 + P)/2^32 + P = P + 129.  3 instructions (64-bit add, v_mul_lo, v_mad_u64_u32).
+BX_HD uint32_t redc64(uint64_t y, uint32_t rc) {
+    BX_ASSERT_BOUND((y >> 39) == 0, "redc64 input < 2^39");
+    const uint64_t acc = y + rc;
+    const uint32_t m = (uint32_t)acc * NEG_P_INV;
     const uint32_t r = (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
-    BX_ASSERT_BOUND(r <= B_RED64, "red64 output");
+    BX_ASSERT_BOUND(r <= B_REDC, "redc64 output");
     return r;
 }
-BX_HD uint32_t red64(uint64_t y, uint32_t add_rr) { return fp_reduce(red64_lazy(y, add_rr)); }
-// the same without a constant (addend literal 0)
-BX_HD uint32_t red64_lazy0(uint64_t y) {
-    uint64_t acc = mad64((uint32_t)(y >> 32), R2, mad64((uint32_t)y, MONT_ONE, 0ull));
-    uint32_t m = (uint32_t)acc * NEG_P_INV;
+// REDC with a change of representation:  r == (y * K1 + add) * 2^-32 (mod P), K2 = K1 * 2^32 mod P.
+//   acc = y_lo*K1 + y_hi*K2 + add < 2^32 * K1 + 128 * P + 2P,  acc + m*P < 2^64,  r < K1 + 61 + P.  4 instructions.
+// On the device the two products are pinned to v_mad_u64_u32: left alone, hipcc reassociates y_lo*K1 + y_hi*K2 into
+// y*K1 + y_hi*(K2 - K1*2^32) as a 64x64-bit multiply (4 multiply-adds and 4 moves per cell instead of 2).
+BX_HD uint64_t mad64_pinned(uint32_t a, uint32_t k, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c) : "vcc");
+    return r;
+#else
+    return mad64(a, k, c);
+#endif
+}
+BX_HD uint64_t mad64_pinned0(uint32_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k) : "vcc");
+    return r;
+#else
+    return mad64(a, k, 0ull);
+#endif
+}
+template <uint32_t K1, uint32_t K2, bool HAS_ADD = true>
+BX_HD uint32_t red64k_lazy(uint64_t y, uint32_t add) {
+    BX_ASSERT_BOUND((y >> 39) == 0, "red64k input < 2^39");
+    uint64_t acc = HAS_ADD ? mad64((uint32_t)y, K1, add) : mad64_pinned0((uint32_t)y, K1);
+    acc = mad64_pinned((uint32_t)(y >> 32), K2, acc);
+    const uint32_t m = (uint32_t)acc * NEG_P_INV;
     return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
 }
 
@@ -116,20 +169,21 @@ BX_HD uint32_t internal_sum_r(uint64_t sum) {
 
 // The whole permutation in the exact order and arithmetic of the device kernel (poseidon2.hip: poseidon2_mix); the
 // device version differs only in pinning the internal-round sum to v_mad_u64_u32 and keeping the diagonal in VGPRs.
-// prm: [0,96) | [96,117) | [117,213) round constants * 2^64 mod P, [DIAG..DIAG+24) diagonal (Montgomery).
+// prm: [0,96) | [96,117) | [117,213) round constants * p2_rc_scale(i), [DIAG..DIAG+24) diagonal (Montgomery).
 template <int DIAG>
 BX_HD void poseidon2_mix_bounded(uint32_t* s, const uint32_t* prm) {
     uint64_t y[P2_CELLS];
     m_ext64w(s, y);
-    for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[i]);
+    for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[i]);
     for (int r = 0; r < 4; ++r) {
         for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
         m_ext64w(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[(r + 1) * P2_CELLS + i]);
+            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[(r + 1) * P2_CELLS + i]);
         } else {
-            s[0] = red64_lazy(y[0], prm[96]);
-            for (int i = 1; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], 0u);
+            s[0] = red64k_lazy<K1_MID, K2_MID>(y[0], prm[96]);
+            for (int i = 1; i < P2_CELLS; ++i) s[i] = red64k_lazy<K1_MID, K2_MID, false>(y[i], 0u);
+            for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(s[i] <= B_RED64, "mid transition output");
         }
     }
     const uint32_t* diag = prm + DIAG;
@@ -152,9 +206,13 @@ BX_HD void poseidon2_mix_bounded(uint32_t* s, const uint32_t* prm) {
         for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
         m_ext64w(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = red64_lazy(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
+            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
         } else {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = red64(y[i], 0u);
+            for (int i = 0; i < P2_CELLS; ++i) {
+                const uint32_t v = red64k_lazy<K1_END, K2_END, false>(y[i], 0u);
+                BX_ASSERT_BOUND(v <= B_END, "end transition output");
+                s[i] = fp_reduce(v);
+            }
         }
     }
 }

@@ -81,21 +81,45 @@ int main() {
         uint32_t r = sbox7_wide(x);
         REQUIRE(r % P == sbox7_bounded(x) % P && r <= B_SBOX_WIDE);
     }
-    // ---- red64 over y < 2^39 incl. the edges ----
+    // ---- the returns to 32 bits over y < 2^39 incl. the edges ----
     const uint64_t ys[] = {0, 1, P, 0xffffffffull, 0x100000000ull, ((uint64_t)1 << 38) - 1, 112ull * B_SBOX_OUT,
                            ((uint64_t)1 << 39) - 1, 112ull * B_SBOX_WIDE};
+    const uint32_t rinv = cx_rpow(-1);
+    const auto red_mid = [](uint64_t y, uint32_t a) { return red64k_lazy<K1_MID, K2_MID>(y, a); };
+    const auto red_end = [](uint64_t y, uint32_t a) { return red64k_lazy<K1_END, K2_END>(y, a); };
     for (uint64_t y : ys)
         for (uint32_t add : edge) {
-            // REDC(y_lo*2^32 + y_hi*2^64 + add_rr) = y + add_rr * 2^-32: the table stores (Montgomery rc) * 2^32
-            uint32_t a_plain = redc_exact(add);
-            uint32_t r = red64_lazy(y, add);
-            REQUIRE(r % P == (uint32_t)(((u128)(y % P) * ((u128)1) + a_plain) % P));
-            REQUIRE(red64(y, add) == r % P);
+            const uint32_t a = add % P;
+            // bare REDC: (y + rc) * R^-1
+            uint32_t r = redc64(y, a);
+            REQUIRE(r % P == (uint32_t)((u128)((y + a) % P) * rinv % P) && r <= B_REDC);
+            // representation-changing REDC: (y * K1 + add) * R^-1
+            uint32_t m = red_mid(y, a), e = red_end(y, a);
+            REQUIRE(m % P == (uint32_t)(((u128)(y % P) * K1_MID + a) % P * rinv % P) && m <= B_RED64);
+            REQUIRE(e % P == (uint32_t)(((u128)(y % P) * K1_END + a) % P * rinv % P) && e <= B_END);
         }
     for (int i = 0; i < 500000; ++i) {
         uint64_t y = rnd64() >> 25;
-        uint32_t add = (uint32_t)(rnd64() % P);
-        REQUIRE(red64_lazy(y, add) % P == (uint32_t)((y % P + redc_exact(add)) % P));
+        uint32_t a = (uint32_t)(rnd64() % P);
+        REQUIRE(redc64(y, a) % P == (uint32_t)((u128)((y + a) % P) * rinv % P));
+        REQUIRE(red_mid(y, a) % P == (uint32_t)(((u128)(y % P) * K1_MID + a) % P * rinv % P));
+    }
+    // the representation constants are what the exponent bookkeeping says (R = 2^32 mod P)
+    {
+        const auto rp = [](int64_t e) { return cx_rpow(e); };
+        REQUIRE(cx_mul(rp(1), rp(-1)) == 1 && rp(1) == MONT_ONE && rp(2) == R2 && rp(3) == R3);
+        int64_t e = 1;                      // canonical Montgomery input
+        e -= 1;                             // initial layer, bare REDC
+        for (int r = 0; r < 3; ++r) e = 7 * e - 6 - 1;  // S-box, layer, bare REDC
+        REQUIRE(e == -399);
+        REQUIRE(cx_mul(rp(7 * e - 6), K1_MID) == rp(2));  // (y * K1_MID) * R^-1 is back at R^1
+        e = 1;                              // after the internal rounds
+        e = 7 * e - 6 - 1;                  // round 4
+        for (int r = 0; r < 2; ++r) e = 7 * e - 6 - 1;  // rounds 5, 6
+        REQUIRE(e == -56 && cx_mul(rp(7 * e - 6), K1_END) == rp(2));
+        REQUIRE(p2_rc_scale(0) == rp(1) && p2_rc_scale(24) == rp(-6) && p2_rc_scale(48) == rp(-55) && p2_rc_scale(72) == rp(-398));
+        REQUIRE(p2_rc_scale(96) == R2 && p2_rc_scale(117) == R2 && p2_rc_scale(141) == rp(1) && p2_rc_scale(165) == rp(-6) &&
+                p2_rc_scale(189) == rp(-55));
     }
     // ---- the external layer (cells up to 2.05423 P) at its extremes ----
     {
@@ -121,7 +145,7 @@ int main() {
         ref.load(POSEIDON2_RC, POSEIDON2_DIAG);
         uint32_t prm[240];
         memset(prm, 0, sizeof prm);
-        for (int i = 0; i < 213; ++i) prm[i] = fp_encode(fp_encode(POSEIDON2_RC[i]));
+        for (int i = 0; i < 213; ++i) prm[i] = (uint32_t)((uint64_t)POSEIDON2_RC[i] * p2_rc_scale(i) % P);
         for (int i = 0; i < 24; ++i) prm[216 + i] = fp_encode(POSEIDON2_DIAG[i]);
         const uint32_t pool[] = {0, 1, 2, P - 1, P - 2, (P - 1) / 2, MONT_ONE, R2};
         for (int t = 0; t < 6000; ++t) {
