@@ -18,61 +18,38 @@ constexpr int CELLS = 24, RATE = 16, RF_HALF = 4, RP = 21;
 constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device parameter table
 
 // ---------------------------------------------------------------------------------------------------------------
-// Instruction budget.  The kernel is VALU-issue-bound and on gfx950 a 32-bit multiply-class op (v_mad_u64_u32,
-// v_mul_lo/hi_u32, v_min_u32, v_lshl_add_u64) costs ~4 cycles per wave and a plain add/sub/and/mov ~2
-// (profiles/r01_microbench2_instr_cost.jsonl): a canonical modular add is 2 cheap + 1 expensive instructions, a lazy
-// Montgomery product 3 expensive ones (+ v_sub, v_min for the canonical form).  The permutation is organised to minimise
-// that weighted instruction count, not multiplications (bounds are verified on the host by tests/host_arith_check.cpp,
-// which compiles poseidon2_arith.hpp with every bound asserted):
-//   * linear layers run UNREDUCED in 64 bits: v_mad_u64_u32 multiplies by the small matrix entries and accumulates in
-//     one instruction (external layer outputs < 2^38, internal-layer sum < 2^37);
+// Instruction budget.  The kernel is VALU-issue-bound and on gfx950 a 32-bit multiply-class op (v_mad_[iu]64_[iu]32,
+// v_mul_lo/hi_u32, v_min_u32, v_lshl_add_u64) costs ~1.9 ns per wave and SIMD and a plain add/sub/and/mov ~1.05 ns
+// (profiles/r01_microbench2_instr_cost.jsonl).  The permutation is organised to minimise that weighted instruction count,
+// not multiplications (every bound below is asserted on the host by tests/host_arith_check.cpp, which compiles
+// poseidon2_arith.hpp for the CPU and compares the whole permutation with the plain canonical implementation):
+//   * cells are SIGNED 32-bit integers, only bounded in magnitude: the signed Montgomery reduction maps |t| <= 1.2 P^2 to
+//     |r| < |t|/2^32 + P/2, so products of cells stay below 0.95 P by themselves and the permutation contains no
+//     conditional subtraction at all except for the 24 words that leave it;
+//   * linear layers run UNREDUCED in 64 bits (v_mad_i64_i32 multiplies by the small matrix entries and accumulates in one
+//     instruction; external-layer outputs < 2^38, internal-layer sum < 2^37);
 //   * the return to 32 bits is one bare REDC per cell with the next round constant in its accumulator:
 //     x = REDC(y + rc') [REDC = * 2^-32 mod P].  The factor 2^-32 is not compensated: the cells of a round share a known
 //     representation factor R^e that the (homogeneous) linear layers carry along and the S-box maps to R^(7e-6); the round
 //     constants are stored pre-scaled, and only the two layers that must hand back Montgomery form (before the internal
-//     rounds, and at the end) multiply by a correction constant (poseidon2_arith.hpp: representation tracking);
-//   * cells are kept only BOUNDED, not canonical, between rounds; a conditional subtraction is spent only where a
-//     bound would otherwise break.  Results are congruent mod P at every step and the words that leave the permutation
-//     are canonical, so the output is bit-identical to the reduce-everywhere form (8.2 k VALU instructions per permutation
-//     measured by PMC, down from ~14.5 k).
+//     rounds, and at the end) multiply by a correction constant (poseidon2_arith.hpp: representation tracking).
+// Results are congruent mod P at every step and the words that leave the permutation are canonical, so the output is
+// bit-identical to the reduce-everywhere form (7.3 k VALU instructions per permutation by PMC, down from ~14.5 k).
 //
-// Bounds (rho = P / 2^32 = 0.46875; lazy(a,b,c) = fp_mad_lazy < (a*b + c)/2^32 + P, contract a*b + c < 2.42 P^2):
-//   redc64 output                      < (2^39 + P)/2^32 + P                < P + 129
-//   red64k<MID> / <END> output         < K1 + 61 + P                        < 1.126 P / 1.055 P  (K1 = R^2801, R^400 mod P)
-//   sbox7_wide(x < 1.13334 P):     x2 = lazy(x,x) < 1.60209 P -> reduce -> x2r < P
-//                                  x3 = lazy(x2r,x) < 1.53125 P,  x4 = lazy(x2r,x2r) < 1.46875 P
-//                                  x7 = lazy(x3,x4): product 2.24902 P^2 (ok), x7 < 2.05423 P < 2^32, left as it is
-//                                  (sbox7_bounded, used for the single internal-round S-box, subtracts once: < 1.05423 P)
-//   m_ext64w(cells < 2.05423 P):   pair sums in 64 bits; rows sum to <= 16 so w < 32.87 P, y < 230.1 P < 2^39, y_hi < 108
-//   internal rounds:               cell i >= 1: lazy(d_i, s_i, sum_r) with s_i < B P gives < (rho B + 1) P: B grows from 1.13334
-//                                  towards the fixed point 1/(1 - rho) = 1.88235 and never passes it (< 2^32 / P = 2.1333);
-//                                  product B P^2 + 2P < 2.42 P^2;  sum < (1.06 + 23 * 1.8824) P < 2^37, sum_hi < 22;
-//                                  sum_r and the S-box cell are reduced to canonical every round.
+// Magnitude bounds (rho = P / 2^32 = 0.46875; sredc(t) in [t/2^32 - P/2, t/2^32 + P/2); int32 holds 1.0667 P):
+//   redc64s output                     |x| <= 57 + P/2                           (external rounds' S-box input)
+//   sbox7s(|x| <= 0.945 P)             |x2| < 0.919 P, |x3| < 0.907 P, |x4| < 0.896 P, |x7| < 0.881 P; products <= 0.893 P^2 < 1.2 P^2
+//   m_ext64s(any int32 cells)          rows sum to <= 112, |y| <= 112 * 2^31 < 2^38
+//   red64ks<MID>/<END> output          |x| < K1 + 26 + P/2  = 0.626 P / 0.555 P    (K1 = R^2801, R^400 mod P)
+//   internal rounds                    cell i: sredc(d_i s_i + sum_r [+ rc]) with d_i < P: B -> rho B + P/2 + 2 has its fixed
+//                                      point at 0.9412 P, 0.945 P is invariant; |sum| < 22.7 P < 2^37; |sum_r| < 0.791 P thanks to
+//                                      the balanced low word of sum.
 // ---------------------------------------------------------------------------------------------------------------
-// Pinned v_mad_u64_u32 forms.  Left to itself hipcc rewrites "x*1 + acc" / "x*2 + acc" into v_lshl_add_u64 plus a v_mov
-// that zero-extends the 32-bit operand into a register pair — two instructions on the same issue port instead of one.
-// K is an inline constant; the 64-bit addend is a VGPR pair or the literal 0.  vcc receives the (unused) carry-out.
-// Only the internal-round sum uses them: pinning the external layer the same way removes ~35 instructions per round (the
-// v_mov pairs that zero-extend each cell) but measures no faster than the compiler's v_lshl_add_u64 form (3.83 vs 3.80 ms
-// for hash_rows at 2^22 x 64), so the external layer stays plain C shared with the host checker.
-template <int K>
-__device__ __forceinline__ uint64_t madk(uint32_t a, uint64_t acc) {
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(a), "v"(acc), "n"(K) : "vcc");
-    return r;
-}
-template <int K>
-__device__ __forceinline__ uint64_t madk0(uint32_t a) {
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "n"(K) : "vcc");
-    return r;
-}
-
 // Loop-carried cells must stay 32-bit values.  Without this hipcc widens the 24 loop phis of the external rounds to i64
-// (every use is a zero-extension into a 64-bit multiply-add), loses track of the zero high words across the back edge and
-// emits full 64x32 / 64x64-bit products for the first two S-box multiplications: 5 extra instructions per cell and round
-// (~10 % of the permutation).  An empty asm with a 32-bit register constraint costs nothing and pins the width.
-__device__ __forceinline__ void pin32(uint32_t* s) {
+// (every use is an extension into a 64-bit multiply-add), loses track of the high words across the back edge and emits full
+// 64x32 / 64x64-bit products for the first two S-box multiplications: 5 extra instructions per cell and round (~10 % of the
+// permutation).  An empty asm with a 32-bit register constraint costs nothing and pins the width.
+__device__ __forceinline__ void pin32(i32* s) {
 #pragma unroll
     for (int i = 0; i < 24; ++i) asm("" : "+v"(s[i]));
 }
@@ -81,38 +58,41 @@ __device__ __forceinline__ void pin32(uint32_t* s) {
 // round's representation): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
 // [216,240) internal diagonal (plain Montgomery form, used as a multiplier; 16-byte aligned).
 // Input: cells < P (canonical).  Output: canonical.
-__device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __restrict__ prm) {
-    uint64_t y[CELLS];
-    // initial external layer; round-0 constants ride in the reduction
-    m_ext64w(s, y);
+__device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __restrict__ prm) {
+    i32 s[CELLS];
+    i64 y[CELLS];
 #pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], prm[i]);
+    for (int i = 0; i < CELLS; ++i) s[i] = (i32)io[i];
+    // initial external layer; round-0 constants ride in the reduction
+    m_ext64s(s, y);
+#pragma unroll
+    for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], prm[i]);
     // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
     // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
         pin32(s);
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_wide(s[i]);
-        m_ext64w(s, y);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7s(s[i]);
+        m_ext64s(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], rc[i]);
+            for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], rc[i]);
         } else {  // back to the Montgomery representation for the internal rounds
-            s[0] = red64k_lazy<K1_MID, K2_MID>(y[0], prm[96]);
+            s[0] = red64ks<K1_MID, K2_MID>(y[0], prm[96]);
 #pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = red64k_lazy<K1_MID, K2_MID, false>(y[i], 0u);
+            for (int i = 1; i < CELLS; ++i) s[i] = red64ks<K1_MID, K2_MID, false>(y[i], 0u);
         }
     }
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
-    // sum_r = sum * 2^32 mod P (canonical) by one reduction (acc < 2^32 * R2 + 22 * R3), and rides in each cell's REDC
-    // accumulator together with the next constant (sum_r + rc < 2P fits 32 bits).
+    // sum_r = sum * 2^32 mod P by one reduction, and rides in each cell's REDC accumulator (cell 0: together with the next
+    // constant).
     // The 24 diagonal words are wave-uniform, but left in SGPRs the compiler reloads them with three s_load + s_waitcnt
     // stalls in every internal round (a scalar-cache round trip is about as long as half a round's arithmetic).  Keep them
     // in VGPRs for the whole permutation instead: six 16-byte vector loads through an offset the compiler cannot prove
     // uniform (an opaque zero), issued once, one wait.
-    uint32_t diag[CELLS];
+    i32 diag[CELLS];
     {
         uint32_t zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
@@ -120,24 +100,24 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
 #pragma unroll
         for (int i = 0; i < CELLS / 4; ++i) {
             const uint4 v = dp[i];
-            diag[4 * i] = v.x; diag[4 * i + 1] = v.y; diag[4 * i + 2] = v.z; diag[4 * i + 3] = v.w;
+            diag[4 * i] = (i32)v.x; diag[4 * i + 1] = (i32)v.y; diag[4 * i + 2] = (i32)v.z; diag[4 * i + 3] = (i32)v.w;
         }
     }
 #pragma unroll 1
     for (int r = 0; r < RP; ++r) {
-        s[0] = sbox7_bounded(s[0]);
-        uint64_t sum = madk0<1>(s[0]);
+        s[0] = sbox7s(s[0]);
+        i64 sum = smulc<1>(s[0]);
 #pragma unroll
-        for (int i = 1; i < CELLS; ++i) sum = madk<1>(s[i], sum);
-        const uint32_t sum_r = internal_sum_r(sum);
+        for (int i = 1; i < CELLS; ++i) sum = smadc<1>(s[i], sum);
+        const i64 c = smulc<1>(internal_sum_rs(sum));
         if (r < RP - 1) {
-            s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));  // next internal constant rides along
+            s[0] = sredc(smad(diag[0], s[0], add_u32(c, prm[97 + r])));  // next internal constant rides along
 #pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = fp_mad_lazy(diag[i], s[i], sum_r);  // bounded, see the table above
+            for (int i = 1; i < CELLS; ++i) s[i] = sredc(smad(diag[i], s[i], c));
         } else {
-            const uint32_t* rc = prm + 117;  // external round 4's constants; back to canonical for the S-boxes
+            const uint32_t* rc = prm + 117;  // external round 4's constants
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r + rc[i]));
+            for (int i = 0; i < CELLS; ++i) s[i] = sredc(smad(diag[i], s[i], add_u32(c, rc[i])));
         }
     }
     // external rounds 4..7
@@ -145,15 +125,15 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* s, const uint32_t* __res
     for (int r = 0; r < RF_HALF; ++r) {
         pin32(s);
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7_wide(s[i]);
-        m_ext64w(s, y);
+        for (int i = 0; i < CELLS; ++i) s[i] = sbox7s(s[i]);
+        m_ext64s(s, y);
         if (r < RF_HALF - 1) {
             const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = redc64(y[i], rc[i]);
+            for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], rc[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = fp_reduce(red64k_lazy<K1_END, K2_END, false>(y[i], 0u));  // canonical Montgomery words leave the permutation
+            for (int i = 0; i < CELLS; ++i) io[i] = canon(red64ks<K1_END, K2_END, false>(y[i], 0u));  // canonical Montgomery words leave the permutation
         }
     }
 }

@@ -1,4 +1,4 @@
-// poseidon2_arith.hpp — the bounded-cell arithmetic of the Poseidon2 kernels, usable from host and device.
+// poseidon2_arith.hpp — the signed, bounded-cell arithmetic of the Poseidon2 kernels, usable from host and device.
 //
 // The same source is compiled into the gfx950 kernels (poseidon2.hip) and into a host checker
 // (tests/host_arith_check.cpp, built with g++ by tests/test_host_arith_cpu.py) that drives every helper with extreme and
@@ -54,100 +54,165 @@ constexpr uint32_t p2_rc_scale(int i) {
          : i < 165 ? cx_rpow(1) : i < 189 ? cx_rpow(-6) : cx_rpow(-55);
 }
 
-// bounds as integers (floor of the real bound, see poseidon2.hip)
-constexpr uint64_t B_REDC = (uint64_t)P + 129;  // redc64 output: (2^39 + P) / 2^32 + P
-constexpr uint64_t B_RED64 = (((uint64_t)0xffffffffu * K1_MID + 127ull * K2_MID + 2ull * P) >> 32) + P;  // red64k<MID> output (1.126 P)
-constexpr uint64_t B_END = (((uint64_t)0xffffffffu * K1_END + 127ull * K2_END + 2ull * P) >> 32) + P;    // red64k<END> output (1.055 P)
-constexpr uint64_t B_SBOX_OUT = 2122444806ull;  // sbox7_bounded output (1.05423 P), the internal rounds' S-box cell
-constexpr uint64_t B_SBOX_WIDE = 4135710731ull; // sbox7_wide output bound for inputs < 1.13334 P (2.05423 P < 2^32); 112 * this < 2^39
-constexpr uint64_t B_INT_CELL = 3789677028ull;  // internal-round cells: fixed point of B -> ((P-1) B + 2P)/2^32 + P  (1.88235 P)
-static_assert(B_RED64 < 2281701410ull && B_END < 2ull * P && B_REDC < B_RED64, "representation constants moved the bounds");
+// ---- signed Montgomery arithmetic ---------------------------------------------------------------------------------------
+// Inside the permutation a cell is a SIGNED 32-bit integer congruent to its value, only bounded in magnitude.  The signed
+// reduction  sredc(t) = (t + m*P) / 2^32  with  m = -t * P^-1 mod 2^32 taken in [-2^31, 2^31)  returns
+//   r == t * 2^-32 (mod P),   t/2^32 - P/2 <= r < t/2^32 + P/2,
+// so a product of two cells of magnitude < P comes back with magnitude < 0.97 P: the set is closed under multiplication
+// and NO conditional subtraction is needed anywhere inside the permutation (the unsigned form needed one per S-box plus
+// one per reduced cell).  Three instructions per product as before: v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32.
+// Only the 24 words that leave the permutation are made canonical (v_add + v_min_u32 each).
+// Validity: |t| <= SREDC_MAX keeps the result inside an int32 and t + m*P inside an int64.
+using i32 = int32_t;
+using i64 = int64_t;
+constexpr i64 SREDC_MAX = ((i64)0x7fffffff - (i64)(P / 2) - 2) * ((i64)1 << 32);  // = 1.209 P^2
 
-BX_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
-
-// x^7 for x < 1.13334 P; returns a value < 1.05423 P congruent to x^7 * 2^(-6*32) (Montgomery).  16 instructions.
-BX_HD uint32_t sbox7_bounded(uint32_t x) {
-    BX_ASSERT_BOUND(x <= 2281701410ull, "sbox input");
-    uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
-    uint32_t x3 = fp_mul_lazy(x2, x);
-    uint32_t x4 = fp_mul_lazy(x2, x2);
-    const uint32_t x7 = fp_mul_lazy(x3, x4);
-    const uint32_t r = fp_reduce(x7);
-    BX_ASSERT_BOUND(r <= B_SBOX_OUT, "sbox output");
-    return r;
-}
-
-// x^7 without the final subtraction: x < 1.13334 P -> value < 2.05423 P (still a u32) congruent to x^7 * 2^(-6*32).
-// The external layer that follows (m_ext64w) forms its pair sums in 64 bits instead; 14 instructions.
-BX_HD uint32_t sbox7_wide(uint32_t x) {
-    BX_ASSERT_BOUND(x <= 2281701410ull, "sbox input");
-    uint32_t x2 = fp_reduce(fp_mul_lazy(x, x));
-    uint32_t x3 = fp_mul_lazy(x2, x);
-    uint32_t x4 = fp_mul_lazy(x2, x2);
-    const uint32_t x7 = fp_mul_lazy(x3, x4);
-    BX_ASSERT_BOUND(x7 <= B_SBOX_WIDE, "wide sbox output");
-    return x7;
-}
-
-// Bare REDC of an unreduced linear-layer output plus a pre-scaled round constant:  r == (y + rc) * 2^-32 (mod P),
-// r < (2^39 + P)/2^32 + P = P + 129.  3 instructions (64-bit add, v_mul_lo, v_mad_u64_u32).
-BX_HD uint32_t redc64(uint64_t y, uint32_t rc) {
-    BX_ASSERT_BOUND((y >> 39) == 0, "redc64 input < 2^39");
-    const uint64_t acc = y + rc;
-    const uint32_t m = (uint32_t)acc * NEG_P_INV;
-    const uint32_t r = (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
-    BX_ASSERT_BOUND(r <= B_REDC, "redc64 output");
-    return r;
-}
-// REDC with a change of representation:  r == (y * K1 + add) * 2^-32 (mod P), K2 = K1 * 2^32 mod P.
-//   acc = y_lo*K1 + y_hi*K2 + add < 2^32 * K1 + 128 * P + 2P,  acc + m*P < 2^64,  r < K1 + 61 + P.  4 instructions.
-// On the device the two products are pinned to v_mad_u64_u32: left alone, hipcc reassociates y_lo*K1 + y_hi*K2 into
-// y*K1 + y_hi*(K2 - K1*2^32) as a 64x64-bit multiply (4 multiply-adds and 4 moves per cell instead of 2).
-BX_HD uint64_t mad64_pinned(uint32_t a, uint32_t k, uint64_t c) {
+// The multiply-add primitives.  On the device each one is a single pinned instruction: written as plain C, hipcc widens the
+// loop-carried cells to i64, forgets that they are sign-extended 32-bit values and emulates 64x64-bit products
+// (v_mad_u64_u32 + 2 v_mul_lo + v_add3 per product), or inserts v_ashrrev/v_mov pairs to build sign-extended register
+// pairs for its shift-add forms.  vcc receives the (unused) carry-out.  The host versions are the definitions.
+BX_HD i64 smad(i32 a, i32 b, i64 c) {  // a*b + c, all signed
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c) : "vcc");
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
     return r;
 #else
-    return mad64(a, k, c);
+    return (i64)a * (i64)b + c;
 #endif
 }
-BX_HD uint64_t mad64_pinned0(uint32_t a, uint32_t k) {
+BX_HD i64 smul(i32 a, i32 b) {  // a*b
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t r;
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return r;
+#else
+    return (i64)a * (i64)b;
+#endif
+}
+BX_HD i64 smad_k(i32 a, uint32_t k, i64 c) {  // a*k + c, k a wave-uniform constant < 2^31 (scalar operand)
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c) : "vcc");
+    return r;
+#else
+    return (i64)a * (i64)k + c;
+#endif
+}
+BX_HD i64 smul_k(i32 a, uint32_t k) {  // a*k
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k) : "vcc");
+    return r;
+#else
+    return (i64)a * (i64)k;
+#endif
+}
+template <int K>
+BX_HD i64 smadc(i32 a, i64 c) {  // a*K + c, K an inline constant
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(a), "v"(c), "n"(K) : "vcc");
+    return r;
+#else
+    return (i64)a * K + c;
+#endif
+}
+template <int K>
+BX_HD i64 smulc(i32 a) {  // a*K
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "n"(K) : "vcc");
+    return r;
+#else
+    return (i64)a * K;
+#endif
+}
+BX_HD i64 add_u32(i64 c, uint32_t k) {  // c + k, k an unsigned wave-uniform word (round constant)
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    asm("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(r) : "s"(k), "v"(c) : "vcc");
+    return r;
+#else
+    return c + (i64)k;
+#endif
+}
+BX_HD i64 umul_k(uint32_t a, uint32_t k) {  // a*k, both unsigned
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k) : "vcc");
     return r;
 #else
-    return mad64(a, k, 0ull);
+    return (i64)((uint64_t)a * (uint64_t)k);
 #endif
 }
-template <uint32_t K1, uint32_t K2, bool HAS_ADD = true>
-BX_HD uint32_t red64k_lazy(uint64_t y, uint32_t add) {
-    BX_ASSERT_BOUND((y >> 39) == 0, "red64k input < 2^39");
-    uint64_t acc = HAS_ADD ? mad64((uint32_t)y, K1, add) : mad64_pinned0((uint32_t)y, K1);
-    acc = mad64_pinned((uint32_t)(y >> 32), K2, acc);
-    const uint32_t m = (uint32_t)acc * NEG_P_INV;
-    return (uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32);
+BX_HD i32 sredc(i64 t) {
+    BX_ASSERT_BOUND(t <= SREDC_MAX && t >= -SREDC_MAX, "sredc operand");
+    const i32 m = (i32)((uint32_t)t * NEG_P_INV);
+    return (i32)(smad_k(m, P, t) >> 32);  // exact: the low word of the sum is zero
+}
+BX_HD i64 iabs64(i64 v) { return v < 0 ? -v : v; }
+
+// magnitude bounds (integers); ub(T) = T/2^32 + P/2 + 1 is the magnitude bound of sredc(t) for |t| <= T
+constexpr i64 ub(i64 T) { return (T >> 32) + (i64)(P / 2) + 1; }
+constexpr i64 B_IN = (i64)P - 1;                      // cells entering the permutation (canonical)
+constexpr i64 B_Y = 112 * ((i64)1 << 31);             // any external-layer output: 112 * max cell magnitude (< 2^31)
+constexpr i64 B_EXT = ub(B_Y + (i64)P);               // redc64s output = S-box input of the external rounds: P/2 + 58
+constexpr i64 B_MIDOUT = ub(((i64)1 << 32) * K1_MID + ((B_Y >> 32) + 1) * (i64)K2_MID + 2 * (i64)P);  // cells entering the internal rounds
+constexpr i64 B_SUMR = ub(((i64)1 << 31) * R2 + 33 * (i64)R3);  // sum_r: balanced low word times R2 (0.791 P)
+// internal-round cells: B -> ub(P * B + B_SUMR + P) has its fixed point at 0.9412 P; 0.945 P is an invariant upper bound
+constexpr i64 B_INT = (i64)((double)P * 0.945);
+static_assert(ub((i64)(P - 1) * B_INT + B_SUMR + (i64)P) <= B_INT && B_MIDOUT <= B_INT, "internal-round bound is not invariant");
+static_assert((i64)(P - 1) * B_INT + B_SUMR + (i64)P <= SREDC_MAX && B_INT * B_INT <= SREDC_MAX, "internal-round products overflow sredc");
+static_assert(24 * B_INT < ((i64)1 << 37), "internal sum");
+
+BX_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
+
+// x^7 * 2^(-6*32) for |x| <= B_INT: four signed products, no subtraction.  |x2| < 0.92 P, |x3|, |x4| < 0.91 P, |x7| < 0.88 P.
+BX_HD i32 sbox7s(i32 x) {
+    BX_ASSERT_BOUND(iabs64(x) <= B_INT, "sbox input");
+    const i32 x2 = sredc(smul(x, x));
+    const i32 x3 = sredc(smul(x2, x));
+    const i32 x4 = sredc(smul(x2, x2));
+    return sredc(smul(x3, x4));
 }
 
-// external layer circ(2*M4, M4, ..., M4) on cells < 2.05423 P (sbox7_wide outputs or canonical inputs), unreduced 64-bit
-// outputs:  w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B):
+// Bare REDC of an external-layer output plus a pre-scaled round constant (canonical, < P):  r == (y + rc) * 2^-32 (mod P),
+// |r| <= B_EXT.  3 instructions (64-bit add, v_mul_lo, v_mad_i64_i32).
+BX_HD i32 redc64s(i64 y, uint32_t rc) {
+    BX_ASSERT_BOUND(iabs64(y) <= B_Y, "external layer output");
+    const i32 r = sredc(add_u32(y, rc));
+    BX_ASSERT_BOUND(iabs64(r) <= B_EXT, "redc64s output");
+    return r;
+}
+
+// REDC with a change of representation:  r == (y * K1 + add) * 2^-32 (mod P),  K2 = K1 * 2^32 mod P,  y = y_hi * 2^32 + y_lo
+// with y_lo unsigned, y_hi signed:  acc = y_lo*K1 + y_hi*K2 + add  in (-(|y_hi|)*P, 2^32 * K1 + ...),  |r| < K1 + P/2 + 60.
+template <uint32_t K1, uint32_t K2, bool HAS_ADD = true>
+BX_HD i32 red64ks(i64 y, uint32_t add) {
+    BX_ASSERT_BOUND(iabs64(y) <= B_Y, "external layer output");
+    static_assert(K1 < (1u << 29) && K2 < P, "correction constant too large for the accumulator bound");
+    i64 acc = umul_k((uint32_t)y, K1);
+    if (HAS_ADD) acc = add_u32(acc, add);
+    return sredc(smad_k((i32)(y >> 32), K2, acc));
+}
+
+// external layer circ(2*M4, M4, ..., M4) on signed cells, unreduced 64-bit outputs:
+//   w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B):
 //   t0 = a+b, t1 = c+d, t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
-// The pair sums do not fit 32 bits and are formed in 64; 4*t + u is one shift-add; y < 230.1 P < 2^39.
-BX_HD void m_ext64w(const uint32_t* s, uint64_t* y) {
+// Rows of the whole layer sum to <= 112, so |y| <= 112 * 2^31 = B_Y for any int32 cells.
+BX_HD void m_ext64s(const i32* s, i64* y) {
 #pragma unroll
     for (int k = 0; k < P2_CELLS; k += 4) {
-        const uint32_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
-        BX_ASSERT_BOUND(a <= B_SBOX_WIDE && b <= B_SBOX_WIDE && c <= B_SBOX_WIDE && d <= B_SBOX_WIDE, "m_ext64w input");
-        const uint64_t t0 = (uint64_t)a + b, t1 = (uint64_t)c + d;
-        const uint64_t t2 = mad64(2u, b, t1), t3 = mad64(2u, d, t0);
-        const uint64_t t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
+        const i32 a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
+        const i64 t0 = smadc<1>(b, smulc<1>(a)), t1 = smadc<1>(d, smulc<1>(c));
+        const i64 t2 = smadc<2>(b, t1), t3 = smadc<2>(d, t0);
+        const i64 t4 = t1 * 4 + t3, t5 = t0 * 4 + t2;
         y[k] = t3 + t5;
         y[k + 1] = t5;
         y[k + 2] = t2 + t4;
         y[k + 3] = t4;
     }
-    uint64_t t[4];
+    i64 t[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         t[j] = y[j];
@@ -158,61 +223,69 @@ BX_HD void m_ext64w(const uint32_t* s, uint64_t* y) {
     for (int i = 0; i < P2_CELLS; ++i) y[i] += t[i & 3];
 }
 
-// internal round helpers (host + device): sum (< 2^37) -> sum * 2^32 mod P, canonical
-BX_HD uint32_t internal_sum_r(uint64_t sum) {
-    BX_ASSERT_BOUND((sum >> 37) == 0, "internal sum < 2^37");
-    uint64_t acc = mad64((uint32_t)sum, R2, 0ull);
-    acc = mad64((uint32_t)(sum >> 32), R3, acc);
-    const uint32_t m = (uint32_t)acc * NEG_P_INV;
-    return fp_reduce((uint32_t)((acc + (uint64_t)m * (uint64_t)P) >> 32));
+// internal rounds: sum of the 24 cells (|sum| < 2^37) -> sum * 2^32 mod P with |result| <= B_SUMR.  The low word is taken
+// BALANCED (in [-2^31, 2^31)) so that its product with R2 stays within +-2^31 R2 and the result within 0.791 P.
+BX_HD i32 internal_sum_rs(i64 sum) {
+    BX_ASSERT_BOUND(iabs64(sum) < ((i64)1 << 37), "internal sum < 2^37");
+    const i32 lo = (i32)(uint32_t)sum;
+    const i32 hi = (i32)(sum >> 32) - (lo >> 31);  // sum = hi * 2^32 + lo with lo signed
+    const i32 r = sredc(smad_k(hi, R3, smul_k(lo, R2)));
+    BX_ASSERT_BOUND(iabs64(r) <= B_SUMR, "sum_r");
+    return r;
+}
+// signed cell -> canonical word (|v| < P)
+BX_HD uint32_t canon(i32 v) {
+    BX_ASSERT_BOUND(iabs64(v) < (i64)P, "canonicalisation input");
+    const uint32_t u = (uint32_t)v;
+    return umin(u, u + P);
 }
 
-// The whole permutation in the exact order and arithmetic of the device kernel (poseidon2.hip: poseidon2_mix); the
-// device version differs only in pinning the internal-round sum to v_mad_u64_u32 and keeping the diagonal in VGPRs.
-// prm: [0,96) | [96,117) | [117,213) round constants * p2_rc_scale(i), [DIAG..DIAG+24) diagonal (Montgomery).
+// The whole permutation in the exact order and arithmetic of the device kernel (poseidon2.hip: poseidon2_mix); the device
+// version differs only in pinning the internal-round sum to v_mad_i64_i32 and keeping the diagonal in VGPRs.
+// prm: [0,96) | [96,117) | [117,213) round constants * p2_rc_scale(i) (canonical), [DIAG..DIAG+24) diagonal (Montgomery).
+// Input and output: canonical Montgomery words.
 template <int DIAG>
-BX_HD void poseidon2_mix_bounded(uint32_t* s, const uint32_t* prm) {
-    uint64_t y[P2_CELLS];
-    m_ext64w(s, y);
-    for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[i]);
+BX_HD void poseidon2_mix_bounded(uint32_t* io, const uint32_t* prm) {
+    i32 s[P2_CELLS];
+    i64 y[P2_CELLS];
+    for (int i = 0; i < P2_CELLS; ++i) {
+        BX_ASSERT_BOUND(io[i] <= B_IN, "canonical input");
+        s[i] = (i32)io[i];
+    }
+    m_ext64s(s, y);
+    for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[i]);
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
-        m_ext64w(s, y);
+        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7s(s[i]);
+        m_ext64s(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[(r + 1) * P2_CELLS + i]);
+            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[(r + 1) * P2_CELLS + i]);
         } else {
-            s[0] = red64k_lazy<K1_MID, K2_MID>(y[0], prm[96]);
-            for (int i = 1; i < P2_CELLS; ++i) s[i] = red64k_lazy<K1_MID, K2_MID, false>(y[i], 0u);
-            for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(s[i] <= B_RED64, "mid transition output");
+            s[0] = red64ks<K1_MID, K2_MID>(y[0], prm[96]);
+            for (int i = 1; i < P2_CELLS; ++i) s[i] = red64ks<K1_MID, K2_MID, false>(y[i], 0u);
+            for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_MIDOUT, "mid transition output");
         }
     }
     const uint32_t* diag = prm + DIAG;
     for (int r = 0; r < 21; ++r) {
-        s[0] = sbox7_bounded(s[0]);
-        uint64_t sum = 0;
-        for (int i = 0; i < P2_CELLS; ++i) sum += s[i];
-        const uint32_t sum_r = internal_sum_r(sum);
+        s[0] = sbox7s(s[0]);
+        i64 sum = smulc<1>(s[0]);
+        for (int i = 1; i < P2_CELLS; ++i) sum = smadc<1>(s[i], sum);
+        const i64 c = smulc<1>(internal_sum_rs(sum));
         if (r < 20) {
-            s[0] = fp_reduce(fp_mad_lazy(diag[0], s[0], sum_r + prm[97 + r]));
-            for (int i = 1; i < P2_CELLS; ++i) {
-                s[i] = fp_mad_lazy(diag[i], s[i], sum_r);
-                BX_ASSERT_BOUND(s[i] <= B_INT_CELL, "internal cell");
-            }
+            s[0] = sredc(smad((i32)diag[0], s[0], add_u32(c, prm[97 + r])));  // next internal constant rides along
+            for (int i = 1; i < P2_CELLS; ++i) s[i] = sredc(smad((i32)diag[i], s[i], c));
         } else {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = fp_reduce(fp_mad_lazy(diag[i], s[i], sum_r + prm[117 + i]));
+            for (int i = 0; i < P2_CELLS; ++i) s[i] = sredc(smad((i32)diag[i], s[i], add_u32(c, prm[117 + i])));
         }
+        for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_INT, "internal cell");
     }
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7_wide(s[i]);
-        m_ext64w(s, y);
+        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7s(s[i]);
+        m_ext64s(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
+            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
         } else {
-            for (int i = 0; i < P2_CELLS; ++i) {
-                const uint32_t v = red64k_lazy<K1_END, K2_END, false>(y[i], 0u);
-                BX_ASSERT_BOUND(v <= B_END, "end transition output");
-                s[i] = fp_reduce(v);
-            }
+            for (int i = 0; i < P2_CELLS; ++i) io[i] = canon(red64ks<K1_END, K2_END, false>(y[i], 0u));
         }
     }
 }

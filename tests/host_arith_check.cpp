@@ -1,7 +1,7 @@
 // host_arith_check.cpp — CPU check of the exact arithmetic source the gfx950 Poseidon2/NTT kernels are built from
 // (boundless_amd/csrc/fp.hpp, poseidon2_arith.hpp), compiled with -DBX_CHECK_BOUNDS so every documented bound and every
 // 64-bit accumulation is asserted while extreme and random operands are pushed through.  Exact results come from
-// unsigned __int128 arithmetic mod P.  Built and run by tests/test_host_arith_cpu.py.
+// (unsigned / signed) __int128 arithmetic mod P.  Built and run by tests/test_host_arith_cpu.py.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,59 +55,76 @@ int main() {
         REQUIRE(r % P == redc_exact(v));
         REQUIRE((u128)r <= v / ((u128)1 << 32) + P);
     }
-    // ---- S-box on the whole admissible input range incl. its upper edge ----
-    const uint64_t sb_in[] = {0, 1, P - 1, P, P + 1, B_RED64 - 1, B_RED64};
-    for (uint64_t x : sb_in) {
-        uint32_t r = sbox7_bounded((uint32_t)x);
-        u128 xr = x % P, e = xr;
-        // Montgomery: sbox7(x) == x^7 * 2^(-6*32)
-        for (int k = 0; k < 6; ++k) e = (u128)redc_exact(e * xr);
-        REQUIRE(r % P == (uint32_t)e && r <= B_SBOX_OUT);
-    }
-    for (int i = 0; i < 500000; ++i) {
-        uint32_t x = (uint32_t)(rnd64() % (B_RED64 + 1));
-        uint32_t r = sbox7_bounded(x);
-        u128 xr = x % P, e = xr;
-        for (int k = 0; k < 6; ++k) e = (u128)redc_exact(e * xr);
-        REQUIRE(r % P == (uint32_t)e);
-    }
-    // ---- the S-box without its final subtraction (external rounds): same residue, documented wide bound ----
-    for (uint64_t x : sb_in) {
-        uint32_t r = sbox7_wide((uint32_t)x);
-        REQUIRE(r % P == sbox7_bounded((uint32_t)x) % P && r <= B_SBOX_WIDE);
-    }
-    for (int i = 0; i < 500000; ++i) {
-        uint32_t x = (uint32_t)(rnd64() % (B_RED64 + 1));
-        uint32_t r = sbox7_wide(x);
-        REQUIRE(r % P == sbox7_bounded(x) % P && r <= B_SBOX_WIDE);
-    }
-    // ---- the returns to 32 bits over y < 2^39 incl. the edges ----
-    const uint64_t ys[] = {0, 1, P, 0xffffffffull, 0x100000000ull, ((uint64_t)1 << 38) - 1, 112ull * B_SBOX_OUT,
-                           ((uint64_t)1 << 39) - 1, 112ull * B_SBOX_WIDE};
-    const uint32_t rinv = cx_rpow(-1);
-    const auto red_mid = [](uint64_t y, uint32_t a) { return red64k_lazy<K1_MID, K2_MID>(y, a); };
-    const auto red_end = [](uint64_t y, uint32_t a) { return red64k_lazy<K1_END, K2_END>(y, a); };
-    for (uint64_t y : ys)
-        for (uint32_t add : edge) {
-            const uint32_t a = add % P;
-            // bare REDC: (y + rc) * R^-1
-            uint32_t r = redc64(y, a);
-            REQUIRE(r % P == (uint32_t)((u128)((y + a) % P) * rinv % P) && r <= B_REDC);
-            // representation-changing REDC: (y * K1 + add) * R^-1
-            uint32_t m = red_mid(y, a), e = red_end(y, a);
-            REQUIRE(m % P == (uint32_t)(((u128)(y % P) * K1_MID + a) % P * rinv % P) && m <= B_RED64);
-            REQUIRE(e % P == (uint32_t)(((u128)(y % P) * K1_END + a) % P * rinv % P) && e <= B_END);
+    // ---- signed Montgomery reduction over its whole contract ----
+    typedef __int128 s128;
+    const auto smod = [](s128 v) { s128 r = v % (s128)P; return (uint32_t)(r < 0 ? r + P : r); };  // exact residue in [0, P)
+    const auto res = [&](i32 v) { return smod((s128)v); };
+    {
+        const i64 ts[] = {0, 1, -1, (i64)P, -(i64)P, SREDC_MAX, -SREDC_MAX, SREDC_MAX - 1, ((i64)1 << 32), -((i64)1 << 32), 0x7fffffffll,
+                          -(i64)0x80000000ll, (i64)0xffffffffll};
+        for (i64 tv : ts) {
+            i32 r = sredc(tv);
+            REQUIRE(res(r) == (uint32_t)((u128)smod((s128)tv) * RINV % P));
+            // t/2^32 - P/2 - 1 <= r <= t/2^32 + P/2 + 1
+            s128 lo = (s128)tv - ((s128)(P / 2 + 1) << 32), hi = (s128)tv + ((s128)(P / 2 + 1) << 32);
+            REQUIRE(((s128)r << 32) >= lo - ((s128)1 << 32) && ((s128)r << 32) <= hi + ((s128)1 << 32));
         }
-    for (int i = 0; i < 500000; ++i) {
-        uint64_t y = rnd64() >> 25;
-        uint32_t a = (uint32_t)(rnd64() % P);
-        REQUIRE(redc64(y, a) % P == (uint32_t)((u128)((y + a) % P) * rinv % P));
-        REQUIRE(red_mid(y, a) % P == (uint32_t)(((u128)(y % P) * K1_MID + a) % P * rinv % P));
+        for (int i = 0; i < 2000000; ++i) {
+            i64 tv = (i64)(rnd64() % (uint64_t)(2 * SREDC_MAX + 1)) - SREDC_MAX;
+            i32 r = sredc(tv);
+            REQUIRE(res(r) == (uint32_t)((u128)smod((s128)tv) * RINV % P));
+            REQUIRE((r < 0 ? -(i64)r : (i64)r) <= ub(tv < 0 ? -tv : tv));
+        }
+    }
+    // ---- S-box on the whole admissible input range incl. both edges ----
+    {
+        const i64 sb_in[] = {0, 1, -1, (i64)P - 1, -((i64)P - 1), B_EXT, -B_EXT, B_INT, -B_INT, B_INT - 1, (i64)(P / 2), -(i64)(P / 2)};
+        const auto want7 = [&](i32 x) {  // x^7 * 2^(-6*32)
+            u128 xr = res(x), e = xr;
+            for (int k = 0; k < 6; ++k) e = (u128)redc_exact(e * xr);
+            return (uint32_t)e;
+        };
+        for (i64 x : sb_in) {
+            if (x > B_INT || x < -B_INT) continue;
+            i32 r = sbox7s((i32)x);
+            REQUIRE(res(r) == want7((i32)x) && (r < 0 ? -(i64)r : (i64)r) < (i64)((double)P * 0.885));
+        }
+        for (int i = 0; i < 500000; ++i) {
+            i32 x = (i32)((i64)(rnd64() % (uint64_t)(2 * B_INT + 1)) - B_INT);
+            REQUIRE(res(sbox7s(x)) == want7(x));
+        }
+    }
+    // ---- the returns to 32 bits over |y| <= B_Y incl. the edges ----
+    {
+        const i64 ys[] = {0, 1, -1, (i64)P, -(i64)P, 0xffffffffll, -(i64)0xffffffffll, 0x100000000ll, -0x100000000ll, B_Y, -B_Y, B_Y - 1,
+                          0x7fffffffll, 0x80000000ll, -0x80000000ll, 0x17fffffffll, -0x180000001ll};
+        const auto red_mid = [](i64 y, uint32_t a) { return red64ks<K1_MID, K2_MID>(y, a); };
+        const auto red_end = [](i64 y, uint32_t a) { return red64ks<K1_END, K2_END>(y, a); };
+        const auto mag = [](i32 v) { return v < 0 ? -(i64)v : (i64)v; };
+        for (i64 y : ys)
+            for (uint32_t add : edge) {
+                const uint32_t a = add % P;
+                const uint32_t yr = smod((s128)y);
+                i32 r = redc64s(y, a);
+                REQUIRE(res(r) == (uint32_t)((u128)((yr + (uint64_t)a) % P) * RINV % P) && mag(r) <= B_EXT);
+                i32 m = red_mid(y, a), e = red_end(y, a);
+                REQUIRE(res(m) == (uint32_t)(((u128)yr * K1_MID + a) % P * RINV % P) && mag(m) <= B_MIDOUT);
+                REQUIRE(res(e) == (uint32_t)(((u128)yr * K1_END + a) % P * RINV % P) && mag(e) < (i64)P);
+                REQUIRE(canon(e) == res(e));
+            }
+        for (int i = 0; i < 500000; ++i) {
+            i64 y = (i64)(rnd64() % (uint64_t)(2 * B_Y + 1)) - B_Y;
+            uint32_t a = (uint32_t)(rnd64() % P);
+            const uint32_t yr = smod((s128)y);
+            REQUIRE(res(redc64s(y, a)) == (uint32_t)((u128)((yr + (uint64_t)a) % P) * RINV % P));
+            REQUIRE(res(red_mid(y, a)) == (uint32_t)(((u128)yr * K1_MID + a) % P * RINV % P));
+            REQUIRE(canon(red_end(y, 0)) == (uint32_t)((u128)yr * K1_END % P * RINV % P));
+        }
     }
     // the representation constants are what the exponent bookkeeping says (R = 2^32 mod P)
     {
         const auto rp = [](int64_t e) { return cx_rpow(e); };
-        REQUIRE(cx_mul(rp(1), rp(-1)) == 1 && rp(1) == MONT_ONE && rp(2) == R2 && rp(3) == R3);
+        REQUIRE(cx_mul(rp(1), rp(-1)) == 1 && rp(1) == MONT_ONE && rp(2) == R2 && rp(3) == R3 && rp(-1) == RINV);
         int64_t e = 1;                      // canonical Montgomery input
         e -= 1;                             // initial layer, bare REDC
         for (int r = 0; r < 3; ++r) e = 7 * e - 6 - 1;  // S-box, layer, bare REDC
@@ -121,24 +138,31 @@ int main() {
         REQUIRE(p2_rc_scale(96) == R2 && p2_rc_scale(117) == R2 && p2_rc_scale(141) == rp(1) && p2_rc_scale(165) == rp(-6) &&
                 p2_rc_scale(189) == rp(-55));
     }
-    // ---- the external layer (cells up to 2.05423 P) at its extremes ----
+    // ---- the external layer on extreme int32 cells ----
     {
-        uint32_t s[24];
-        uint64_t y[24];
+        i32 s[24];
+        i64 y[24];
         const int M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
-        for (int t = 0; t < 20001; ++t) {
-            for (int i = 0; i < 24; ++i) s[i] = t == 0 ? (uint32_t)B_SBOX_WIDE : (uint32_t)(rnd64() % (B_SBOX_WIDE + 1));
-            m_ext64w(s, y);
+        for (int t = 0; t < 20003; ++t) {
+            for (int i = 0; i < 24; ++i)
+                s[i] = t == 0 ? 0x7fffffff : t == 1 ? (i32)0x80000000 : t == 2 ? ((i & 1) ? 0x7fffffff : (i32)0x80000000) : (i32)(uint32_t)rnd64();
+            m_ext64s(s, y);
             for (int i = 0; i < 24; ++i) {
-                u128 want = 0;
-                for (int j = 0; j < 24; ++j) want += (u128)M4[i & 3][j & 3] * (i / 4 == j / 4 ? 2 : 1) * s[j];
-                REQUIRE((u128)y[i] == want && (y[i] >> 39) == 0);
+                s128 want = 0;
+                for (int j = 0; j < 24; ++j) want += (s128)(M4[i & 3][j & 3] * (i / 4 == j / 4 ? 2 : 1)) * s[j];
+                REQUIRE((s128)y[i] == want && (y[i] < 0 ? -y[i] : y[i]) <= B_Y);
             }
         }
     }
     // ---- internal-round sum_r at its edges ----
-    for (uint64_t sum : {(uint64_t)0, (uint64_t)P, (uint64_t)0xffffffffull, (uint64_t)B_SBOX_OUT + 23 * B_INT_CELL, ((uint64_t)1 << 37) - 1})
-        REQUIRE(internal_sum_r(sum) == (uint32_t)((u128)(sum % P) * (((u128)1 << 32) % P) % P));
+    for (i64 sum : {(i64)0, (i64)P, -(i64)P, (i64)0xffffffffll, (i64)0x7fffffffll, (i64)0x80000000ll, -(i64)0x80000000ll, -(i64)0x80000001ll,
+                    24 * B_INT, -24 * B_INT, ((i64)1 << 37) - 1, -(((i64)1 << 37) - 1)})
+        REQUIRE(res(internal_sum_rs(sum)) == (uint32_t)((u128)smod((s128)sum) * (((u128)1 << 32) % P) % P));
+    for (int i = 0; i < 500000; ++i) {
+        i64 sum = (i64)(rnd64() >> 26) - ((i64)1 << 37);
+        if (sum <= -((i64)1 << 37)) continue;
+        REQUIRE(res(internal_sum_rs(sum)) == (uint32_t)((u128)smod((s128)sum) * (((u128)1 << 32) % P) % P));
+    }
     // ---- the whole permutation, device order and arithmetic, vs the plain canonical implementation ----
     {
         HostPoseidon2 ref;
