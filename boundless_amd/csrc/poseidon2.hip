@@ -45,15 +45,6 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 //                                      point at 0.9412 P, 0.945 P is invariant; |sum| < 22.7 P < 2^37; |sum_r| < 0.791 P thanks to
 //                                      the balanced low word of sum.
 // ---------------------------------------------------------------------------------------------------------------
-// Loop-carried cells must stay 32-bit values.  Without this hipcc widens the 24 loop phis of the external rounds to i64
-// (every use is an extension into a 64-bit multiply-add), loses track of the high words across the back edge and emits full
-// 64x32 / 64x64-bit products for the first two S-box multiplications: 5 extra instructions per cell and round (~10 % of the
-// permutation).  An empty asm with a 32-bit register constraint costs nothing and pins the width.
-__device__ __forceinline__ void pin32(i32* s) {
-#pragma unroll
-    for (int i = 0; i < 24; ++i) asm("" : "+v"(s[i]));
-}
-
 // Device parameter table (round constants scaled by p2_rc_scale(i) so that they can ride in a REDC accumulator of the
 // round's representation): [0,96) external rounds 0-3 | [96,117) internal rounds | [117,213) external rounds 4-7 |
 // [216,240) internal diagonal (plain Montgomery form, used as a multiplier; 16-byte aligned).
@@ -65,24 +56,17 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
     for (int i = 0; i < CELLS; ++i) s[i] = (i32)io[i];
     // initial external layer; round-0 constants ride in the reduction
     m_ext64s(s, y);
-#pragma unroll
-    for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], prm[i]);
+    redc64s_all(y, prm, s);
     // external rounds 0..3: S-box, layer, reduction with the NEXT round's constants (after round 3 only cell 0 has one:
     // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        pin32(s);
-#pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7s(s[i]);
+        sbox7s_n<CELLS>(s);
         m_ext64s(s, y);
         if (r < RF_HALF - 1) {
-            const uint32_t* rc = prm + (r + 1) * CELLS;
-#pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], rc[i]);
+            redc64s_all(y, prm + (r + 1) * CELLS, s);
         } else {  // back to the Montgomery representation for the internal rounds
-            s[0] = red64ks<K1_MID, K2_MID>(y[0], prm[96]);
-#pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = red64ks<K1_MID, K2_MID, false>(y[i], 0u);
+            red64ks_all<K1_MID, K2_MID, true>(y, prm[96], s);
         }
     }
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
@@ -104,36 +88,21 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
         }
     }
 #pragma unroll 1
-    for (int r = 0; r < RP; ++r) {
-        s[0] = sbox7s(s[0]);
-        i64 sum = smulc<1>(s[0]);
-#pragma unroll
-        for (int i = 1; i < CELLS; ++i) sum = smadc<1>(s[i], sum);
-        const i64 c = smulc<1>(internal_sum_rs(sum));
-        if (r < RP - 1) {
-            s[0] = sredc(smad(diag[0], s[0], add_u32(c, prm[97 + r])));  // next internal constant rides along
-#pragma unroll
-            for (int i = 1; i < CELLS; ++i) s[i] = sredc(smad(diag[i], s[i], c));
-        } else {
-            const uint32_t* rc = prm + 117;  // external round 4's constants
-#pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = sredc(smad(diag[i], s[i], add_u32(c, rc[i])));
-        }
+    for (int r = 0; r < RP - 1; ++r) {
+        internal_round<false>(s, diag, prm + 97 + r);
     }
+    internal_round<true>(s, diag, prm + 117);  // external round 4's constants ride in the last internal round
     // external rounds 4..7
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        pin32(s);
-#pragma unroll
-        for (int i = 0; i < CELLS; ++i) s[i] = sbox7s(s[i]);
+        sbox7s_n<CELLS>(s);
         m_ext64s(s, y);
         if (r < RF_HALF - 1) {
-            const uint32_t* rc = prm + 117 + (r + 1) * CELLS;
-#pragma unroll
-            for (int i = 0; i < CELLS; ++i) s[i] = redc64s(y[i], rc[i]);
+            redc64s_all(y, prm + 117 + (r + 1) * CELLS, s);
         } else {
+            red64ks_all<K1_END, K2_END, false>(y, 0u, s);
 #pragma unroll
-            for (int i = 0; i < CELLS; ++i) io[i] = canon(red64ks<K1_END, K2_END, false>(y[i], 0u));  // canonical Montgomery words leave the permutation
+            for (int i = 0; i < CELLS; ++i) io[i] = canon(s[i]);  // canonical Montgomery words leave the permutation
         }
     }
 }

@@ -70,85 +70,120 @@ constexpr i64 SREDC_MAX = ((i64)0x7fffffff - (i64)(P / 2) - 2) * ((i64)1 << 32);
 // The multiply-add primitives.  On the device each one is a single pinned instruction: written as plain C, hipcc widens the
 // loop-carried cells to i64, forgets that they are sign-extended 32-bit values and emulates 64x64-bit products
 // (v_mad_u64_u32 + 2 v_mul_lo + v_add3 per product), or inserts v_ashrrev/v_mov pairs to build sign-extended register
-// pairs for its shift-add forms.  vcc receives the (unused) carry-out.  The host versions are the definitions.
-BX_HD i64 smad(i32 a, i32 b, i64 c) {  // a*b + c, all signed
+// pairs for its shift-add forms.  The statements are volatile so that the stage-wise source order below (independent chains
+// interleaved) survives the scheduler, which otherwise re-serialises each cell's chain to save registers.
+// `alt` (mod 4) picks one of four scratch SGPR pairs for the unused carry-out: hipcc separates adjacent inline-asm
+// statements whose register operands overlap with an s_nop (an assumed forwarding hazard), and an s_nop after every
+// multiply-add costs ~18 % at the kernel's 3 waves per SIMD (profiles/r01_microbench3_mad_forms.jsonl).  Rotating the pair
+// and keeping dependent statements a stage apart removes most of them (467 -> 198 in hash_fold); the rest are spread thinly
+// enough that removing them is below measurement noise.
+// The host versions are the definitions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BX_MAD_ASM(op, args, ...)                                                                  \
+    do {                                                                                           \
+        switch (alt & 3) {                                                                         \
+            case 0: asm volatile(op " %0, s[40:41], " args : "=v"(r) : __VA_ARGS__ : "s40", "s41"); break; \
+            case 1: asm volatile(op " %0, s[42:43], " args : "=v"(r) : __VA_ARGS__ : "s42", "s43"); break; \
+            case 2: asm volatile(op " %0, s[44:45], " args : "=v"(r) : __VA_ARGS__ : "s44", "s45"); break; \
+            default: asm volatile(op " %0, s[46:47], " args : "=v"(r) : __VA_ARGS__ : "s46", "s47"); break; \
+        }                                                                                          \
+    } while (0)
+#endif
+BX_HD i64 smad(i32 a, i32 b, i64 c, int alt = 0) {  // a*b + c, all signed
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %2, %3", "v"(a), "v"(b), "v"(c));
     return r;
 #else
+    (void)alt;
     return (i64)a * (i64)b + c;
 #endif
 }
-BX_HD i64 smul(i32 a, i32 b) {  // a*b
+BX_HD i64 smul(i32 a, i32 b, int alt = 0) {  // a*b
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "v"(b));
     return r;
 #else
+    (void)alt;
     return (i64)a * (i64)b;
 #endif
 }
-BX_HD i64 smad_k(i32 a, uint32_t k, i64 c) {  // a*k + c, k a wave-uniform constant < 2^31 (scalar operand)
+BX_HD i64 smad_k(i32 a, uint32_t k, i64 c, int alt = 0) {  // a*k + c, k a wave-uniform constant < 2^31 (scalar operand)
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %2, %3", "v"(a), "s"(k), "v"(c));
     return r;
 #else
+    (void)alt;
     return (i64)a * (i64)k + c;
 #endif
 }
-BX_HD i64 smul_k(i32 a, uint32_t k) {  // a*k
+BX_HD i64 smul_k(i32 a, uint32_t k, int alt = 0) {  // a*k
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "s"(k));
     return r;
 #else
+    (void)alt;
     return (i64)a * (i64)k;
 #endif
 }
 template <int K>
-BX_HD i64 smadc(i32 a, i64 c) {  // a*K + c, K an inline constant
+BX_HD i64 smadc(i32 a, i64 c, int alt = 0) {  // a*K + c, K an inline constant
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %3, %2" : "=v"(r) : "v"(a), "v"(c), "n"(K) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %3, %2", "v"(a), "v"(c), "n"(K));
     return r;
 #else
+    (void)alt;
     return (i64)a * K + c;
 #endif
 }
 template <int K>
-BX_HD i64 smulc(i32 a) {  // a*K
+BX_HD i64 smulc(i32 a, int alt = 0) {  // a*K
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "n"(K) : "vcc");
+    BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "n"(K));
     return r;
 #else
+    (void)alt;
     return (i64)a * K;
 #endif
 }
-BX_HD i64 add_u32(i64 c, uint32_t k) {  // c + k, k an unsigned wave-uniform word (round constant)
+BX_HD i64 add_u32(i64 c, uint32_t k, int alt = 0) {  // c + k, k an unsigned wave-uniform word (round constant)
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(r) : "s"(k), "v"(c) : "vcc");
+    BX_MAD_ASM("v_mad_u64_u32", "%1, 1, %2", "s"(k), "v"(c));
     return r;
 #else
+    (void)alt;
     return c + (i64)k;
 #endif
 }
-BX_HD i64 umul_k(uint32_t a, uint32_t k) {  // a*k, both unsigned
+BX_HD i64 umul_k(uint32_t a, uint32_t k, int alt = 0) {  // a*k, both unsigned
 #if defined(__HIP_DEVICE_COMPILE__)
     i64 r;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k) : "vcc");
+    BX_MAD_ASM("v_mad_u64_u32", "%1, %2, 0", "v"(a), "s"(k));
     return r;
 #else
+    (void)alt;
     return (i64)((uint64_t)a * (uint64_t)k);
 #endif
 }
-BX_HD i32 sredc(i64 t) {
+BX_HD i32 mont_m(i64 t) {  // m = -t * P^-1 mod 2^32 as a signed word (pinned so that a stage's 24 low products stay together)
+#if defined(__HIP_DEVICE_COMPILE__)
+    i32 m;
+    asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"((uint32_t)t), "s"(NEG_P_INV));
+    return m;
+#else
+    return (i32)((uint32_t)t * NEG_P_INV);
+#endif
+}
+BX_HD i32 sredc(i64 t, int alt = 0) {
     BX_ASSERT_BOUND(t <= SREDC_MAX && t >= -SREDC_MAX, "sredc operand");
-    const i32 m = (i32)((uint32_t)t * NEG_P_INV);
-    return (i32)(smad_k(m, P, t) >> 32);  // exact: the low word of the sum is zero
+    const i32 m = mont_m(t);
+    return (i32)(smad_k(m, P, t, alt) >> 32);  // exact: the low word of the sum is zero
 }
 BX_HD i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
@@ -167,6 +202,21 @@ static_assert(24 * B_INT < ((i64)1 << 37), "internal sum");
 
 BX_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * (uint64_t)b + c; }
 
+// N independent reductions, issued stage by stage (all low products, then all corrections): the pinned primitives are
+// opaque to the compiler's scheduler, so independent chains are interleaved here, in the source, to keep dependent
+// multiply-adds of one cell apart.
+template <int N>
+BX_HD void sredc_n(const i64* t, i32* r) {
+    i32 m[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        BX_ASSERT_BOUND(t[i] <= SREDC_MAX && t[i] >= -SREDC_MAX, "sredc operand");
+        m[i] = mont_m(t[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = (i32)(smad_k(m[i], P, t[i], i & 3) >> 32);
+}
+
 // x^7 * 2^(-6*32) for |x| <= B_INT: four signed products, no subtraction.  |x2| < 0.92 P, |x3|, |x4| < 0.91 P, |x7| < 0.88 P.
 BX_HD i32 sbox7s(i32 x) {
     BX_ASSERT_BOUND(iabs64(x) <= B_INT, "sbox input");
@@ -174,6 +224,28 @@ BX_HD i32 sbox7s(i32 x) {
     const i32 x3 = sredc(smul(x2, x));
     const i32 x4 = sredc(smul(x2, x2));
     return sredc(smul(x3, x4));
+}
+// the same on N cells at once, stage-wise
+template <int N>
+BX_HD void sbox7s_n(i32* x) {
+    i64 t[N], u[N];
+    i32 x2[N], x3[N], x4[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        BX_ASSERT_BOUND(iabs64(x[i]) <= B_INT, "sbox input");
+        t[i] = smul(x[i], x[i], i & 3);
+    }
+    sredc_n<N>(t, x2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        t[i] = smul(x2[i], x[i], 2 * i);
+        u[i] = smul(x2[i], x2[i], 2 * i + 1);
+    }
+    sredc_n<N>(t, x3);
+    sredc_n<N>(u, x4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = smul(x3[i], x4[i], i & 3);
+    sredc_n<N>(t, x);
 }
 
 // Bare REDC of an external-layer output plus a pre-scaled round constant (canonical, < P):  r == (y + rc) * 2^-32 (mod P),
@@ -183,6 +255,19 @@ BX_HD i32 redc64s(i64 y, uint32_t rc) {
     const i32 r = sredc(add_u32(y, rc));
     BX_ASSERT_BOUND(iabs64(r) <= B_EXT, "redc64s output");
     return r;
+}
+
+// the 24 bare reductions of a layer, stage-wise; rc = 24 pre-scaled constants
+BX_HD void redc64s_all(const i64* y, const uint32_t* rc, i32* s) {
+    i64 acc[P2_CELLS];
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) {
+        BX_ASSERT_BOUND(iabs64(y[i]) <= B_Y, "external layer output");
+        acc[i] = add_u32(y[i], rc[i], i & 3);
+    }
+    sredc_n<P2_CELLS>(acc, s);
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_EXT, "redc64s output");
 }
 
 // REDC with a change of representation:  r == (y * K1 + add) * 2^-32 (mod P),  K2 = K1 * 2^32 mod P,  y = y_hi * 2^32 + y_lo
@@ -195,22 +280,50 @@ BX_HD i32 red64ks(i64 y, uint32_t add) {
     if (HAS_ADD) acc = add_u32(acc, add);
     return sredc(smad_k((i32)(y >> 32), K2, acc));
 }
+// the 24 representation-changing reductions of a layer, stage-wise; only cell 0 may carry an addend
+template <uint32_t K1, uint32_t K2, bool HAS_ADD0>
+BX_HD void red64ks_all(const i64* y, uint32_t add0, i32* s) {
+    static_assert(K1 < (1u << 29) && K2 < P, "correction constant too large for the accumulator bound");
+    i64 acc[P2_CELLS];
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) {
+        BX_ASSERT_BOUND(iabs64(y[i]) <= B_Y, "external layer output");
+        acc[i] = umul_k((uint32_t)y[i], K1, i & 3);
+    }
+    if (HAS_ADD0) acc[0] = add_u32(acc[0], add0, 0);
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) acc[i] = smad_k((i32)(y[i] >> 32), K2, acc[i], (i + 1) & 3);
+    sredc_n<P2_CELLS>(acc, s);
+}
 
 // external layer circ(2*M4, M4, ..., M4) on signed cells, unreduced 64-bit outputs:
 //   w_k = M4 * x_k,  T = sum_k w_k,  y_k = w_k + T.   M4 by the Poseidon2 addition chain (appendix B):
 //   t0 = a+b, t1 = c+d, t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
 // Rows of the whole layer sum to <= 112, so |y| <= 112 * 2^31 = B_Y for any int32 cells.
 BX_HD void m_ext64s(const i32* s, i64* y) {
+    i64 t0[6], t1[6], t2[6], t3[6];  // the six 4-cell groups advance together (see sredc_n)
 #pragma unroll
-    for (int k = 0; k < P2_CELLS; k += 4) {
-        const i32 a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
-        const i64 t0 = smadc<1>(b, smulc<1>(a)), t1 = smadc<1>(d, smulc<1>(c));
-        const i64 t2 = smadc<2>(b, t1), t3 = smadc<2>(d, t0);
-        const i64 t4 = t1 * 4 + t3, t5 = t0 * 4 + t2;
-        y[k] = t3 + t5;
-        y[k + 1] = t5;
-        y[k + 2] = t2 + t4;
-        y[k + 3] = t4;
+    for (int g = 0; g < 6; ++g) {
+        t0[g] = smulc<1>(s[4 * g], 2 * g);
+        t1[g] = smulc<1>(s[4 * g + 2], 2 * g + 1);
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        t0[g] = smadc<1>(s[4 * g + 1], t0[g], 2 * g);
+        t1[g] = smadc<1>(s[4 * g + 3], t1[g], 2 * g + 1);
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        t2[g] = smadc<2>(s[4 * g + 1], t1[g], 2 * g);
+        t3[g] = smadc<2>(s[4 * g + 3], t0[g], 2 * g + 1);
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const i64 t4 = t1[g] * 4 + t3[g], t5 = t0[g] * 4 + t2[g];
+        y[4 * g] = t3[g] + t5;
+        y[4 * g + 1] = t5;
+        y[4 * g + 2] = t2[g] + t4;
+        y[4 * g + 3] = t4;
     }
     i64 t[4];
 #pragma unroll
@@ -233,6 +346,61 @@ BX_HD i32 internal_sum_rs(i64 sum) {
     BX_ASSERT_BOUND(iabs64(r) <= B_SUMR, "sum_r");
     return r;
 }
+// one internal round on all cells: s[0] <- S-box, sum, s[i] <- sredc(diag[i] * s[i] + sum_r [+ rc]).
+// RC_ALL = false: only cell 0 gets the constant rc[0]; true: every cell i gets rc[i] (the last internal round).
+template <bool RC_ALL>
+BX_HD void internal_round(i32* s, const i32* diag, const uint32_t* rc) {
+    // The S-box of cell 0 is one dependent chain of 12 instructions; the sum of the other 23 cells does not depend on it and
+    // is issued in between (two partial sums), so that no two adjacent statements depend on each other.  The trailing
+    // argument of each primitive is its position in the instruction stream (carry-out pair rotation).
+    BX_ASSERT_BOUND(iabs64(s[0]) <= B_INT, "sbox input");
+    i64 pa = smulc<1>(s[1], 0), pb = smulc<1>(s[2], 1);
+    i64 t = smul(s[0], s[0], 2);                                    // x^2
+    pa = smadc<1>(s[3], pa, 3);
+    i32 m = mont_m(t);
+    pb = smadc<1>(s[4], pb, 0);
+    const i32 x2 = (i32)(smad_k(m, P, t, 1) >> 32);
+    pa = smadc<1>(s[5], pa, 2);
+    t = smul(x2, s[0], 3);                                          // x^3
+    pb = smadc<1>(s[6], pb, 0);
+    i64 u = smul(x2, x2, 1);                                        // x^4
+    pa = smadc<1>(s[7], pa, 2);
+    m = mont_m(t);
+    pb = smadc<1>(s[8], pb, 3);
+    i32 m2 = mont_m(u);
+    pa = smadc<1>(s[9], pa, 0);
+    const i32 x3 = (i32)(smad_k(m, P, t, 1) >> 32);
+    pb = smadc<1>(s[10], pb, 2);
+    const i32 x4 = (i32)(smad_k(m2, P, u, 3) >> 32);
+    pa = smadc<1>(s[11], pa, 0);
+    t = smul(x3, x4, 1);                                            // x^7
+    pb = smadc<1>(s[12], pb, 2);
+    pa = smadc<1>(s[13], pa, 3);
+    m = mont_m(t);
+    pb = smadc<1>(s[14], pb, 0);
+    pa = smadc<1>(s[15], pa, 1);
+    s[0] = (i32)(smad_k(m, P, t, 2) >> 32);
+#pragma unroll
+    for (int i = 16; i < P2_CELLS; ++i) {
+        if (i & 1) pa = smadc<1>(s[i], pa, i + 3);
+        else pb = smadc<1>(s[i], pb, i + 3);
+    }
+    pa = smadc<1>(s[0], pa, 3);
+    const i64 sum = pa + pb;
+    const i64 c = smulc<1>(internal_sum_rs(sum), 1);
+    i64 tt[P2_CELLS];
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) {
+        if (RC_ALL || i == 0)
+            tt[i] = smad(diag[i], s[i], add_u32(c, rc[i], 2 * i + 2), 2 * i + 3);
+        else
+            tt[i] = smad(diag[i], s[i], c, i + 2);
+    }
+    sredc_n<P2_CELLS>(tt, s);
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_INT, "internal cell");
+}
+
 // signed cell -> canonical word (|v| < P)
 BX_HD uint32_t canon(i32 v) {
     BX_ASSERT_BOUND(iabs64(v) < (i64)P, "canonicalisation input");
@@ -246,46 +414,35 @@ BX_HD uint32_t canon(i32 v) {
 // Input and output: canonical Montgomery words.
 template <int DIAG>
 BX_HD void poseidon2_mix_bounded(uint32_t* io, const uint32_t* prm) {
-    i32 s[P2_CELLS];
+    i32 s[P2_CELLS], diag[P2_CELLS];
     i64 y[P2_CELLS];
     for (int i = 0; i < P2_CELLS; ++i) {
         BX_ASSERT_BOUND(io[i] <= B_IN, "canonical input");
         s[i] = (i32)io[i];
+        diag[i] = (i32)prm[DIAG + i];
     }
     m_ext64s(s, y);
-    for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[i]);
+    redc64s_all(y, prm, s);
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7s(s[i]);
+        sbox7s_n<P2_CELLS>(s);
         m_ext64s(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[(r + 1) * P2_CELLS + i]);
+            redc64s_all(y, prm + (r + 1) * P2_CELLS, s);
         } else {
-            s[0] = red64ks<K1_MID, K2_MID>(y[0], prm[96]);
-            for (int i = 1; i < P2_CELLS; ++i) s[i] = red64ks<K1_MID, K2_MID, false>(y[i], 0u);
+            red64ks_all<K1_MID, K2_MID, true>(y, prm[96], s);
             for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_MIDOUT, "mid transition output");
         }
     }
-    const uint32_t* diag = prm + DIAG;
-    for (int r = 0; r < 21; ++r) {
-        s[0] = sbox7s(s[0]);
-        i64 sum = smulc<1>(s[0]);
-        for (int i = 1; i < P2_CELLS; ++i) sum = smadc<1>(s[i], sum);
-        const i64 c = smulc<1>(internal_sum_rs(sum));
-        if (r < 20) {
-            s[0] = sredc(smad((i32)diag[0], s[0], add_u32(c, prm[97 + r])));  // next internal constant rides along
-            for (int i = 1; i < P2_CELLS; ++i) s[i] = sredc(smad((i32)diag[i], s[i], c));
-        } else {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = sredc(smad((i32)diag[i], s[i], add_u32(c, prm[117 + i])));
-        }
-        for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_INT, "internal cell");
-    }
+    for (int r = 0; r < 20; ++r) internal_round<false>(s, diag, prm + 97 + r);
+    internal_round<true>(s, diag, prm + 117);
     for (int r = 0; r < 4; ++r) {
-        for (int i = 0; i < P2_CELLS; ++i) s[i] = sbox7s(s[i]);
+        sbox7s_n<P2_CELLS>(s);
         m_ext64s(s, y);
         if (r < 3) {
-            for (int i = 0; i < P2_CELLS; ++i) s[i] = redc64s(y[i], prm[117 + (r + 1) * P2_CELLS + i]);
+            redc64s_all(y, prm + 117 + (r + 1) * P2_CELLS, s);
         } else {
-            for (int i = 0; i < P2_CELLS; ++i) io[i] = canon(red64ks<K1_END, K2_END, false>(y[i], 0u));
+            red64ks_all<K1_END, K2_END, false>(y, 0u, s);
+            for (int i = 0; i < P2_CELLS; ++i) io[i] = canon(s[i]);
         }
     }
 }
