@@ -39,23 +39,36 @@ struct R16Args {
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t i) { return i + (i >> 4); }
 
-template <bool INV>
+// Butterflies.  Canonical in, canonical out by default; two conditional subtractions per butterfly can be dropped where the
+// value is consumed by a twiddle product next (a lazy Montgomery product accepts operands < 2P: 2P * P < 2.42 P^2):
+//   DIF (inverse):  b' = (a - b) * w   — the difference feeds the product directly: a - b + P in (0, 2P), no v_min;
+//   DIT (forward):  an output that is a "b" (multiplied) operand of the next stage of the same register-resident step may
+//                   stay in [0, 2P): a + t without the subtraction, a - t + P without the v_min.  LA / LB say which.
+template <bool INV, bool LA = false, bool LB = false>
 __device__ __forceinline__ void bfly_tw(uint32_t& a, uint32_t& b, uint32_t w) {
     if (!INV) {
-        uint32_t t = fp_mul(b, w);
-        b = fp_sub(a, t);
-        a = fp_add(a, t);
+        const uint32_t t = fp_mul(b, w);  // b < 2P allowed
+        const uint32_t d = a - t;
+        b = LB ? d + P : umin(d, d + P);
+        const uint32_t u = a + t;
+        a = LA ? u : umin(u, u - P);
     } else {
-        uint32_t u = fp_add(a, b);
-        b = fp_mul(fp_sub(a, b), w);
+        const uint32_t u = fp_add(a, b);
+        b = fp_mul(a - b + P, w);
         a = u;
     }
 }
+template <bool LA = false, bool LB = false>
 __device__ __forceinline__ void bfly_one(uint32_t& a, uint32_t& b) {
-    uint32_t u = fp_add(a, b);
-    b = fp_sub(a, b);
-    a = u;
+    const uint32_t u = a + b, d = a - b;
+    a = LA ? u : umin(u, u - P);
+    b = LB ? d + P : umin(d, d + P);
 }
+// DIT stage with half = 2^(k-1) inside a K-stage step: may the outputs of butterfly (j, j + half) stay lazy?  Both outputs
+// are "b" operands of stage k+1 iff bit 2*half of j is set.  With a trivial (w = 1) first twiddle group (S0ZERO) the b
+// operand of a next-stage butterfly with jj' = 0 is added, not multiplied, and must be canonical: that is output j of a
+// butterfly that is itself in the trivial group (jj = 0); output j + half never lands there.
+#define BX_DIT_LAZY_B(last, j, half) (!(last) && (((j) & (2 * (half))) != 0))
 
 // the K stages of one step on the thread's 16 registers
 template <int K, bool INV, bool S0ZERO, int SKIP>
@@ -76,11 +89,17 @@ __device__ __forceinline__ void step_compute(uint32_t (&x)[16], const uint32_t* 
             for (int jj = 0; jj < half; ++jj) {
                 if (S0ZERO && jj == 0) {
 #pragma unroll
-                    for (int j = 0; j < E; j += 2 * half) bfly_one(xu[j], xu[j + half]);
+                    for (int j = 0; j < E; j += 2 * half) {
+                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_one<false, true>(xu[j], xu[j + half]);
+                        else bfly_one(xu[j], xu[j + half]);
+                    }
                 } else {
                     const uint32_t wv = ltw[(1u << (s0 + k - 1)) + lo + ((uint32_t)jj << s0)];
 #pragma unroll
-                    for (int j = jj; j < E; j += 2 * half) bfly_tw<INV>(xu[j], xu[j + half], wv);
+                    for (int j = jj; j < E; j += 2 * half) {
+                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_tw<INV, true, true>(xu[j], xu[j + half], wv);
+                        else bfly_tw<INV>(xu[j], xu[j + half], wv);
+                    }
                 }
             }
         }
@@ -124,11 +143,17 @@ __device__ __forceinline__ void step_compute_tw(uint32_t (&x)[16], const uint32_
             for (int jj = 0; jj < half; ++jj) {
                 if (S0ZERO && jj == 0) {
 #pragma unroll
-                    for (int j = 0; j < E; j += 2 * half) bfly_one(xu[j], xu[j + half]);
+                    for (int j = 0; j < E; j += 2 * half) {
+                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_one<false, true>(xu[j], xu[j + half]);
+                        else bfly_one(xu[j], xu[j + half]);
+                    }
                 } else {
                     const uint32_t wv = tw[w * E + half - 1 + jj];
 #pragma unroll
-                    for (int j = jj; j < E; j += 2 * half) bfly_tw<INV>(xu[j], xu[j + half], wv);
+                    for (int j = jj; j < E; j += 2 * half) {
+                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_tw<INV, true, true>(xu[j], xu[j + half], wv);
+                        else bfly_tw<INV>(xu[j], xu[j + half], wv);
+                    }
                 }
             }
         }
