@@ -450,6 +450,7 @@ __global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
 // workgroup: the twist slice of the tile and the twiddles of all three steps depend only on the tile, so they are loaded
 // once and reused for `a.cpw` consecutive columns.  Cuts the twist re-reads (one 2^m-word table per column otherwise:
 // measured 0.9 GB fetched per launch for 0.2 GB of input) and ~60 address/load instructions per column.
+// 158 VGPRs = 3 waves per SIMD; forcing 4 (128 VGPRs, 34 spill instructions) or 5 measured 3 % / 18 % slower.
 template <int SKIP>
 __global__ __launch_bounds__(256) void ntt_passA_fwd12_multi_kernel(R16Args a) {
     extern __shared__ uint32_t lds[];
