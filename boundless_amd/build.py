@@ -16,7 +16,7 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libbx_hip_hal.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
 
 

@@ -34,7 +34,7 @@ constexpr int DIAG_OFF = 216;  // diagonal starts 16-byte aligned in the device 
 //     constants are stored pre-scaled, and only the two layers that must hand back Montgomery form (before the internal
 //     rounds, and at the end) multiply by a correction constant (poseidon2_arith.hpp: representation tracking).
 // Results are congruent mod P at every step and the words that leave the permutation are canonical, so the output is
-// bit-identical to the reduce-everywhere form (7.3 k VALU instructions per permutation by PMC, down from ~14.5 k).
+// bit-identical to the reduce-everywhere form (6.6 k VALU instructions per permutation by PMC, down from ~14.5 k).
 //
 // Magnitude bounds (rho = P / 2^32 = 0.46875; sredc(t) in [t/2^32 - P/2, t/2^32 + P/2); int32 holds 1.0667 P):
 //   redc64s output                     |x| <= 57 + P/2                           (external rounds' S-box input)
