@@ -53,7 +53,7 @@ class _TaskInfo(C.Structure):
 
 class _AgentConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("inflight", C.c_uint32), ("w_code", C.c_uint32), ("w_data", C.c_uint32),
-                ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("verify", C.c_int32),
+                ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("no_verify", C.c_int32),
                 ("task_stream", C.c_char * 64)]
 
 
@@ -210,7 +210,7 @@ class Agent:
         self.taskdb = taskdb or TaskDb()
         self.prover = prover
         cfg = _AgentConfig(device=device, inflight=inflight or (1 if prover is not None else 3), w_code=widths[0],
-                           w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, verify=int(verify),
+                           w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, no_verify=int(not verify),
                            task_stream=task_stream.encode())
         self._errs = {}
         ops_ptr = None

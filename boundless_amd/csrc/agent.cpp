@@ -594,7 +594,7 @@ struct bx_agent {
     }
     //   second half: verify -> store under the recursion-receipt key -> unlink the segment
     std::string finish_stage(Pending* p) {
-        if (cfg.verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
+        if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
             if (const char* ve = bx_verify_segment(p->seal.data(), p->words))
                 return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
         }

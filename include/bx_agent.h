@@ -146,7 +146,7 @@ typedef struct bx_agent_config {
     uint32_t w_code, w_data, w_accum; /* synthetic segment group widths; 0 = BASELINE config (16/256/64) */
     uint64_t redis_ttl;      /* seconds; 0 = 8 h (the reference's default `redis_ttl`) */
     double poll_time;        /* idle sleep between empty claims, seconds; <= 0 = 1 s (`poll_time`) */
-    int32_t verify;          /* verify each seal before storing it (prove.rs:53-55); default on = 1 */
+    int32_t no_verify;       /* 0 = verify each seal before storing it, as the reference does (prove.rs:53-55); 1 = skip */
     char task_stream[64];    /* worker type passed to request_work; "" = "prove" */
 } bx_agent_config;
 

@@ -52,7 +52,6 @@ int main() {
     memset(&cfg, 0, sizeof cfg);
     cfg.inflight = 6;
     cfg.poll_time = 0.001;
-    cfg.verify = 1;
     bx_segment_prover_ops pops{nullptr, seal_words, prove};
     bx_agent* agent = nullptr;
     if (const char* e = bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) {

@@ -81,7 +81,6 @@ int main(void) {
     cfg.inflight = 2;
     cfg.w_code = 4, cfg.w_data = 8, cfg.w_accum = 4;
     cfg.poll_time = 0.01;
-    cfg.verify = 1;
     bx_agent* agent = NULL;
     CHECK(bx_agent_create(&cfg, &sops, &tops, NULL, &agent));
     uint64_t done = 0;
