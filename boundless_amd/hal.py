@@ -161,6 +161,10 @@ class HipHal:
             raise HalError(msg.decode())
         self.ctx = ctx
         self.device = device
+        # BX_TUNABLES="name=value,..." applies bx_set_tunable to every context (A/B runs of the same command)
+        for item in filter(None, os.environ.get("BX_TUNABLES", "").split(",")):
+            name, _, value = item.partition("=")
+            self._check(self.lib.bx_set_tunable(self.ctx, name.strip().encode(), int(value)))
 
     def close(self):
         if getattr(self, "ctx", None):
