@@ -73,6 +73,7 @@ struct bx_ctx {
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
     long hash_rows_block = 256;
     long fold_fuse_below = 1 << 15;  // Merkle layers with at most this many inputs are folded 9 levels per launch
+    long deep_bitrev = 1;            // segment prover: keep trace coefficients bit-reversed through the DEEP phase (read at bx_prover_create)
 
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -248,6 +248,8 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         c->ntt_cols_per_wg = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
+    } else if (!strcmp(name, "deep_bitrev")) {
+        c->deep_bitrev = value != 0;
     } else if (!strcmp(name, "fold_fuse_below")) {
         BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
         c->fold_fuse_below = value;

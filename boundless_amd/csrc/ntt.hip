@@ -515,6 +515,36 @@ extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) 
     return nullptr;
 }
 
+// Bit reversal of AoS extension-field arrays (16-byte elements): one thread swaps element i with element rev(i), i < rev(i).
+__global__ void bit_reverse_ext_kernel(uint4* __restrict__ io, int n, size_t total) {
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(g & (((size_t)1 << n) - 1));
+        const uint32_t r = bit_reverse(i, n);
+        if (i < r) {
+            uint4* base = io + (g - i);
+            const uint4 a = base[i], b = base[r];
+            base[i] = b;
+            base[r] = a;
+        }
+    }
+}
+extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t count) {
+    if (!c) return "bx_batch_bit_reverse_ext: null ctx";
+    BX_REQUIRE(c, count > 0 && io_ext.len % (4 * count) == 0 && is_pow2(io_ext.len / (4 * count)),
+               "batch_bit_reverse_ext: io.len/(4*count) must be a power of two");
+    BX_REQUIRE(c, ((uintptr_t)io_ext.dptr & 15) == 0, "batch_bit_reverse_ext: buffer must be 16-byte aligned");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_bit_reverse", 8.0 * (double)io_ext.len);
+    const size_t elems = io_ext.len / 4;
+    const int n = ilog2(elems / count);
+    if (n == 0) return nullptr;
+    size_t blocks = (elems + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bit_reverse_ext_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint4*)io_ext.dptr, n, elems);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
 extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) {
     if (!c) return "bx_zk_shift: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "zk_shift: io.len/count must be a power of two");

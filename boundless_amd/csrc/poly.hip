@@ -73,14 +73,24 @@ __global__ __launch_bounds__(256) void mix_poly_kernel(uint32_t* __restrict__ ou
 //   x^seg_base * sum_{t<256} x^t * sum_{i<K} c[base + t + 256 i] * (x^256)^i.
 // The 256 + K powers are built once per workgroup by doubling in LDS (pw[d + i] = pw[d] * pw[i]), so the per-coefficient
 // cost is one Fp4-by-Fp product (4 Montgomery products) plus one LDS broadcast read.
+// Bit-reversed storage (brev_log = n > 0, poly_size = 2^n >= one segment): position j = seg * 2^15 + ii * 256 + t holds the
+// coefficient of x^bitrev_n(j) = x^(rev(seg)) * (x^(2^(n-15)))^rev7(ii) * (x^(2^(n-8)))^rev8(t), so the same two power tables
+// serve with bases x^(2^(n-8)) and x^(2^(n-15)) and bit-reversed table indices.
 constexpr int EV_K = 128, EV_T = 256;
 __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __restrict__ coeffs, size_t poly_size,
                                                             const uint32_t* __restrict__ which, const uint32_t* __restrict__ xs,
-                                                            uint32_t* __restrict__ partials, uint32_t segs) {
+                                                            uint32_t* __restrict__ partials, uint32_t segs, int brev_log) {
     __shared__ uint32_t xpow[EV_T * 4];  // x^t (reused for the final reduction)
     __shared__ uint32_t ypow[EV_K * 4];  // (x^256)^i
     const uint32_t e = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
-    const Fp4 x = ld4(xs + 4 * (size_t)e);
+    const Fp4 x0 = ld4(xs + 4 * (size_t)e);
+    Fp4 x = x0;  // base of the 256-entry table: x, or x^(2^(n-8)) for bit-reversed storage
+    Fp4 xk = x0;  // x^(2^(n-15)), base of the 128-entry table for bit-reversed storage
+    if (brev_log) {
+        for (int i = 0; i < brev_log - 15; ++i) xk = f4_mul(xk, xk);
+        x = xk;
+        for (int i = 0; i < 7; ++i) x = f4_mul(x, x);
+    }
     const size_t seg_elems = (size_t)EV_T * EV_K;
     const size_t base = (size_t)seg * seg_elems;
     const uint32_t* c = coeffs + (size_t)which[e] * poly_size + base;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         }
         __syncthreads();
     }
-    const Fp4 X = f4_mul(ld4(xpow + 4 * (EV_T - 1)), x);  // x^256
+    const Fp4 X = brev_log ? xk : f4_mul(ld4(xpow + 4 * (EV_T - 1)), x);  // x^256 (natural order)
     if (tid == 0) {
         st4(ypow, f4_one());
         st4(ypow + 4, X);
@@ -111,7 +121,11 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         __syncthreads();
     }
     Fp4 acc = f4_zero();
-    if (remaining >= seg_elems) {
+    if (brev_log) {
+#pragma unroll 8
+        for (int i = 0; i < EV_K; ++i)
+            acc = f4_add(acc, f4_scale(ld4(ypow + 4 * (__brev((uint32_t)i) >> 25)), c[(size_t)tid + (size_t)EV_T * i]));
+    } else if (remaining >= seg_elems) {
 #pragma unroll 8
         for (int i = 0; i < EV_K; ++i) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[(size_t)tid + (size_t)EV_T * i]));
     } else {
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
             if (j < remaining) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[j]));
         }
     }
-    acc = f4_mul(acc, ld4(xpow + 4 * tid));
+    acc = f4_mul(acc, ld4(xpow + 4 * (brev_log ? (__brev(tid) >> 24) : tid)));
     __syncthreads();
     st4(xpow + 4 * tid, acc);
     __syncthreads();
@@ -128,7 +142,10 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         if ((int)tid < s) st4(xpow + 4 * tid, f4_add(ld4(xpow + 4 * tid), ld4(xpow + 4 * (tid + s))));
         __syncthreads();
     }
-    if (tid == 0) st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(xpow), f4_pow(x, base)));
+    if (tid == 0) {
+        const uint64_t ex = brev_log ? (uint64_t)(__brev(seg) >> (32 - (brev_log - 15))) * (brev_log > 15) : (uint64_t)base;
+        st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(xpow), f4_pow(x0, ex)));
+    }
 }
 __global__ void eval_final_kernel(const uint32_t* __restrict__ partials, uint32_t segs, uint32_t* __restrict__ out,
                                   uint32_t evals) {
@@ -342,27 +359,40 @@ extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t 
     return nullptr;
 }
 
-extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
-    if (!c) return "bx_batch_evaluate_any: null ctx";
+static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out, bool bitrev,
+                                     const char* name) {
     BX_REQUIRE(c, poly_count > 0 && coeffs.len % poly_count == 0, "batch_evaluate_any: coeffs.len not a multiple of poly_count");
     size_t evals = which.len;
     BX_REQUIRE(c, xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_any: xs/out must hold one ext elem per eval");
     BX_HIP(c, hipSetDevice(c->device));
     size_t poly_size = coeffs.len / poly_count;
-    OpScope op(c, "batch_evaluate_any", 4.0 * (double)(poly_size * evals));
-    if (!evals) return nullptr;
     size_t seg_elems = (size_t)EV_T * EV_K;
+    int brev_log = 0;
+    if (bitrev) {
+        BX_REQUIRE(c, is_pow2(poly_size) && poly_size >= seg_elems, "batch_evaluate_any_bitrev: polynomial size must be a power of two >= 2^15");
+        brev_log = ilog2(poly_size);
+    }
+    OpScope op(c, name, 4.0 * (double)(poly_size * evals));
+    if (!evals) return nullptr;
     size_t segs = (poly_size + seg_elems - 1) / seg_elems;
     BX_REQUIRE(c, evals <= 65535, "batch_evaluate_any: more than 65535 evaluations in one call");
     BX_TRY(ensure_scratch(c, 4 * evals * segs));
     hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
                        (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)xs.dptr,
-                       c->d_scratch, (uint32_t)segs);
+                       c->d_scratch, (uint32_t)segs, brev_log);
     BX_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(eval_final_kernel, dim3((unsigned)((evals + 63) / 64)), dim3(64), 0, c->stream, c->d_scratch,
                        (uint32_t)segs, (uint32_t*)out.dptr, (uint32_t)evals);
     BX_LAUNCH_CHECK(c);
     return nullptr;
+}
+extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
+    if (!c) return "bx_batch_evaluate_any: null ctx";
+    return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, false, "batch_evaluate_any");
+}
+extern "C" const char* bx_batch_evaluate_any_bitrev(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
+    if (!c) return "bx_batch_evaluate_any_bitrev: null ctx";
+    return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, true, "batch_evaluate_any");
 }
 
 extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) {

@@ -151,6 +151,7 @@ struct bx_prover {
     bx_ctx* c = nullptr;
     bx_segment_params shape{};
     size_t N = 0;
+    bool coeffs_bitrev = false;  // trace coefficients stay in bit-reversed order (N >= 2^15), see commit_group
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
     DevBuf mixpows, combos, final_poly, which, xs, evals, rems, positions, qout;
@@ -205,7 +206,11 @@ const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
     PV(bx_batch_interpolate_ntt(c, g.coeffs.b, g.width));
     PV(bx_zk_shift(c, g.coeffs.b, g.width));
     PV(bx_batch_expand_into_evaluate_ntt(c, g.evaluated.b, g.coeffs.b, g.width, 2));
-    PV(bx_batch_bit_reverse(c, g.coeffs.b, g.width));
+    // PolyGroup::new bit-reverses the coefficients to natural order here.  At BASELINE sizes the trace coefficients stay
+    // bit-reversed instead (p->coeffs_bitrev): the taps are evaluated by bx_batch_evaluate_any_bitrev, the DEEP mix is
+    // element-wise and therefore order-agnostic, and only the two combination polynomials are bit-reversed afterwards —
+    // 32 words per row moved instead of 336.
+    if (!p->coeffs_bitrev) PV(bx_batch_bit_reverse(c, g.coeffs.b, g.width));
     return tree_commit(p, g.tree, g.evaluated.b, T);
 }
 
@@ -241,6 +246,7 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     p->c = c;
     p->shape = *shape;
     p->N = (size_t)1 << shape->po2;
+    p->coeffs_bitrev = shape->po2 >= 15 && c->deep_bitrev;
     p->err[0] = 0;
     p->h2.load(c->h_rc, c->h_diag);
     const size_t N = p->N, D = 4 * N;
@@ -395,7 +401,10 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         size_t ne = which.size();
         PV(bx_h2d(c, p->which.slice(0, ne), which.data(), ne));
         PV(bx_h2d(c, p->xs.slice(0, 4 * ne), xs.data(), 4 * ne));
-        PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
+        if (p->coeffs_bitrev && g < 3)
+            PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
+        else
+            PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
         std::vector<uint32_t> ev(4 * ne);
         PV(bx_d2h(c, ev.data(), p->evals.slice(0, 4 * ne), 4 * ne));
         size_t e = 0;
@@ -440,6 +449,8 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
                 cur = f4_mul(cur, mix);
             }
         }
+        // combos 0 and 1 collect the trace groups (bit-reversed storage), combo 2 only the check group (natural order)
+        if (p->coeffs_bitrev) PV(bx_batch_bit_reverse_ext(c, p->combos.slice(0, 8 * N), 2));
         for (int id = 0; id < 3; ++id) {
             uint32_t low[8];
             bx_buf head = p->combos.slice((size_t)id * 4 * N, 8);

@@ -80,6 +80,8 @@ def load_library():
         "bx_fri_fold": [ctx, BxBuf, BxBuf, u32p],
         "bx_mix_poly_coeffs": [ctx, BxBuf, u32p, u32p, BxBuf, BxBuf, sz, sz],
         "bx_batch_evaluate_any": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
+        "bx_batch_evaluate_any_bitrev": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
+        "bx_batch_bit_reverse_ext": [ctx, BxBuf, sz],
         "bx_eltwise_add_elem": [ctx, BxBuf, BxBuf, BxBuf],
         "bx_eltwise_copy_elem": [ctx, BxBuf, BxBuf],
         "bx_eltwise_zeroize_elem": [ctx, BxBuf],
@@ -259,6 +261,14 @@ class HipHal:
 
     def batch_evaluate_any(self, coeffs, poly_count, which, xs, out):
         self._check(self.lib.bx_batch_evaluate_any(self.ctx, coeffs.raw, poly_count, which.raw, xs.raw, out.raw))
+
+    def batch_evaluate_any_bitrev(self, coeffs, poly_count, which, xs, out):
+        """Extension: the same over bit-reversed coefficient storage (include/bx_hal.h)."""
+        self._check(self.lib.bx_batch_evaluate_any_bitrev(self.ctx, coeffs.raw, poly_count, which.raw, xs.raw, out.raw))
+
+    def batch_bit_reverse_ext(self, io, count):
+        """Extension: batch_bit_reverse for AoS Buffer<ExtElem> (16-byte elements)."""
+        self._check(self.lib.bx_batch_bit_reverse_ext(self.ctx, io.raw, count))
 
     def eltwise_add_elem(self, output, a, b):
         self._check(self.lib.bx_eltwise_add_elem(self.ctx, output.raw, a.raw, b.raw))

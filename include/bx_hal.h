@@ -108,6 +108,13 @@ const char* bx_mix_poly_coeffs(bx_ctx* ctx, bx_buf out_ext, const uint32_t mix_s
 /* Hal::batch_evaluate_any(coeffs, poly_count, which, xs, out): out[i] = sum_j coeffs[which[i]*size+j]*xs[i]^j */
 const char* bx_batch_evaluate_any(bx_ctx* ctx, bx_buf coeffs, size_t poly_count, bx_buf which_u32,
                                   bx_buf xs_ext, bx_buf out_ext);
+/* Extensions for provers that keep coefficient polynomials in bit-reversed order (what batch_interpolate_ntt leaves
+ * and batch_expand_into_evaluate_ntt reads), so that only the few DEEP combination polynomials are ever bit-reversed:
+ * batch_evaluate_any over bit-reversed coefficient storage (polynomial size a power of two >= 2^15; same result as
+ * batch_evaluate_any on the natural-order array), and batch_bit_reverse for AoS Buffer<ExtElem> (16-byte elements). */
+const char* bx_batch_evaluate_any_bitrev(bx_ctx* ctx, bx_buf coeffs_bitrev, size_t poly_count, bx_buf which_u32,
+                                         bx_buf xs_ext, bx_buf out_ext);
+const char* bx_batch_bit_reverse_ext(bx_ctx* ctx, bx_buf io_ext, size_t count);
 /* Hal::eltwise_add_elem / eltwise_copy_elem / eltwise_zeroize_elem / eltwise_sum_extelem */
 const char* bx_eltwise_add_elem(bx_ctx* ctx, bx_buf out, bx_buf a, bx_buf b);
 const char* bx_eltwise_copy_elem(bx_ctx* ctx, bx_buf out, bx_buf in);

@@ -367,6 +367,47 @@ def test_batch_evaluate_any_vs_oracle(hal, oracle, size, npoly, evals):
     assert np.array_equal(out.view(), ref)
 
 
+def _bitrev_perm(n):
+    idx = np.arange(1 << n, dtype=np.uint64)
+    r = np.zeros_like(idx)
+    for b in range(n):
+        r |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(n - 1 - b)
+    return r.astype(np.int64)
+
+
+@pytest.mark.parametrize("n,npoly,evals", [(15, 3, 5), (16, 2, 4), (18, 2, 3), (20, 2, 3)])
+def test_batch_evaluate_any_over_bit_reversed_storage(hal, oracle, n, npoly, evals):
+    """Extension entry point: evaluating the bit-reversed array equals the oracle's evaluation of the natural-order one."""
+    size = 1 << n
+    rng = np.random.default_rng(n)
+    coeffs = rnd(n, npoly * size)
+    perm = _bitrev_perm(n)
+    stored = coeffs.reshape(npoly, size)[:, perm].reshape(-1).copy()  # stored[j] = coeffs[bitrev(j)]
+    which = rng.integers(0, npoly, evals, dtype=np.uint32)
+    xs = rnd(13, 4 * evals)
+    out = hal.alloc(4 * evals)
+    hal.batch_evaluate_any_bitrev(hal.copy_from(stored), npoly, hal.copy_from(which), hal.copy_from(xs), out)
+    ref = np.zeros(4 * evals, np.uint32)
+    oracle.bxo_batch_evaluate_any(coeffs, size, c(which), xs, ref, evals)
+    assert np.array_equal(out.view(), ref)
+    from boundless_amd.hal import HalError
+
+    with pytest.raises(HalError, match="2\\^15"):
+        hal.batch_evaluate_any_bitrev(hal.copy_from(rnd(1, 1 << 10)), 1, hal.copy_from(which[:1] * 0), hal.copy_from(xs[:4]), hal.alloc(4))
+
+
+@pytest.mark.parametrize("n,count", [(1, 3), (5, 2), (12, 3), (16, 2), (20, 2)])
+def test_batch_bit_reverse_ext(hal, n, count):
+    size = 1 << n
+    data = rnd(n + 40, 4 * size * count)
+    buf = hal.copy_from(data)
+    hal.batch_bit_reverse_ext(buf, count)
+    ref = data.reshape(count, size, 4)[:, _bitrev_perm(n), :].reshape(-1)
+    assert np.array_equal(buf.view(), ref)
+    hal.batch_bit_reverse_ext(buf, count)  # an involution
+    assert np.array_equal(buf.view(), data)
+
+
 @pytest.mark.parametrize("size", [1, 5, 64, 100, 4096, 1 << 16, 1 << 20])
 def test_poly_divide_vs_oracle(hal, oracle, size):
     poly = rnd(size, 4 * size)

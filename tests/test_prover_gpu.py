@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
     (10, (4, 8, 4), 1234),
     (12, (3, 17, 5), 0xB0D1E550000),
     (13, (16, 32, 8), 77),
+    (15, (2, 5, 3), 99),  # smallest size that keeps the trace coefficients bit-reversed through the DEEP phase
     (16, (4, 12, 4), 0xB0D1E550001),
 ])
 def test_seal_bit_exact_vs_oracle(po2, widths, seed):
@@ -32,6 +33,26 @@ def test_seal_bit_exact_vs_oracle(po2, widths, seed):
         assert np.array_equal(r2.seal, s2) and not np.array_equal(r2.seal, receipt.seal)
     finally:
         srv.close()
+
+
+def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
+    """`deep_bitrev` = 0 runs upstream's order (bit-reverse every coefficient column, evaluate, mix); the default keeps the
+    trace coefficients bit-reversed and reverses only the two combination polynomials.  Same seal either way."""
+    from boundless_amd.hal import HipHal
+    from boundless_amd.prover import HipProverServer, Segment
+
+    seals = []
+    for flag in (0, 1):
+        hal = HipHal(0)
+        hal._check(hal.lib.bx_set_tunable(hal.ctx, b"deep_bitrev", flag))
+        srv = HipProverServer(0, po2=16, widths=(3, 9, 4), hal=hal)
+        try:
+            seals.append(srv.prove_segment(Segment(0, 16, 4242)).seal)
+        finally:
+            srv.close()
+    assert np.array_equal(seals[0], seals[1])
+    want, _ = ol.prove_segment(16, 3, 9, 4, 4242)
+    assert np.array_equal(seals[1], want)
 
 
 def test_seal_is_deterministic_and_shape_errors():
