@@ -53,6 +53,7 @@ struct bx_ctx {
     uint32_t* d_tw_inv = nullptr;
     std::map<bx::TwistKey, uint32_t*> twist;
     std::map<int, bx::ZkTab> zk;
+    std::map<int, uint32_t*> zk_full;  // n -> 3^bitrev_n(i), i < 2^n (fused interpolate + zk_shift)
 
     // Poseidon2 parameters: host canonical copy + device Montgomery copy [213 rc | 24 diag]
     uint32_t h_rc[BX_POSEIDON2_RC_COUNT];

@@ -222,8 +222,10 @@ void ntt_free_tables(bx_ctx* c) {
         (void)hipFree(kv.second.lo);
         (void)hipFree(kv.second.hi);
     }
+    for (auto& kv : c->zk_full) (void)hipFree(kv.second);
     c->twist.clear();
     c->zk.clear();
+    c->zk_full.clear();
 }
 
 static const char* get_twist(bx_ctx* c, int m, int m_hi, bool inverse, uint32_t** out) {
@@ -327,7 +329,8 @@ static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
 
 // pass A over `count` columns of size 2^m made of 2^(m - m_hi) blocks; returns false in *ok if the shape is not covered
 static const char* fast_pass_a(bx_ctx* c, bool inv, uint32_t* out, const uint32_t* in, const uint32_t* twist, uint32_t scale,
-                               size_t count, int m, int m_hi, int expand, int skip, bool* ok) {
+                               size_t count, int m, int m_hi, int expand, int skip, bool* ok, const uint32_t* post = nullptr,
+                               bool* post_applied = nullptr) {
     *ok = false;
     int lrows = (int)c->ntt_tile_a_log;
     if (lrows < m_hi) lrows = m_hi;
@@ -337,6 +340,10 @@ static const char* fast_pass_a(bx_ctx* c, bool inv, uint32_t* out, const uint32_
     if (!(skip == 0 || (skip == 2 && !inv))) return nullptr;
     R16Args a;
     a.out = out; a.in = in; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.twist = twist; a.scale = scale;
+    // the final store of the inverse pass A applies `post` only in its 16-words-per-thread form (the last step is K = 4 at s0 = 0 whenever m_hi >= 4)
+    const bool can_post = inv && post && m_hi >= 4;
+    a.post = can_post ? post : nullptr;
+    if (post_applied) *post_applied = can_post;
     a.lr = m_hi; a.lrows = lrows; a.lt = 0; a.expand = expand; a.row_shift = 0;
     a.tile_stride = 1u << lrows;
     a.in_col_stride = ((size_t)1 << m) >> expand; a.out_col_stride = (size_t)1 << m;
@@ -409,7 +416,8 @@ static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t 
     return nullptr;
 }
 
-static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m) {
+static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m, const uint32_t* post = nullptr, bool* post_applied = nullptr) {
+    if (post_applied) *post_applied = false;
     if (m == 0 || count == 0) return nullptr;
     Split sp = choose_split(c, m);
     BX_REQUIRE(c, sp.m_hi <= TW_LOG && sp.m_lo <= TW_LOG, "ntt: size too large");
@@ -431,7 +439,8 @@ static const char* inverse(bx_ctx* c, uint32_t* io, size_t count, int m) {
         BX_LAUNCH_CHECK(c);
     }
     uint32_t scale = fp_inv(fp_encode((uint32_t)M));
-    if (c->ntt_fast) BX_TRY(fast_pass_a(c, true, io, io, twist, scale, count, m, sp.m_hi, 0, 0, &done_a));
+    if (c->ntt_fast) BX_TRY(fast_pass_a(c, true, io, io, twist, scale, count, m, sp.m_hi, 0, 0, &done_a, post, post_applied));
+    if (!done_a && post_applied) *post_applied = false;
     if (!done_a) {
         unsigned R = 1u << sp.m_hi;
         unsigned threads = R / 2 < 64 ? 64 : (R / 2 > 256 ? 256 : R / 2);
@@ -462,9 +471,54 @@ static const char* get_zk(bx_ctx* c, int n, ZkTab* out) {
     return nullptr;
 }
 
+__global__ void zk_full_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, int n,
+                               int lo_bits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ((size_t)1 << n)) out[i] = fp_mul(lo[i & ((1u << lo_bits) - 1u)], hi[i >> lo_bits]);
+}
+// 3^bitrev_n(i) for every position of a size-2^n column (4 MB at n = 20, read through L2 by the fused inverse pass)
+static const char* get_zk_full(bx_ctx* c, int n, const uint32_t** out) {
+    auto it = c->zk_full.find(n);
+    if (it != c->zk_full.end()) {
+        *out = it->second;
+        return nullptr;
+    }
+    ZkTab t;
+    BX_TRY(get_zk(c, n, &t));
+    uint32_t* full = nullptr;
+    BX_HIP(c, hipMalloc(&full, ((size_t)1 << n) * 4));
+    hipLaunchKernelGGL(zk_full_kernel, dim3((unsigned)((((size_t)1 << n) + 255) / 256)), dim3(256), 0, c->stream, full, t.lo, t.hi, n,
+                       t.lo_bits);
+    BX_LAUNCH_CHECK(c);
+    c->zk_full[n] = full;
+    *out = full;
+    return nullptr;
+}
+
 }  // namespace bx
 
 using namespace bx;
+
+static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count);
+
+// Extension: batch_interpolate_ntt followed by zk_shift in one call.  When the register-radix path covers the shape the
+// shift rides on the final store of the inverse transform (one extra product per element instead of a read-modify-write
+// pass over the coefficients); otherwise it is the two calls.
+extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t count) {
+    if (!c) return "bx_batch_interpolate_zk: null ctx";
+    BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_zk: io.len/count must be a power of two");
+    BX_HIP(c, hipSetDevice(c->device));
+    const int m = ilog2(io.len / count);
+    bool fused = false;
+    {
+        OpScope op(c, "batch_interpolate_ntt", 8.0 * (double)io.len);
+        const uint32_t* post = nullptr;
+        if (m >= 12 && c->ntt_fast) BX_TRY(get_zk_full(c, m, &post));
+        BX_TRY(inverse(c, (uint32_t*)io.dptr, count, m, post, &fused));
+    }
+    if (fused) return nullptr;
+    return zk_shift_impl(c, io, count);
+}
 
 extern "C" const char* bx_batch_interpolate_ntt(bx_ctx* c, bx_buf io, size_t count) {
     if (!c) return "bx_batch_interpolate_ntt: null ctx";
@@ -547,6 +601,9 @@ extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t
 
 extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) {
     if (!c) return "bx_zk_shift: null ctx";
+    return zk_shift_impl(c, io, count);
+}
+static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count) {
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "zk_shift: io.len/count must be a power of two");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "zk_shift", 8.0 * (double)io.len);

@@ -26,6 +26,7 @@ struct R16Args {
     const uint32_t* in;
     const uint32_t* tw;     // stage table (forward or inverse roots)
     const uint32_t* twist;  // pass A only: per-element factor (nullptr = none)
+    const uint32_t* post = nullptr;  // pass A inverse only: per-position factor applied on the final store
     uint32_t scale;         // pass A inverse without twist: 1/M
     int lr, lrows, lt;
     int expand;     // pass A forward: load shift (out[i] = in[i >> expand])
@@ -271,6 +272,15 @@ __device__ __forceinline__ void glb_put(const uint32_t (&x)[16], const R16Args& 
     constexpr int U = 16 >> K, E = 1 << K;
     if (PASS_A && INV && K == 4 && s0 == 0) {
         uint4* o = reinterpret_cast<uint4*>(dst + tile_off + (size_t)tid * 16);
+        if (a.post) {  // fused zk_shift: the factor of position p of the column
+            const uint4* f = reinterpret_cast<const uint4*>(a.post + tile_off + (size_t)tid * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 g = f[i];
+                o[i] = make_uint4(fp_mul(x[4 * i], g.x), fp_mul(x[4 * i + 1], g.y), fp_mul(x[4 * i + 2], g.z), fp_mul(x[4 * i + 3], g.w));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = make_uint4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
         return;

@@ -203,8 +203,7 @@ const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
 // Prover::commit_group: interpolate -> zk_shift -> PolyGroup::new (expand+evaluate, bit_reverse, Merkle) -> commit
 const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
     bx_ctx* c = p->c;
-    PV(bx_batch_interpolate_ntt(c, g.coeffs.b, g.width));
-    PV(bx_zk_shift(c, g.coeffs.b, g.width));
+    PV(bx_batch_interpolate_zk(c, g.coeffs.b, g.width));  // = batch_interpolate_ntt + zk_shift
     PV(bx_batch_expand_into_evaluate_ntt(c, g.evaluated.b, g.coeffs.b, g.width, 2));
     // PolyGroup::new bit-reverses the coefficients to natural order here.  At BASELINE sizes the trace coefficients stay
     // bit-reversed instead (p->coeffs_bitrev): the taps are evaluated by bx_batch_evaluate_any_bitrev, the DEEP mix is

@@ -82,6 +82,7 @@ def load_library():
         "bx_batch_evaluate_any": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
         "bx_batch_evaluate_any_bitrev": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
         "bx_batch_bit_reverse_ext": [ctx, BxBuf, sz],
+        "bx_batch_interpolate_zk": [ctx, BxBuf, sz],
         "bx_eltwise_add_elem": [ctx, BxBuf, BxBuf, BxBuf],
         "bx_eltwise_copy_elem": [ctx, BxBuf, BxBuf],
         "bx_eltwise_zeroize_elem": [ctx, BxBuf],
@@ -265,6 +266,10 @@ class HipHal:
     def batch_evaluate_any_bitrev(self, coeffs, poly_count, which, xs, out):
         """Extension: the same over bit-reversed coefficient storage (include/bx_hal.h)."""
         self._check(self.lib.bx_batch_evaluate_any_bitrev(self.ctx, coeffs.raw, poly_count, which.raw, xs.raw, out.raw))
+
+    def batch_interpolate_zk(self, io, count):
+        """Extension: batch_interpolate_ntt + zk_shift in one call."""
+        self._check(self.lib.bx_batch_interpolate_zk(self.ctx, io.raw, count))
 
     def batch_bit_reverse_ext(self, io, count):
         """Extension: batch_bit_reverse for AoS Buffer<ExtElem> (16-byte elements)."""

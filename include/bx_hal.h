@@ -115,6 +115,9 @@ const char* bx_batch_evaluate_any(bx_ctx* ctx, bx_buf coeffs, size_t poly_count,
 const char* bx_batch_evaluate_any_bitrev(bx_ctx* ctx, bx_buf coeffs_bitrev, size_t poly_count, bx_buf which_u32,
                                          bx_buf xs_ext, bx_buf out_ext);
 const char* bx_batch_bit_reverse_ext(bx_ctx* ctx, bx_buf io_ext, size_t count);
+/* Extension: batch_interpolate_ntt(io, count) followed by zk_shift(io, count) as one call; on the register-radix path the
+ * shift rides on the final store of the inverse transform.  Same result as the two calls. */
+const char* bx_batch_interpolate_zk(bx_ctx* ctx, bx_buf io, size_t count);
 /* Hal::eltwise_add_elem / eltwise_copy_elem / eltwise_zeroize_elem / eltwise_sum_extelem */
 const char* bx_eltwise_add_elem(bx_ctx* ctx, bx_buf out, bx_buf a, bx_buf b);
 const char* bx_eltwise_copy_elem(bx_ctx* ctx, bx_buf out, bx_buf in);

@@ -396,6 +396,18 @@ def test_batch_evaluate_any_over_bit_reversed_storage(hal, oracle, n, npoly, eva
         hal.batch_evaluate_any_bitrev(hal.copy_from(rnd(1, 1 << 10)), 1, hal.copy_from(which[:1] * 0), hal.copy_from(xs[:4]), hal.alloc(4))
 
 
+@pytest.mark.parametrize("n,count", [(0, 3), (3, 4), (11, 3), (12, 2), (13, 5), (16, 3), (20, 2), (22, 1)])
+def test_batch_interpolate_zk_equals_the_two_calls(hal, n, count):
+    """Extension entry point: interpolate + zk_shift fused into the inverse transform's final store."""
+    size = 1 << n
+    data = rnd(n + 70, size * count)
+    a, b = hal.copy_from(data), hal.copy_from(data)
+    hal.batch_interpolate_ntt(a, count)
+    hal.zk_shift(a, count)
+    hal.batch_interpolate_zk(b, count)
+    assert np.array_equal(a.view(), b.view())
+
+
 @pytest.mark.parametrize("n,count", [(1, 3), (5, 2), (12, 3), (16, 2), (20, 2)])
 def test_batch_bit_reverse_ext(hal, n, count):
     size = 1 << n
