@@ -61,7 +61,8 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
     // the first internal round's)
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        sbox7s_n<CELLS>(s);
+        sbox7s_n<CELLS / 2>(s);  // two halves: 12 independent chains are enough ILP and halve the live 64-bit temporaries
+        sbox7s_n<CELLS / 2>(s + CELLS / 2);
         m_ext64s(s, y);
         if (r < RF_HALF - 1) {
             redc64s_all(y, prm + (r + 1) * CELLS, s);
@@ -72,11 +73,11 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
     // internal rounds: cells[i] = sum + diag[i]*cells[i].  sum is accumulated in 64 bits, turned into
     // sum_r = sum * 2^32 mod P by one reduction, and rides in each cell's REDC accumulator (cell 0: together with the next
     // constant).
-    // The 24 diagonal words are wave-uniform, but left in SGPRs the compiler reloads them with three s_load + s_waitcnt
-    // stalls in every internal round (a scalar-cache round trip is about as long as half a round's arithmetic).  Keep them
-    // in VGPRs for the whole permutation instead: six 16-byte vector loads through an offset the compiler cannot prove
-    // uniform (an opaque zero), issued once, one wait.
-    i32 diag[CELLS];
+    // The 24 diagonal words are wave-uniform.  Loaded as scalars the compiler re-issues the s_load (+ s_waitcnt stall) in every
+    // internal round; held in VGPRs they cost 24 registers.  So: six 16-byte vector loads through an offset the compiler cannot prove uniform (an opaque zero), issued once,
+    // then v_readfirstlane into SGPRs — values the compiler can neither rematerialise from memory nor widen, and that the
+    // multiply-adds read as their one scalar operand.
+    uint32_t diag[CELLS];
     {
         uint32_t zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
@@ -84,7 +85,10 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
 #pragma unroll
         for (int i = 0; i < CELLS / 4; ++i) {
             const uint4 v = dp[i];
-            diag[4 * i] = (i32)v.x; diag[4 * i + 1] = (i32)v.y; diag[4 * i + 2] = (i32)v.z; diag[4 * i + 3] = (i32)v.w;
+            diag[4 * i] = __builtin_amdgcn_readfirstlane(v.x);
+            diag[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+            diag[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+            diag[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
         }
     }
 #pragma unroll 1
@@ -95,7 +99,8 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
     // external rounds 4..7
 #pragma unroll 1
     for (int r = 0; r < RF_HALF; ++r) {
-        sbox7s_n<CELLS>(s);
+        sbox7s_n<CELLS / 2>(s);  // two halves: 12 independent chains are enough ILP and halve the live 64-bit temporaries
+        sbox7s_n<CELLS / 2>(s + CELLS / 2);
         m_ext64s(s, y);
         if (r < RF_HALF - 1) {
             redc64s_all(y, prm + 117 + (r + 1) * CELLS, s);
@@ -107,8 +112,10 @@ __device__ __forceinline__ void poseidon2_mix(uint32_t* io, const uint32_t* __re
     }
 }
 
+// Occupancy: the stage-wise order fixes the register pressure (the statements are volatile), so the stages are 12 cells wide
+// (3 four-cell groups in the linear layer): 108-120 VGPRs, four waves per SIMD without spills.  Five (96 VGPRs) spills.
 // hash_rows: lane = row.  matrix is column-major rows x cols.
-__global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_rows_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
                                                         const uint32_t* __restrict__ prm, uint32_t rows, uint32_t cols) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ o
 }
 
 // hash_fold: lane = output node; io[out+i] = H(io[in+2i] || io[in+2i+1]).
-__global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
                                                         uint32_t input_size, uint32_t output_size) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= output_size) return;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ i
 // Small layers in one launch: a workgroup owns `per_wg` (<= 512) consecutive input digests and folds them `levels`
 // levels deep through LDS, writing every intermediate layer.  Used once a layer no longer fills the chip, where each
 // separate launch would cost a full single-wave permutation latency.
-__global__ __launch_bounds__(256) void hash_fold_multi_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_multi_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
                                                               uint32_t input_size, uint32_t per_wg, int levels) {
     __shared__ uint32_t sh[256 * 8];
     const uint32_t tid = threadIdx.x;

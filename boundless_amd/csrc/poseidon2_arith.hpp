@@ -259,13 +259,17 @@ BX_HD i32 redc64s(i64 y, uint32_t rc) {
 
 // the 24 bare reductions of a layer, stage-wise; rc = 24 pre-scaled constants
 BX_HD void redc64s_all(const i64* y, const uint32_t* rc, i32* s) {
-    i64 acc[P2_CELLS];
+    constexpr int H = P2_CELLS / 2;  // two halves: 12 chains are enough ILP and halve the live temporaries
 #pragma unroll
-    for (int i = 0; i < P2_CELLS; ++i) {
-        BX_ASSERT_BOUND(iabs64(y[i]) <= B_Y, "external layer output");
-        acc[i] = add_u32(y[i], rc[i], i & 3);
+    for (int h = 0; h < P2_CELLS; h += H) {
+        i64 acc[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            BX_ASSERT_BOUND(iabs64(y[h + i]) <= B_Y, "external layer output");
+            acc[i] = add_u32(y[h + i], rc[h + i], i & 3);
+        }
+        sredc_n<H>(acc, s + h);
     }
-    sredc_n<P2_CELLS>(acc, s);
 #pragma unroll
     for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_EXT, "redc64s output");
 }
@@ -284,16 +288,20 @@ BX_HD i32 red64ks(i64 y, uint32_t add) {
 template <uint32_t K1, uint32_t K2, bool HAS_ADD0>
 BX_HD void red64ks_all(const i64* y, uint32_t add0, i32* s) {
     static_assert(K1 < (1u << 29) && K2 < P, "correction constant too large for the accumulator bound");
-    i64 acc[P2_CELLS];
+    constexpr int H = P2_CELLS / 2;
 #pragma unroll
-    for (int i = 0; i < P2_CELLS; ++i) {
-        BX_ASSERT_BOUND(iabs64(y[i]) <= B_Y, "external layer output");
-        acc[i] = umul_k((uint32_t)y[i], K1, i & 3);
+    for (int h = 0; h < P2_CELLS; h += H) {
+        i64 acc[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            BX_ASSERT_BOUND(iabs64(y[h + i]) <= B_Y, "external layer output");
+            acc[i] = umul_k((uint32_t)y[h + i], K1, i & 3);
+        }
+        if (HAS_ADD0 && h == 0) acc[0] = add_u32(acc[0], add0, 0);
+#pragma unroll
+        for (int i = 0; i < H; ++i) acc[i] = smad_k((i32)(y[h + i] >> 32), K2, acc[i], (i + 1) & 3);
+        sredc_n<H>(acc, s + h);
     }
-    if (HAS_ADD0) acc[0] = add_u32(acc[0], add0, 0);
-#pragma unroll
-    for (int i = 0; i < P2_CELLS; ++i) acc[i] = smad_k((i32)(y[i] >> 32), K2, acc[i], (i + 1) & 3);
-    sredc_n<P2_CELLS>(acc, s);
 }
 
 // external layer circ(2*M4, M4, ..., M4) on signed cells, unreduced 64-bit outputs:
@@ -301,29 +309,38 @@ BX_HD void red64ks_all(const i64* y, uint32_t add0, i32* s) {
 //   t0 = a+b, t1 = c+d, t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, w = [t3+t5, t5, t2+t4, t4].
 // Rows of the whole layer sum to <= 112, so |y| <= 112 * 2^31 = B_Y for any int32 cells.
 BX_HD void m_ext64s(const i32* s, i64* y) {
-    i64 t0[6], t1[6], t2[6], t3[6];  // the six 4-cell groups advance together (see sredc_n)
+    // The 4-cell groups advance three at a time (see sredc_n): enough independent chains to keep dependent multiply-adds
+    // apart, and half the live 64-bit temporaries of advancing all six together (131 -> <= 128 VGPRs = a fourth wave per SIMD).
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        t0[g] = smulc<1>(s[4 * g], 2 * g);
-        t1[g] = smulc<1>(s[4 * g + 2], 2 * g + 1);
-    }
+    for (int h = 0; h < 2; ++h) {
+        i64 t0[3], t1[3], t2[3], t3[3];
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        t0[g] = smadc<1>(s[4 * g + 1], t0[g], 2 * g);
-        t1[g] = smadc<1>(s[4 * g + 3], t1[g], 2 * g + 1);
-    }
+        for (int q = 0; q < 3; ++q) {
+            const int g = 3 * h + q;
+            t0[q] = smulc<1>(s[4 * g], 2 * q);
+            t1[q] = smulc<1>(s[4 * g + 2], 2 * q + 1);
+        }
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        t2[g] = smadc<2>(s[4 * g + 1], t1[g], 2 * g);
-        t3[g] = smadc<2>(s[4 * g + 3], t0[g], 2 * g + 1);
-    }
+        for (int q = 0; q < 3; ++q) {
+            const int g = 3 * h + q;
+            t0[q] = smadc<1>(s[4 * g + 1], t0[q], 2 * q + 2);
+            t1[q] = smadc<1>(s[4 * g + 3], t1[q], 2 * q + 3);
+        }
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        const i64 t4 = t1[g] * 4 + t3[g], t5 = t0[g] * 4 + t2[g];
-        y[4 * g] = t3[g] + t5;
-        y[4 * g + 1] = t5;
-        y[4 * g + 2] = t2[g] + t4;
-        y[4 * g + 3] = t4;
+        for (int q = 0; q < 3; ++q) {
+            const int g = 3 * h + q;
+            t2[q] = smadc<2>(s[4 * g + 1], t1[q], 2 * q);
+            t3[q] = smadc<2>(s[4 * g + 3], t0[q], 2 * q + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int g = 3 * h + q;
+            const i64 t4 = t1[q] * 4 + t3[q], t5 = t0[q] * 4 + t2[q];
+            y[4 * g] = t3[q] + t5;
+            y[4 * g + 1] = t5;
+            y[4 * g + 2] = t2[q] + t4;
+            y[4 * g + 3] = t4;
+        }
     }
     i64 t[4];
 #pragma unroll
@@ -349,7 +366,7 @@ BX_HD i32 internal_sum_rs(i64 sum) {
 // one internal round on all cells: s[0] <- S-box, sum, s[i] <- sredc(diag[i] * s[i] + sum_r [+ rc]).
 // RC_ALL = false: only cell 0 gets the constant rc[0]; true: every cell i gets rc[i] (the last internal round).
 template <bool RC_ALL>
-BX_HD void internal_round(i32* s, const i32* diag, const uint32_t* rc) {
+BX_HD void internal_round(i32* s, const uint32_t* diag, const uint32_t* rc) {
     // The S-box of cell 0 is one dependent chain of 12 instructions; the sum of the other 23 cells does not depend on it and
     // is issued in between (two partial sums), so that no two adjacent statements depend on each other.  The trailing
     // argument of each primitive is its position in the instruction stream (carry-out pair rotation).
@@ -388,15 +405,19 @@ BX_HD void internal_round(i32* s, const i32* diag, const uint32_t* rc) {
     pa = smadc<1>(s[0], pa, 3);
     const i64 sum = pa + pb;
     const i64 c = smulc<1>(internal_sum_rs(sum), 1);
-    i64 tt[P2_CELLS];
+    constexpr int H = P2_CELLS / 2;
 #pragma unroll
-    for (int i = 0; i < P2_CELLS; ++i) {
-        if (RC_ALL || i == 0)
-            tt[i] = smad(diag[i], s[i], add_u32(c, rc[i], 2 * i + 2), 2 * i + 3);
-        else
-            tt[i] = smad(diag[i], s[i], c, i + 2);
+    for (int h = 0; h < P2_CELLS; h += H) {
+        i64 tt[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if (RC_ALL || h + i == 0)
+                tt[i] = smad_k(s[h + i], diag[h + i], add_u32(c, rc[h + i], 2 * i + 2), 2 * i + 3);  // diag < P < 2^31: a scalar operand
+            else
+                tt[i] = smad_k(s[h + i], diag[h + i], c, i + 2);
+        }
+        sredc_n<H>(tt, s + h);
     }
-    sredc_n<P2_CELLS>(tt, s);
 #pragma unroll
     for (int i = 0; i < P2_CELLS; ++i) BX_ASSERT_BOUND(iabs64(s[i]) <= B_INT, "internal cell");
 }
@@ -414,12 +435,12 @@ BX_HD uint32_t canon(i32 v) {
 // Input and output: canonical Montgomery words.
 template <int DIAG>
 BX_HD void poseidon2_mix_bounded(uint32_t* io, const uint32_t* prm) {
-    i32 s[P2_CELLS], diag[P2_CELLS];
+    i32 s[P2_CELLS];
     i64 y[P2_CELLS];
+    const uint32_t* diag = prm + DIAG;
     for (int i = 0; i < P2_CELLS; ++i) {
         BX_ASSERT_BOUND(io[i] <= B_IN, "canonical input");
         s[i] = (i32)io[i];
-        diag[i] = (i32)prm[DIAG + i];
     }
     m_ext64s(s, y);
     redc64s_all(y, prm, s);
