@@ -75,6 +75,21 @@ def cpu_baseline(po2_sample, widths, po2_full):
     }
 
 
+def job_valu_view(segments_per_s_per_gpu):
+    """Whole-job VALU issue rate: wave-level VALU instructions per segment (PMC, profiles/r01_job_valu_insts.json, all
+    kernels of the default workload) x the measured segment rate of one GPU, against the multiply-class issue peak."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01_job_valu_insts.json")))
+        rate = j["per_segment"] * segments_per_s_per_gpu
+        return {"valu_wave_insts_per_segment": j["per_segment"], "wave_insts_per_s_per_gpu": rate,
+                "issue_peak_mul": 1024 * 2.4e9 / 4, "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3),
+                "ns_per_wave_inst_per_simd": round(1024 / rate * 1e9, 3),
+                "note": "a multiply-class instruction measures 1.93-1.96 ns per wave and SIMD, a plain add 1.1 ns "
+                        "(profiles/r01_microbench3_mad_forms.jsonl): the job average sits at the multiply-class cost"}
+    except Exception:
+        return None
+
+
 def agent_mode(args, widths, device, lanes):
     """Segments/s through the native prove agent (include/bx_agent.h) over the in-memory hot store and task db."""
     from boundless_amd import agent as ag
@@ -322,6 +337,7 @@ def main():
             "roofline": roofline,
             "roofline_in_region": roofline_in_region,
             "roofline_dominant": dominant,
+            "roofline_job": job_valu_view(proved_total / elapsed / max(world, 1)),
             "kernels": kernels,
             "kernels_isolated": iso_k,
         }
