@@ -200,6 +200,18 @@ const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
     return nullptr;
 }
 
+// the mixed u polynomials (two ext coefficients per combo) come off the low end of the three combination polynomials
+struct SubLow {
+    uint32_t v[24];
+};
+__global__ void sub_low_kernel(uint32_t* __restrict__ combos, uint32_t combo_words, SubLow s) {
+    const uint32_t i = threadIdx.x;
+    if (i < 24) {
+        uint32_t* p = combos + (size_t)(i / 8) * combo_words + (i % 8);
+        *p = fp_sub(*p, s.v[i]);
+    }
+}
+
 // Prover::commit_group: interpolate -> zk_shift -> PolyGroup::new (expand+evaluate, bit_reverse, Merkle) -> commit
 const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
     bx_ctx* c = p->c;
@@ -272,12 +284,11 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     BX_TRY(p->mixpows.alloc(c, 4 * w_total));
     BX_TRY(p->combos.alloc(c, 3 * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
-    size_t max_evals = 2 * max_w;
-    BX_TRY(p->which.alloc(c, max_evals));
-    BX_TRY(p->xs.alloc(c, 4 * max_evals));
-    BX_TRY(p->evals.alloc(c, 4 * max_evals));
+    // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
+    BX_TRY(p->which.alloc(c, total_taps));
+    BX_TRY(p->xs.alloc(c, 4 * total_taps));
+    BX_TRY(p->evals.alloc(c, 4 * total_taps));
     BX_TRY(p->rems.alloc(c, 16));
-    BX_TRY(p->positions.alloc(c, BX_QUERIES));
     // FRI rounds
     size_t size = N;
     size_t fri_query_words = 0;
@@ -299,7 +310,9 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
         trace_query_words += p->groups[g].tree.query_words();
     }
     for (auto& r : p->rounds) max_q = std::max(max_q, r.tree.query_words());
-    BX_TRY(p->qout.alloc(c, max_q * BX_QUERIES));
+    // the 50 openings of every tree are gathered into one buffer and copied back together
+    BX_TRY(p->positions.alloc(c, BX_QUERIES * (4 + p->rounds.size())));
+    BX_TRY(p->qout.alloc(c, (trace_query_words + fri_query_words) * BX_QUERIES));
     // seal bound: header + tops + coeff_u + final coeffs + queries
     size_t bound = 4;
     for (int g = 0; g < 4; ++g) bound += 8 * p->groups[g].tree.top_size();
@@ -388,38 +401,49 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     // then test check(Z) against the trace taps (verify.cpp)
     const Fp4 Z4 = f4_scale(host_pow(Z, 4), fp_inv(MONT_THREE));
     std::vector<uint32_t> coeff_u;  // flattened ext elems, column by column, group by group
-    for (int g = 0; g < 4; ++g) {
-        Group& G = p->groups[g];
+    {
         std::vector<uint32_t> which, xs;
-        for (uint32_t col = 0; col < G.width; ++col)
-            for (uint32_t t = 0; t < G.taps[col]; ++t) {
-                which.push_back(col);
-                const Fp4& x = g == 3 ? Z4 : (t == 0 ? Z : Zb);
-                xs.insert(xs.end(), x.c, x.c + 4);
-            }
-        size_t ne = which.size();
-        PV(bx_h2d(c, p->which.slice(0, ne), which.data(), ne));
-        PV(bx_h2d(c, p->xs.slice(0, 4 * ne), xs.data(), 4 * ne));
-        if (p->coeffs_bitrev && g < 3)
-            PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
-        else
-            PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(0, ne), p->xs.slice(0, 4 * ne), p->evals.slice(0, 4 * ne)));
-        std::vector<uint32_t> ev(4 * ne);
-        PV(bx_d2h(c, ev.data(), p->evals.slice(0, 4 * ne), 4 * ne));
+        size_t first[5] = {0, 0, 0, 0, 0};
+        for (int g = 0; g < 4; ++g) {
+            Group& G = p->groups[g];
+            for (uint32_t col = 0; col < G.width; ++col)
+                for (uint32_t t = 0; t < G.taps[col]; ++t) {
+                    which.push_back(col);
+                    const Fp4& x = g == 3 ? Z4 : (t == 0 ? Z : Zb);
+                    xs.insert(xs.end(), x.c, x.c + 4);
+                }
+            first[g + 1] = which.size();
+        }
+        const size_t ne_all = which.size();
+        PV(bx_h2d(c, p->which.slice(0, ne_all), which.data(), ne_all));
+        PV(bx_h2d(c, p->xs.slice(0, 4 * ne_all), xs.data(), 4 * ne_all));
+        for (int g = 0; g < 4; ++g) {
+            Group& G = p->groups[g];
+            const size_t o = first[g], ne = first[g + 1] - first[g];
+            if (p->coeffs_bitrev && g < 3)
+                PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
+            else
+                PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
+        }
+        std::vector<uint32_t> ev(4 * ne_all);
+        PV(bx_d2h(c, ev.data(), p->evals.slice(0, 4 * ne_all), 4 * ne_all));
         size_t e = 0;
-        for (uint32_t col = 0; col < G.width; ++col) {
-            if (G.taps[col] == 1) {
-                coeff_u.insert(coeff_u.end(), ev.begin() + 4 * e, ev.begin() + 4 * e + 4);
-                e += 1;
-            } else {
-                // line through (Z, y0), (Zb, y1): c1 = (y1 - y0)/(Zb - Z), c0 = y0 - c1*Z
-                Fp4 y0{{ev[4 * e], ev[4 * e + 1], ev[4 * e + 2], ev[4 * e + 3]}};
-                Fp4 y1{{ev[4 * e + 4], ev[4 * e + 5], ev[4 * e + 6], ev[4 * e + 7]}};
-                Fp4 c1 = f4_mul(f4_sub(y1, y0), f4_inv(f4_sub(Zb, Z)));
-                Fp4 c0 = f4_sub(y0, f4_mul(c1, Z));
-                coeff_u.insert(coeff_u.end(), c0.c, c0.c + 4);
-                coeff_u.insert(coeff_u.end(), c1.c, c1.c + 4);
-                e += 2;
+        for (int g = 0; g < 4; ++g) {
+            Group& G = p->groups[g];
+            for (uint32_t col = 0; col < G.width; ++col) {
+                if (G.taps[col] == 1) {
+                    coeff_u.insert(coeff_u.end(), ev.begin() + 4 * e, ev.begin() + 4 * e + 4);
+                    e += 1;
+                } else {
+                    // line through (Z, y0), (Zb, y1): c1 = (y1 - y0)/(Zb - Z), c0 = y0 - c1*Z
+                    Fp4 y0{{ev[4 * e], ev[4 * e + 1], ev[4 * e + 2], ev[4 * e + 3]}};
+                    Fp4 y1{{ev[4 * e + 4], ev[4 * e + 5], ev[4 * e + 6], ev[4 * e + 7]}};
+                    Fp4 c1 = f4_mul(f4_sub(y1, y0), f4_inv(f4_sub(Zb, Z)));
+                    Fp4 c0 = f4_sub(y0, f4_mul(c1, Z));
+                    coeff_u.insert(coeff_u.end(), c0.c, c0.c + 4);
+                    coeff_u.insert(coeff_u.end(), c1.c, c1.c + 4);
+                    e += 2;
+                }
             }
         }
     }
@@ -450,13 +474,13 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         }
         // combos 0 and 1 collect the trace groups (bit-reversed storage), combo 2 only the check group (natural order)
         if (p->coeffs_bitrev) PV(bx_batch_bit_reverse_ext(c, p->combos.slice(0, 8 * N), 2));
-        for (int id = 0; id < 3; ++id) {
-            uint32_t low[8];
-            bx_buf head = p->combos.slice((size_t)id * 4 * N, 8);
-            PV(bx_d2h(c, low, head, 8));
-            for (int t = 0; t < 2; ++t)
-                for (int k = 0; k < 4; ++k) low[4 * t + k] = fp_sub(low[4 * t + k], combo_u[id][t].c[k]);
-            PV(bx_h2d(c, head, low, 8));
+        {   // subtract the mixed u polynomials (degree < 2) from the low coefficients of the three combos, on the device
+            SubLow sl;
+            for (int id = 0; id < 3; ++id)
+                for (int t = 0; t < 2; ++t)
+                    for (int k = 0; k < 4; ++k) sl.v[8 * id + 4 * t + k] = combo_u[id][t].c[k];
+            hipLaunchKernelGGL(sub_low_kernel, dim3(1), dim3(32), 0, c->stream, (uint32_t*)p->combos.b.dptr, (uint32_t)(4 * N), sl);
+            if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: sub_low launch failed");
         }
         PV(bx_poly_divide(c, p->combos.slice(0, 4 * N), Z.c, p->rems.slice(0, 4)));
         PV(bx_poly_divide(c, p->combos.slice(4 * N, 4 * N), Z.c, p->rems.slice(4, 4)));
@@ -496,23 +520,29 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         uint32_t pos0[BX_QUERIES];
         for (int q = 0; q < BX_QUERIES; ++q) pos0[q] = T.random_bits(bits) % (uint32_t)D;
         size_t n_trees = 4 + p->rounds.size();
-        std::vector<std::vector<uint32_t>> host(n_trees);
-        std::vector<size_t> qw(n_trees);
+        std::vector<size_t> qw(n_trees), off(n_trees + 1, 0);
+        std::vector<uint32_t> all_pos(n_trees * BX_QUERIES);
         uint32_t pos[BX_QUERIES];
         memcpy(pos, pos0, sizeof pos);
         for (size_t t = 0; t < n_trees; ++t) {
             Tree& tr = t < 4 ? p->groups[t].tree : p->rounds[t - 4].tree;
-            bx_buf matrix = t < 4 ? p->groups[t].evaluated.b : p->rounds[t - 4].evaluated.b;
             if (t >= 4)
                 for (int q = 0; q < BX_QUERIES; ++q) pos[q] %= (uint32_t)tr.rows;  // group = pos % (domain / FRI_FOLD)
+            memcpy(all_pos.data() + t * BX_QUERIES, pos, sizeof pos);
             qw[t] = tr.query_words();
-            PV(bx_h2d(c, p->positions.b, pos, BX_QUERIES));
-            PV(bx_merkle_query_gather(c, p->qout.b, matrix, tr.nodes.b, tr.rows, tr.cols, p->positions.b, BX_QUERIES, tr.top_size()));
-            host[t].resize(qw[t] * BX_QUERIES);
-            PV(bx_d2h(c, host[t].data(), p->qout.b, host[t].size()));
+            off[t + 1] = off[t] + qw[t] * BX_QUERIES;
         }
+        PV(bx_h2d(c, p->positions.b, all_pos.data(), all_pos.size()));
+        for (size_t t = 0; t < n_trees; ++t) {
+            Tree& tr = t < 4 ? p->groups[t].tree : p->rounds[t - 4].tree;
+            bx_buf matrix = t < 4 ? p->groups[t].evaluated.b : p->rounds[t - 4].evaluated.b;
+            PV(bx_merkle_query_gather(c, p->qout.slice(off[t], qw[t] * BX_QUERIES), matrix, tr.nodes.b, tr.rows, tr.cols,
+                                      p->positions.slice(t * BX_QUERIES, BX_QUERIES), BX_QUERIES, tr.top_size()));
+        }
+        std::vector<uint32_t> host_all(off[n_trees]);
+        PV(bx_d2h(c, host_all.data(), p->qout.slice(0, off[n_trees]), off[n_trees]));
         for (int q = 0; q < BX_QUERIES; ++q)
-            for (size_t t = 0; t < n_trees; ++t) T.write(host[t].data() + (size_t)q * qw[t], qw[t]);
+            for (size_t t = 0; t < n_trees; ++t) T.write(host_all.data() + off[t] + (size_t)q * qw[t], qw[t]);
     }
     if (seal_words) *seal_words = T.seal.size();
     if (T.seal.size() > seal_cap) return perr(p, "bx_prove_segment: seal buffer too small");
