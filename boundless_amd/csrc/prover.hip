@@ -187,15 +187,11 @@ const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
     bx_ctx* c = p->c;
     PV(bx_merkle_build(c, t.nodes.b, matrix, t.rows));
     size_t top = t.top_size();
-    std::vector<uint32_t> host(8 * top + 8);
-    // top layer nodes[top..2*top) and the root nodes[1]
-    PV(bx_d2h(c, host.data(), t.nodes.slice(8 * top, 8 * top), 8 * top));
-    if (top == 1) {
-        memcpy(t.root, host.data(), 32);
-    } else {
-        PV(bx_d2h(c, t.root, t.nodes.slice(8, 8), 8));
-    }
-    T.write(host.data(), 8 * top);
+    // the root nodes[1] and the top layer nodes[top..2*top) are the two ends of one contiguous run: one copy
+    std::vector<uint32_t> host(8 * (2 * top - 1));
+    PV(bx_d2h(c, host.data(), t.nodes.slice(8, host.size()), host.size()));
+    memcpy(t.root, host.data(), 32);
+    T.write(host.data() + 8 * (top - 1), 8 * top);
     T.commit(t.root);
     return nullptr;
 }
