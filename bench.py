@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
     ap.add_argument("--cpu-sample-po2", type=int, default=16)
+    ap.add_argument("--dump", type=str, default=None, help="directory: every rank writes rank{r}.npz with the segment indices it claimed in the timed region and their seals (parity tests of the N>1 path)")
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
 
@@ -171,6 +172,7 @@ def main():
         lock = threading.Lock()
         done = [0]
         last = [None]
+        claimed = {}
 
         def worker(sv):
             while True:
@@ -182,6 +184,8 @@ def main():
                         return
                     done[0] += 1
                 last[0] = sv.prove_segment(Segment.synthetic(index=idx, po2=args.po2))
+                if args.dump and tag == "timed":
+                    claimed[idx] = last[0].seal
 
         if len(servers) == 1:
             worker(servers[0])
@@ -189,6 +193,13 @@ def main():
             ts = [threading.Thread(target=worker, args=(sv,)) for sv in servers]
             [t.start() for t in ts]
             [t.join() for t in ts]
+        if args.dump and tag == "timed":
+            import numpy as np
+
+            os.makedirs(args.dump, exist_ok=True)
+            order = sorted(claimed)
+            np.savez(os.path.join(args.dump, f"rank{rank}.npz"), indices=np.array(order, dtype=np.int64),
+                     **{f"seal_{i}": claimed[i] for i in order})
         return done[0], last[0]
 
     per_rank = args.steps * len(servers)
