@@ -1,0 +1,282 @@
+// circuit.hip — device side of the synthetic circuit that stands in for risc0-circuit-rv32im under
+// `ProverServer::prove_segment` (bento/crates/workflow/src/tasks/prove.rs:41-49): witness generation, the accumulate
+// step and eval_check.  include/bx_prover.h ("The synthetic circuit") is the normative text; circuit.hpp holds the shape
+// rules shared with the host verifier.  Upstream's counterparts are the machine-generated `witgen`/`step_exec`, `accum`
+// and `eval_check` kernels of risc0-circuit-rv32im-sys 4.0.1 (reference Cargo.lock:8996), which are not vendored.
+//
+// All three stages are VALU-bound (no HBM or MFMA roofline applies): a derived cell / a constraint costs T*(G-1)
+// Montgomery products, the loads around it are one coalesced dword per lane and column.
+#include "circuit.hpp"
+#include "ctx.hpp"
+#include "circuit_dev.hpp"
+
+namespace bx {
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
+    uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
+    return v >= P ? v - P : v;
+}
+
+// ---- witness: code group (selectors + public control words) ----
+__global__ void witness_code_kernel(uint32_t* __restrict__ code, Circuit cc, uint64_t gseed) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.wc, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t c = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        code[i] = c == 0 ? (r == 0 ? MONT_ONE : 0u) : c == 1 ? (r == n - 1 ? MONT_ONE : 0u) : synth_word(gseed, c, r);
+    }
+}
+// ---- witness: free data columns (the permuted copies 4p+3, p < pairs, are placed by Hal::scatter afterwards) ----
+__global__ void witness_free_kernel(uint32_t* __restrict__ data, Circuit cc, uint64_t gseed) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.F, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t c = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        if ((c & 3u) == 3u && (c >> 2) < cc.pairs) continue;
+        data[i] = synth_word(gseed, c, r);
+    }
+}
+// offsets of pair p's scatter: entry r of column 4p+2 goes to column 4p+3, row perm_p(r)   (built once per prover)
+__global__ void perm_offsets_kernel(uint32_t* __restrict__ offsets, uint32_t* __restrict__ index, Circuit cc) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.pairs, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t p = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        offsets[i] = (4 * p + 3) * n + cc.perm_row(p, r);
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) index[i] = (uint32_t)i;  // one entry per cycle
+}
+
+// ---- witness: derived data columns, one thread per row, columns in order (column F+j reads F+j-1 .. F+j-4) ----
+template <int TT, int GG>
+__global__ __launch_bounds__(256) void witness_derive_kernel(uint32_t* __restrict__ data, const uint32_t* __restrict__ code, Circuit cc) {
+    const uint32_t n = 1u << cc.po2;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t rb = (r + n - 1) & (n - 1);
+    uint32_t ring[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = cc.csel_col((unsigned)q);
+        ring[q] = col < 0 ? MONT_ONE : code[(size_t)col * n + r];
+    }
+    for (uint32_t j = 0; j < cc.J; ++j) {
+        uint32_t pool[Circuit::POOL];
+        pool[0] = data[(size_t)j * n + r];
+        pool[1] = (j & 3u) == 0 ? data[(size_t)j * n + rb] : pool[0];
+        pool[2] = ring[0]; pool[3] = ring[1]; pool[4] = ring[2]; pool[5] = ring[3];
+        const int ck = cc.csel_col(j);
+        pool[6] = ck < 0 ? MONT_ONE : code[(size_t)ck * n + r];
+        const uint32_t d = cons_sum<TT, GG>(pool, cc.T, cc.G);
+        data[(size_t)(cc.F + j) * n + r] = d;
+        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = d;
+    }
+}
+
+// ---- accumulate: the columns the accumulators run over are saved before the data group is interpolated in place ----
+__global__ void accum_gather_kernel(uint32_t* __restrict__ srcvals, const uint32_t* __restrict__ data, Circuit cc) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.E, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t e = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        srcvals[i] = data[(size_t)cc.acc_src(e) * n + r];
+    }
+}
+// run[e][r] = beta_e + x (AoS ext), the input of Hal::prefix_products
+__global__ void accum_build_kernel(uint32_t* __restrict__ run, const uint32_t* __restrict__ srcvals, const uint32_t* __restrict__ betas, Circuit cc) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.E, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t e = (uint32_t)(i >> cc.po2);
+        const uint4 b = *reinterpret_cast<const uint4*>(betas + 4 * e);  // wave-uniform
+        *reinterpret_cast<uint4*>(run + 4 * i) = make_uint4(fp_add(b.x, srcvals[i]), b.y, b.z, b.w);
+    }
+}
+// accumulator e, component k -> accum column 4e+k; columns >= 4E are noise
+__global__ void accum_store_kernel(uint32_t* __restrict__ accum, const uint32_t* __restrict__ run, Circuit cc, uint64_t gseed) {
+    const uint32_t n = 1u << cc.po2;
+    const size_t total = (size_t)n * cc.E, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t e = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        const uint4 v = *reinterpret_cast<const uint4*>(run + 4 * i);
+        uint32_t* o = accum + (size_t)(4 * e) * n + r;
+        o[0] = v.x; o[n] = v.y; o[2 * (size_t)n] = v.z; o[3 * (size_t)n] = v.w;
+    }
+    const size_t noise = (size_t)n * (cc.wa - 4 * cc.E);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < noise; i += stride) {
+        const uint32_t c = 4 * cc.E + (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
+        accum[(size_t)c * n + r] = synth_word(gseed, c, r);
+    }
+}
+
+// ---- eval_check: check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1) on the 4N domain, one thread per domain point ----
+struct ZInv {
+    uint32_t v[4];  // 1 / (3^N w_4^m - 1), m = row mod 4
+};
+template <int TT, int GG>
+__global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ check, const uint32_t* __restrict__ ecode,
+                                                         const uint32_t* __restrict__ edata, const uint32_t* __restrict__ eacc, Circuit cc,
+                                                         const uint32_t* __restrict__ mixpows, const uint32_t* __restrict__ betas, ZInv zinv) {
+    const uint32_t dom = 4u << cc.po2;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dom) return;
+    const uint32_t ib = (i + dom - 4u) & (dom - 1u);  // one row back: x * w_N^-1 = w_4N^(row - 4)
+    Fp4 tot = f4_zero();
+    uint32_t ring[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = cc.csel_col((unsigned)q);
+        ring[q] = col < 0 ? MONT_ONE : ecode[(size_t)col * dom + i];
+    }
+    for (uint32_t j = 0; j < cc.J; ++j) {
+        uint32_t pool[Circuit::POOL];
+        pool[0] = edata[(size_t)j * dom + i];
+        pool[1] = (j & 3u) == 0 ? edata[(size_t)j * dom + ib] : pool[0];
+        pool[2] = ring[0]; pool[3] = ring[1]; pool[4] = ring[2]; pool[5] = ring[3];
+        const int ck = cc.csel_col(j);
+        pool[6] = ck < 0 ? MONT_ONE : ecode[(size_t)ck * dom + i];
+        const uint32_t d = edata[(size_t)(cc.F + j) * dom + i];
+        const uint32_t cons = fp_sub(d, cons_sum<TT, GG>(pool, cc.T, cc.G));
+        const uint4 m = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)j);  // wave-uniform
+        tot = f4_add(tot, f4_scale(Fp4{{m.x, m.y, m.z, m.w}}, cons));
+        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = d;
+    }
+    const uint32_t first = ecode[i];
+    for (uint32_t e = 0; e < cc.E; ++e) {
+        Fp4 a, ab;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a.c[k] = eacc[(size_t)(4 * e + k) * dom + i];
+            ab.c[k] = eacc[(size_t)(4 * e + k) * dom + ib];
+        }
+        Fp4 inner = f4_scale(ab, fp_sub(MONT_ONE, first));
+        inner.c[0] = fp_add(inner.c[0], first);
+        const uint4 b = *reinterpret_cast<const uint4*>(betas + 4 * (size_t)e);
+        Fp4 fac{{fp_add(b.x, edata[(size_t)cc.acc_src(e) * dom + i]), b.y, b.z, b.w}};
+        const uint4 m = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)(cc.J + e));
+        tot = f4_add(tot, f4_mul(Fp4{{m.x, m.y, m.z, m.w}}, f4_sub(a, f4_mul(inner, fac))));
+    }
+    if (cc.pairs) {
+        const uint32_t last = ecode[(size_t)dom + i];
+        for (uint32_t p = 0; p < cc.pairs; ++p) {
+            Fp4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                d.c[k] = fp_sub(eacc[(size_t)(4 * (2 * p + 1) + k) * dom + i], eacc[(size_t)(4 * (2 * p) + k) * dom + i]);
+            const uint4 m = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)(cc.J + cc.E + p));
+            tot = f4_add(tot, f4_mul(Fp4{{m.x, m.y, m.z, m.w}}, f4_scale(d, last)));
+        }
+    }
+    tot = f4_scale(tot, zinv.v[i & 3u]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) check[(size_t)k * dom + i] = tot.c[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-side launchers (called by prover.hip); each returns NULL or an error string owned by the ctx
+// ---------------------------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(size_t n, unsigned bs = 256, size_t cap = 1 << 16) {
+    size_t b = (n + bs - 1) / bs;
+    return (unsigned)(b > cap ? cap : (b ? b : 1));
+}
+
+#define BX_CIRCUIT_DISPATCH(KERNEL, ...)                                              \
+    do {                                                                              \
+        if (cc.T == 16 && cc.G == 3) hipLaunchKernelGGL((KERNEL<16, 3>), __VA_ARGS__); \
+        else if (cc.T == 32 && cc.G == 3) hipLaunchKernelGGL((KERNEL<32, 3>), __VA_ARGS__); \
+        else if (cc.T == 8 && cc.G == 2) hipLaunchKernelGGL((KERNEL<8, 2>), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<0, 0>), __VA_ARGS__);                          \
+    } while (0)
+
+const char* circuit_perm_tables(bx_ctx* c, const Circuit& cc, bx_buf offsets, bx_buf index) {
+    const size_t n = (size_t)1 << cc.po2;
+    BX_REQUIRE(c, offsets.len >= n * cc.pairs && index.len >= n + 1, "circuit_perm_tables: buffers too small");
+    hipLaunchKernelGGL(perm_offsets_kernel, dim3(grid_for(n * (cc.pairs ? cc.pairs : 1))), dim3(256), 0, c->stream, (uint32_t*)offsets.dptr,
+                       (uint32_t*)index.dptr, cc);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+// code + data witness.  `data`/`code` are the groups' column-major N x width buffers; the permuted copies go through
+// Hal::scatter (one call per pair, one entry per cycle), the derived columns through one thread per row.
+const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, bx_buf perm_offsets,
+                            bx_buf perm_index) {
+    const size_t n = (size_t)1 << cc.po2;
+    BX_REQUIRE(c, code.len == n * cc.wc && data.len == n * cc.wd, "circuit_witness: group buffer size mismatch");
+    {
+        OpScope op(c, "witgen_fill", 4.0 * (double)(n * (cc.wc + cc.F)));
+        hipLaunchKernelGGL(witness_code_kernel, dim3(grid_for(n * cc.wc)), dim3(256), 0, c->stream, (uint32_t*)code.dptr, cc, seed_code);
+        BX_LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(witness_free_kernel, dim3(grid_for(n * cc.F)), dim3(256), 0, c->stream, (uint32_t*)data.dptr, cc, seed_data);
+        BX_LAUNCH_CHECK(c);
+    }
+    for (uint32_t p = 0; p < cc.pairs; ++p) {
+        bx_buf values{(uint32_t*)data.dptr + (size_t)(4 * p + 2) * n, n};
+        bx_buf offs{(uint32_t*)perm_offsets.dptr + (size_t)p * n, n};
+        BX_TRY(bx_scatter(c, data, bx_buf{perm_index.dptr, n + 1}, offs, values));
+    }
+    if (cc.J) {
+        OpScope op(c, "witgen_derive", 4.0 * (double)(n * (cc.J + cc.J + cc.J / 4)));
+        BX_CIRCUIT_DISPATCH(witness_derive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)data.dptr,
+                            (const uint32_t*)code.dptr, cc);
+        BX_LAUNCH_CHECK(c);
+    }
+    return nullptr;
+}
+
+const char* circuit_accum_gather(bx_ctx* c, const Circuit& cc, bx_buf srcvals, bx_buf data) {
+    const size_t n = (size_t)1 << cc.po2;
+    if (!cc.E) return nullptr;
+    BX_REQUIRE(c, srcvals.len >= n * cc.E, "circuit_accum_gather: buffer too small");
+    OpScope op(c, "accum_gather", 8.0 * (double)(n * cc.E));
+    hipLaunchKernelGGL(accum_gather_kernel, dim3(grid_for(n * cc.E)), dim3(256), 0, c->stream, (uint32_t*)srcvals.dptr, (const uint32_t*)data.dptr, cc);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+// the accumulate step: run = beta_e + x  ->  Hal::prefix_products  ->  accum columns (+ noise columns)
+const char* circuit_accumulate(bx_ctx* c, const Circuit& cc, bx_buf accum, bx_buf run, bx_buf srcvals, bx_buf betas_dev, uint64_t seed_accum) {
+    const size_t n = (size_t)1 << cc.po2;
+    BX_REQUIRE(c, accum.len == n * cc.wa, "circuit_accumulate: group buffer size mismatch");
+    if (cc.E) {
+        BX_REQUIRE(c, run.len >= 4 * n * cc.E && srcvals.len >= n * cc.E && betas_dev.len >= 4 * cc.E, "circuit_accumulate: buffers too small");
+        {
+            OpScope op(c, "accum_build", 20.0 * (double)(n * cc.E));
+            hipLaunchKernelGGL(accum_build_kernel, dim3(grid_for(n * cc.E)), dim3(256), 0, c->stream, (uint32_t*)run.dptr,
+                               (const uint32_t*)srcvals.dptr, (const uint32_t*)betas_dev.dptr, cc);
+            BX_LAUNCH_CHECK(c);
+        }
+        BX_TRY(bx_batch_prefix_products(c, bx_buf{run.dptr, 4 * n * cc.E}, cc.E));
+    }
+    OpScope op(c, "accum_store", 4.0 * (double)(n * cc.wa) + 16.0 * (double)(n * cc.E));
+    hipLaunchKernelGGL(accum_store_kernel, dim3(grid_for(n * (cc.wa ? cc.wa : 1))), dim3(256), 0, c->stream, (uint32_t*)accum.dptr,
+                       (const uint32_t*)run.dptr, cc, seed_accum);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+// eval_check over the committed 4N evaluations; `check` receives the four ext planes of check(x) over the domain
+const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, bx_buf mixpows, bx_buf betas_dev,
+                               const uint32_t zinv[4]) {
+    const size_t dom = (size_t)4 << cc.po2;
+    BX_REQUIRE(c, check.len == 4 * dom && ecode.len == dom * cc.wc && edata.len == dom * cc.wd && eacc.len == dom * cc.wa,
+               "circuit_eval_check: buffer size mismatch");
+    BX_REQUIRE(c, mixpows.len >= 4 * cc.constraints(), "circuit_eval_check: mix power table too small");
+    ZInv z;
+    for (int m = 0; m < 4; ++m) z.v[m] = zinv[m];
+    // every committed evaluation is read once (plus the one-row-back taps), the check planes are written once
+    OpScope op(c, "eval_check", 4.0 * (double)dom * (cc.wc + cc.wd + cc.J / 4.0 + 2.0 * cc.wa + 4.0));
+    BX_CIRCUIT_DISPATCH(eval_check_kernel, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)check.dptr,
+                        (const uint32_t*)ecode.dptr, (const uint32_t*)edata.dptr, (const uint32_t*)eacc.dptr, cc, (const uint32_t*)mixpows.dptr,
+                        (const uint32_t*)betas_dev.dptr, z);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+}  // namespace bx

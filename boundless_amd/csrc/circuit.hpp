@@ -1,0 +1,56 @@
+// circuit.hpp — shape of the synthetic circuit that stands in for risc0-circuit-rv32im (include/bx_prover.h, "The
+// synthetic circuit", is the normative text): which columns are free / derived / accumulators, which have a tap one row
+// back, which pool entry is factor f of term t.  Shared by the prover (prover.hip, circuit.hip) and the host verifier
+// (verify.cpp).  The test oracle under oracle/ restates the same rules independently.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/bx_prover.h"
+
+#if defined(__HIPCC__)
+#define BX_CIRC_HD __host__ __device__
+#else
+#define BX_CIRC_HD
+#endif
+
+namespace bx {
+
+struct Circuit {
+    static constexpr unsigned POOL = 7;  // u, u one row back, the four previous derived columns, a code column
+    uint32_t po2, wc, wd, wa, T, G;
+    uint32_t F, J, E, pairs;
+    Circuit() = default;
+    Circuit(uint32_t po2_, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree)
+        : po2(po2_), wc(w_code), wd(w_data), wa(w_accum), T(terms ? terms : BX_CIRCUIT_DEFAULT_TERMS),
+          G(degree ? degree : BX_CIRCUIT_DEFAULT_DEGREE) {
+        F = (wd + 1) / 2;  // free data columns [0, F); derived [F, wd)
+        J = wd - F;
+        E = wa / 4;  // ext accumulators; accum columns [4E, wa) are noise
+        pairs = 0;
+        while (2 * pairs + 1 < E && 4 * pairs + 3 < F) ++pairs;
+        if (wc < 2) pairs = 0;  // the closing constraint needs the `last` selector (code column 1)
+    }
+    size_t constraints() const { return (size_t)J + E + pairs; }
+    BX_CIRC_HD static constexpr unsigned pool_idx(unsigned t, unsigned f) { return (3 * t + t / 7 + f * (2 * (t % 3) + 1)) % POOL; }
+    // code column behind csel(i), or -1 for the constant one (fewer than three code columns)
+    BX_CIRC_HD int csel_col(unsigned i) const { return wc >= 3 ? (int)(2 + i % (wc - 2)) : -1; }
+    // data column accumulator e runs over
+    BX_CIRC_HD uint32_t acc_src(uint32_t e) const {
+        const uint32_t p = e / 2;
+        if (p < pairs) return (e & 1) ? 4 * p + 3 : 4 * p + 2;
+        return e % F;
+    }
+    // row permutation of pair p: data[4p+3][perm(r)] = data[4p+2][r]
+    BX_CIRC_HD uint32_t perm_row(uint32_t p, uint32_t r) const {
+        return (uint32_t)(((uint64_t)r * 2654435761ull + 12345u + p) & (((uint64_t)1 << po2) - 1));
+    }
+    // taps of column c of group g (0 code, 1 data, 2 accum, 3 check): 2 = also opened one row back
+    BX_CIRC_HD uint32_t taps_of(int g, uint32_t c) const {
+        if (g == 1) return c % 4 == 0 ? 2u : 1u;
+        if (g == 2) return c < 4 * E ? 2u : 1u;
+        return 1u;
+    }
+};
+
+}  // namespace bx

@@ -60,6 +60,11 @@ struct bx_ctx {
     uint32_t h_diag[24];
     uint32_t* d_p2 = nullptr;
 
+    // deferred device-side errors (e.g. a scatter offset out of range): kernels OR bits into *d_flag, the blocking entry
+    // points (bx_d2h, bx_sync) copy it to the pinned *h_flag with their own synchronisation and report it
+    uint32_t* d_flag = nullptr;
+    uint32_t* h_flag = nullptr;
+
     // scratch (grown on demand)
     uint32_t* d_scratch = nullptr;
     size_t scratch_words = 0;
@@ -130,8 +135,21 @@ struct OpScope {
 
 // internal launchers shared between translation units (each returns NULL or an error string)
 const char* ensure_scratch(bx_ctx* c, size_t words);
+constexpr uint32_t FLAG_SCATTER_RANGE = 1u;  // bits of bx_ctx::d_flag
+constexpr uint32_t FLAG_SCATTER_INDEX = 2u;
+const char* sync_and_check_flag(bx_ctx* c);  // hipStreamSynchronize + deferred device errors
 const char* ntt_init_tables(bx_ctx* c);
 void ntt_free_tables(bx_ctx* c);
 const char* poseidon2_upload_params(bx_ctx* c);
+
+// the synthetic circuit's device stages (circuit.hip), driven by prover.hip
+struct Circuit;
+const char* circuit_perm_tables(bx_ctx* c, const Circuit& cc, bx_buf offsets, bx_buf index);
+const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, bx_buf perm_offsets,
+                            bx_buf perm_index);
+const char* circuit_accum_gather(bx_ctx* c, const Circuit& cc, bx_buf srcvals, bx_buf data);
+const char* circuit_accumulate(bx_ctx* c, const Circuit& cc, bx_buf accum, bx_buf run, bx_buf srcvals, bx_buf betas_dev, uint64_t seed_accum);
+const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, bx_buf mixpows, bx_buf betas_dev,
+                               const uint32_t zinv[4]);
 
 }  // namespace bx

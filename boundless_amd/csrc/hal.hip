@@ -78,6 +78,12 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
         delete c;
         return "bx_init: hipEventCreate failed";
     }
+    if (hipMalloc(&c->d_flag, 4) != hipSuccess || hipMemset(c->d_flag, 0, 4) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_flag, 4, hipHostMallocDefault) != hipSuccess) {
+        bx_free(c);
+        return "bx_init: allocating the device error flag failed";
+    }
+    *c->h_flag = 0;
     // constants sanity (fp.hpp literals vs. computed)
     if (fp_encode(1u) != MONT_ONE || fp_encode(P - 11u) != MONT_NBETA || fp_encode(11u) != MONT_BETA ||
         fp_encode(3u) != MONT_THREE) {
@@ -100,6 +106,22 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
     return nullptr;
 }
 
+namespace bx {
+const char* sync_and_check_flag(bx_ctx* c) {
+    BX_HIP(c, hipMemcpyAsync(c->h_flag, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    BX_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t f = *c->h_flag;
+    if (f) {
+        BX_HIP(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+        *c->h_flag = 0;
+        if (f & FLAG_SCATTER_RANGE) return set_msg(c, "scatter: an offset is outside the destination buffer");
+        if (f & FLAG_SCATTER_INDEX) return set_msg(c, "scatter: index range exceeds offsets/values");
+        return set_msg(c, "deferred device error");
+    }
+    return nullptr;
+}
+}  // namespace bx
+
 extern "C" const char* bx_free(bx_ctx* c) {
     if (!c) return nullptr;
     (void)hipSetDevice(c->device);
@@ -108,6 +130,8 @@ extern "C" const char* bx_free(bx_ctx* c) {
     ntt_free_tables(c);
     if (c->d_p2) (void)hipFree(c->d_p2);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -163,8 +187,7 @@ extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words
     BX_REQUIRE(c, words <= src.len, "bx_d2h: copy larger than the buffer");
     BX_HIP(c, hipSetDevice(c->device));
     BX_HIP(c, hipMemcpyAsync(dst, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
-    return nullptr;
+    return sync_and_check_flag(c);
 }
 extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) {
     if (!c) return "bx_d2d: null ctx";
@@ -176,8 +199,7 @@ extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) {
 extern "C" const char* bx_sync(bx_ctx* c) {
     if (!c) return "bx_sync: null ctx";
     BX_HIP(c, hipSetDevice(c->device));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
-    return nullptr;
+    return sync_and_check_flag(c);
 }
 
 extern "C" const char* bx_timer_start(bx_ctx* c) {

@@ -245,9 +245,12 @@ __global__ void div_apply_kernel(uint32_t* __restrict__ poly, size_t size, Fp4 z
 
 // ---- prefix_products: inclusive running product of ext elements, same three-phase shape as poly_divide ----
 constexpr int PP_L = 64;
+// blockIdx.y = sequence of a batch (each with its own n elements of io and `chunks` aggregates)
 __global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, uint32_t* __restrict__ agg, size_t chunks) {
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= chunks) return;
+    io += 4 * n * blockIdx.y;
+    agg += 4 * chunks * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = f4_one();
     for (size_t i = lo; i < hi; ++i) p = f4_mul(p, ld4(io + 4 * i));
@@ -256,6 +259,7 @@ __global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, uint3
 // agg[ch] <- product of all chunks before ch (exclusive scan), one workgroup, log-step scan across threads
 __global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks) {
     extern __shared__ uint32_t sh[];
+    agg += 4 * chunks * blockIdx.x;
     const uint32_t nt = blockDim.x, tid = threadIdx.x;
     size_t per = (chunks + nt - 1) / nt;
     size_t lo = (size_t)tid * per < chunks ? (size_t)tid * per : chunks;
@@ -281,6 +285,8 @@ __global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks) {
 __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint32_t* __restrict__ carry_in, size_t chunks) {
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= chunks) return;
+    io += 4 * n * blockIdx.y;
+    carry_in += 4 * chunks * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = ld4(carry_in + 4 * ch);
     for (size_t i = lo; i < hi; ++i) {
@@ -288,15 +294,24 @@ __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint3
         st4(io + 4 * i, p);
     }
 }
-__global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __restrict__ index, const uint32_t* __restrict__ offsets,
-                               const uint32_t* __restrict__ values, size_t entries, size_t into_len, uint32_t first, uint32_t* __restrict__ bad) {
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x + first;
-    if (e >= entries) return;
-    uint32_t o = offsets[e];
+// entries [index[0], index[last]) are written.  The per-cycle grouping of upstream's scatter only orders writes that hit
+// the same offset, which its circuits never produce, so one pass over the range is equivalent.  Nothing is read back by
+// the host: a bad offset or index range raises a bit of the ctx's deferred error flag (reported by the next bx_d2h / bx_sync).
+__global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __restrict__ index, size_t index_len,
+                               const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ values, size_t entries, size_t into_len,
+                               uint32_t* __restrict__ flag) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = index[0], hi = index[index_len - 1];  // wave-uniform
+    if (lo > hi || hi > entries) {
+        if (e == 0) atomicOr(flag, FLAG_SCATTER_INDEX);
+        return;
+    }
+    if (e < lo || e >= hi) return;
+    const uint32_t o = offsets[e];
     if (o < into_len) {
         into[o] = values[e];
     } else {
-        *bad = 1u;
+        atomicOr(flag, FLAG_SCATTER_RANGE);
     }
 }
 
@@ -467,25 +482,31 @@ extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4
     return nullptr;
 }
 
-extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) {
-    if (!c) return "bx_prefix_products: null ctx";
+extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t count) {
+    if (!c) return "bx_batch_prefix_products: null ctx";
     BX_REQUIRE(c, io.len % 4 == 0, "prefix_products: buffer must hold AoS ext elements");
+    BX_REQUIRE(c, count >= 1 && (io.len / 4) % count == 0, "prefix_products: the buffer does not split into `count` equal sequences");
+    BX_REQUIRE(c, count <= 65535, "prefix_products: too many sequences");
     BX_HIP(c, hipSetDevice(c->device));
-    size_t n = io.len / 4;
+    size_t n = io.len / 4 / count;
     if (n < 2) return nullptr;
     OpScope op(c, "prefix_products", 8.0 * (double)io.len);
     size_t chunks = (n + PP_L - 1) / PP_L;
-    BX_TRY(ensure_scratch(c, 4 * chunks + 8));
-    hipLaunchKernelGGL(pp_local_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)io.dptr, n,
-                       c->d_scratch, chunks);
+    BX_TRY(ensure_scratch(c, 4 * chunks * count + 8));
+    hipLaunchKernelGGL(pp_local_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream,
+                       (const uint32_t*)io.dptr, n, c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);
     unsigned nt = chunks >= 1024 ? 1024 : 64;
-    hipLaunchKernelGGL(pp_scan_kernel, dim3(1), dim3(nt), nt * 16, c->stream, c->d_scratch, chunks);
+    hipLaunchKernelGGL(pp_scan_kernel, dim3((unsigned)count), dim3(nt), nt * 16, c->stream, c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(pp_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n,
+    hipLaunchKernelGGL(pp_apply_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n,
                        c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);
     return nullptr;
+}
+extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) {
+    if (!c) return "bx_prefix_products: null ctx";
+    return bx_batch_prefix_products(c, io, 1);
 }
 
 extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf offsets, bx_buf values) {
@@ -493,25 +514,12 @@ extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf o
     BX_REQUIRE(c, offsets.len == values.len, "scatter: offsets and values must have the same length");
     BX_HIP(c, hipSetDevice(c->device));
     if (index.len < 2 || offsets.len == 0) return nullptr;
-    // entries [index[0], index[last]) are written; the per-cycle grouping only orders writes that hit the same offset,
-    // which upstream's circuits never produce, so one pass over the range is equivalent.
-    uint32_t ends[2];
-    BX_HIP(c, hipMemcpyAsync(&ends[0], index.dptr, 4, hipMemcpyDeviceToHost, c->stream));
-    BX_HIP(c, hipMemcpyAsync(&ends[1], (const uint32_t*)index.dptr + (index.len - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
-    BX_REQUIRE(c, ends[0] <= ends[1] && ends[1] <= offsets.len, "scatter: index range exceeds offsets/values");
-    if (ends[0] == ends[1]) return nullptr;
-    OpScope op(c, "scatter", 12.0 * (double)(ends[1] - ends[0]));
-    BX_TRY(ensure_scratch(c, 8));
-    BX_HIP(c, hipMemsetAsync(c->d_scratch, 0, 4, c->stream));
-    size_t cnt = ends[1] - ends[0];
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)into.dptr,
-                       (const uint32_t*)index.dptr, (const uint32_t*)offsets.dptr, (const uint32_t*)values.dptr, (size_t)ends[1],
-                       into.len, ends[0], c->d_scratch);
+    // asynchronous like every other entry point: range errors are raised on the device and reported by the next
+    // blocking call on this ctx (bx_d2h / bx_sync)
+    OpScope op(c, "scatter", 12.0 * (double)offsets.len);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((offsets.len + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)into.dptr,
+                       (const uint32_t*)index.dptr, index.len, (const uint32_t*)offsets.dptr, (const uint32_t*)values.dptr, offsets.len,
+                       into.len, c->d_flag);
     BX_LAUNCH_CHECK(c);
-    uint32_t bad = 0;
-    BX_HIP(c, hipMemcpyAsync(&bad, c->d_scratch, 4, hipMemcpyDeviceToHost, c->stream));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
-    BX_REQUIRE(c, bad == 0, "scatter: an offset is outside the destination buffer");
     return nullptr;
 }

@@ -5,10 +5,11 @@
 // poly_group::PolyGroup} (risc0-zkp 3.0.3, reference Cargo.lock:9155) as called by
 // bento/crates/workflow/src/tasks/prove.rs:41-49.  The call sequence, constants (INV_RATE 4, FRI_FOLD 16,
 // FRI_MIN_DEGREE 256, QUERIES 50, CHECK_SIZE 16), Merkle top-layer rule and transcript order are upstream's; the
-// witness fill and the check polynomial are synthetic stand-ins (see bx_prover.h).
+// circuit (witness generation, accumulate, eval_check: circuit.hip) is the synthetic one specified in bx_prover.h.
 #include <algorithm>
 #include <memory>
 
+#include "circuit.hpp"
 #include "ctx.hpp"
 #include "transcript.hpp"
 #include "../../include/bx_prover.h"
@@ -17,58 +18,18 @@ namespace bx {
 
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
 
-__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
-    uint64_t z = x + GOLDEN;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__host__ __device__ inline uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
-    uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
-    return v >= P ? v - P : v;
-}
-
-// stand-in for witness generation: column-major rows x cols of pseudo-random field words
-__global__ void synth_fill_kernel(uint32_t* __restrict__ out, uint32_t rows, uint32_t cols, uint64_t seed) {
-    size_t total = (size_t)rows * cols, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
-        out[i] = synth_word(seed, (uint32_t)(i / rows), (uint32_t)(i % rows));
-}
 __global__ void ext_pows_kernel(uint32_t* __restrict__ out, Fp4 base, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fp4 r = f4_pow(base, i);
     out[4 * i + 0] = r.c[0]; out[4 * i + 1] = r.c[1]; out[4 * i + 2] = r.c[2]; out[4 * i + 3] = r.c[3];
 }
-// stand-in for eval_check: check[k][r] = sum_c mix^c * (e_c(r)^3 + e_c(r)) over every committed trace column.
-struct CheckArgs {
-    const uint32_t* eval[3];
-    uint32_t width[3];
-};
-__global__ __launch_bounds__(256) void synth_eval_check_kernel(uint32_t* __restrict__ check, CheckArgs a,
-                                                               const uint32_t* __restrict__ mixpows, uint32_t rows) {
-    // 4 consecutive rows per lane: 16-byte loads/stores, HBM-bound (every committed evaluation is read once)
-    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
-    if (r >= rows) return;
-    Fp4 acc[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};
-    uint32_t gi = 0;
-    for (int g = 0; g < 3; ++g) {
-        const uint32_t* e = a.eval[g] + r;
-        for (uint32_t c = 0; c < a.width[g]; ++c, ++gi) {
-            const uint4 v4 = *reinterpret_cast<const uint4*>(e + (size_t)c * rows);
-            const uint4 w4 = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)gi);  // wave-uniform
-            const Fp4 w{{w4.x, w4.y, w4.z, w4.w}};
-            const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t t = fp_add(fp_mul(fp_mul(v[k], v[k]), v[k]), v[k]);
-                acc[k] = f4_add(acc[k], f4_scale(w, t));
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<uint4*>(check + (size_t)k * rows + r) = make_uint4(acc[0].c[k], acc[1].c[k], acc[2].c[k], acc[3].c[k]);
+// beta_e = beta^(floor(e/2)+1): the two accumulators of a pair share their challenge
+__global__ void beta_table_kernel(uint32_t* __restrict__ out, Fp4 beta, uint32_t n) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fp4 r = f4_pow(beta, e / 2 + 1);
+    out[4 * e + 0] = r.c[0]; out[4 * e + 1] = r.c[1]; out[4 * e + 2] = r.c[2]; out[4 * e + 3] = r.c[3];
 }
 // MerkleTreeProver::prove for a batch of queries (one workgroup per query).
 __global__ void merkle_query_gather_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
@@ -150,11 +111,13 @@ using namespace bx;
 struct bx_prover {
     bx_ctx* c = nullptr;
     bx_segment_params shape{};
+    Circuit cc;
     size_t N = 0;
     bool coeffs_bitrev = false;  // trace coefficients stay in bit-reversed order (N >= 2^15), see commit_group
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
     DevBuf mixpows, combos, final_poly, which, xs, evals, rems, positions, qout;
+    DevBuf perm_offsets, perm_index, acc_src, acc_run, betas;  // the circuit's witness / accumulate scratch
     std::vector<FriRound> rounds;
     DevBuf final_coeffs;
     uint32_t last_roots[32];
@@ -247,11 +210,17 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
     BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 22, "bx_prover_create: po2 must be in [9, 22]");
     BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
+    BX_REQUIRE(c, shape->w_code < 65536 && shape->w_data < 65536 && shape->w_accum < 65536, "bx_prover_create: group width out of range");
+    BX_REQUIRE(c, shape->cons_terms <= BX_CIRCUIT_MAX_TERMS && shape->cons_degree <= BX_CIRCUIT_MAX_DEGREE,
+               "bx_prover_create: cons_terms must be <= 64 and cons_degree <= 5 (0 = default)");
     BX_HIP(c, hipSetDevice(c->device));
     std::unique_ptr<bx_prover> p(new (std::nothrow) bx_prover());
     BX_REQUIRE(c, p != nullptr, "bx_prover_create: out of host memory");
     p->c = c;
     p->shape = *shape;
+    p->cc = Circuit(shape->po2, shape->w_code, shape->w_data, shape->w_accum, shape->cons_terms, shape->cons_degree);
+    p->shape.cons_terms = p->cc.T;
+    p->shape.cons_degree = p->cc.G;
     p->N = (size_t)1 << shape->po2;
     p->coeffs_bitrev = shape->po2 >= 15 && c->deep_bitrev;
     p->err[0] = 0;
@@ -266,18 +235,25 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
         BX_TRY(G.coeffs.alloc(c, (size_t)G.width * N));
         BX_TRY(G.evaluated.alloc(c, (size_t)G.width * D));
         BX_TRY(tree_init(c, G.tree, D, G.width));
-        // synthetic tap set: every column is opened at Z; every 4th column of data/accum also one row back
-        G.taps.assign(G.width, 1);
-        if (g == 1 || g == 2)
-            for (uint32_t col = 0; col < G.width; col += 4) G.taps[col] = 2;
+        // the circuit's tap set: every column is opened at Z; data columns c % 4 == 0 and the accumulators also one row back
+        G.taps.resize(G.width);
+        for (uint32_t col = 0; col < G.width; ++col) G.taps[col] = p->cc.taps_of(g, col);
         std::vector<uint32_t> ids(G.width);
         for (uint32_t col = 0; col < G.width; ++col) ids[col] = g == 3 ? 2u : (G.taps[col] == 2 ? 1u : 0u);
         BX_TRY(G.combo_ids.alloc(c, G.width));
         BX_TRY(bx_h2d(c, G.combo_ids.b, ids.data(), G.width));
         for (uint32_t t : G.taps) total_taps += t;
     }
-    size_t w_total = (size_t)widths[0] + widths[1] + widths[2];
-    BX_TRY(p->mixpows.alloc(c, 4 * w_total));
+    {
+        const Circuit& cc = p->cc;
+        BX_TRY(p->mixpows.alloc(c, 4 * (cc.constraints() + 1)));
+        BX_TRY(p->perm_offsets.alloc(c, N * (cc.pairs ? cc.pairs : 1)));
+        BX_TRY(p->perm_index.alloc(c, N + 1));
+        BX_TRY(p->acc_src.alloc(c, N * (cc.E ? cc.E : 1)));
+        BX_TRY(p->acc_run.alloc(c, 4 * N * (cc.E ? cc.E : 1)));
+        BX_TRY(p->betas.alloc(c, 4 * (cc.E ? cc.E : 1)));
+        BX_TRY(circuit_perm_tables(c, cc, p->perm_offsets.b, p->perm_index.b));
+    }
     BX_TRY(p->combos.alloc(c, 3 * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
     // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
@@ -310,7 +286,7 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     BX_TRY(p->positions.alloc(c, BX_QUERIES * (4 + p->rounds.size())));
     BX_TRY(p->qout.alloc(c, (trace_query_words + fri_query_words) * BX_QUERIES));
     // seal bound: header + tops + coeff_u + final coeffs + queries
-    size_t bound = 4;
+    size_t bound = BX_SEAL_HEADER_WORDS;
     for (int g = 0; g < 4; ++g) bound += 8 * p->groups[g].tree.top_size();
     for (auto& r : p->rounds) bound += 8 * r.tree.top_size();
     bound += 4 * total_taps + 4 * size + BX_QUERIES * (trace_query_words + fri_query_words);
@@ -346,42 +322,56 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
 
     // ---- header ----
     {
-        uint32_t hdr[4] = {po2, p->shape.w_code, p->shape.w_data, p->shape.w_accum}, enc[4], dg[8];
-        for (int i = 0; i < 4; ++i) enc[i] = fp_encode(hdr[i]);
-        T.write(hdr, 4);
-        p->h2.hash_elems(dg, enc, 4);
+        uint32_t hdr[BX_SEAL_HEADER_WORDS] = {po2, p->shape.w_code, p->shape.w_data, p->shape.w_accum, p->cc.T, p->cc.G};
+        uint32_t enc[BX_SEAL_HEADER_WORDS], dg[8];
+        for (int i = 0; i < BX_SEAL_HEADER_WORDS; ++i) enc[i] = fp_encode(hdr[i]);
+        T.write(hdr, BX_SEAL_HEADER_WORDS);
+        p->h2.hash_elems(dg, enc, BX_SEAL_HEADER_WORDS);
         T.commit(dg);
     }
-    // ---- trace groups: code, data, then accum (which depends on the transcript, like upstream's accum mix) ----
+    // ---- witness generation (code + data), then the commits in transcript order; the accumulate step needs the
+    //      challenge drawn after the data commit, like upstream's accum mix ----
+    const Circuit& cc = p->cc;
+    Fp4 beta = f4_zero();
+    PV(circuit_witness(c, cc, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed + GOLDEN * 1, seed + GOLDEN * 2, p->perm_offsets.b,
+                       p->perm_index.b));
+    PV(circuit_accum_gather(c, cc, p->acc_src.b, p->groups[1].coeffs.b));  // commit_group interpolates in place
     for (int g = 0; g < 3; ++g) {
         Group& G = p->groups[g];
-        uint64_t gseed = seed + GOLDEN * (uint64_t)(g + 1);
         if (g == 2) {
-            Fp4 am = T.random_ext();
-            gseed ^= ((uint64_t)am.c[0] << 32) | am.c[1];
+            beta = T.random_ext();
+            const uint64_t gseed = (seed + GOLDEN * 3) ^ (((uint64_t)beta.c[0] << 32) | beta.c[1]);
+            if (cc.E) {
+                hipLaunchKernelGGL(beta_table_kernel, dim3((cc.E + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->betas.b.dptr, beta, cc.E);
+                if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: beta table launch failed");
+            }
+            PV(circuit_accumulate(c, cc, G.coeffs.b, p->acc_run.b, p->acc_src.b, p->betas.b, gseed));
         }
-        hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, c->stream, (uint32_t*)G.coeffs.b.dptr, (uint32_t)N, G.width,
-                           gseed);
-        if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: synth_fill launch failed");
         PV(commit_group(p, G, T));
         memcpy(p->last_roots + 8 * g, G.tree.root, 32);
     }
-    // ---- check polynomial (stand-in for eval_check) ----
+    // ---- eval_check: the constraint polynomial over the 4N domain, divided by the vanishing polynomial ----
     Group& CK = p->groups[3];
     {
         Fp4 poly_mix = T.random_ext();
-        uint32_t w_total = p->shape.w_code + p->shape.w_data + p->shape.w_accum;
-        hipLaunchKernelGGL(ext_pows_kernel, dim3((w_total + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->mixpows.b.dptr, poly_mix,
-                           w_total);
-        CheckArgs a;
-        for (int g = 0; g < 3; ++g) {
-            a.eval[g] = (const uint32_t*)p->groups[g].evaluated.b.dptr;
-            a.width[g] = p->groups[g].width;
+        const uint32_t n_cons = (uint32_t)cc.constraints();
+        if (n_cons) {
+            hipLaunchKernelGGL(ext_pows_kernel, dim3((n_cons + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->mixpows.b.dptr, poly_mix, n_cons);
+            if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: mix power launch failed");
+        }
+        // 1 / ((3x)^N - 1) takes four values on the domain x = w_4N^row: (3x)^N = 3^N w_4^(row mod 4)
+        uint32_t zinv[4];
+        {
+            const uint32_t t3n = fp_pow(MONT_THREE, (uint64_t)N), w4 = fp_pow(fp_encode(137u), (uint64_t)1 << 25);  // ROU_FWD[2]
+            uint32_t cur = MONT_ONE;
+            for (int m = 0; m < 4; ++m) {
+                zinv[m] = fp_inv(fp_sub(fp_mul(t3n, cur), MONT_ONE));
+                cur = fp_mul(cur, w4);
+            }
         }
         // the 16N-word check buffer holds the 4 ext planes over the 4N domain
-        hipLaunchKernelGGL(synth_eval_check_kernel, dim3((unsigned)((D / 4 + 255) / 256)), dim3(256), 0, c->stream,
-                           (uint32_t*)CK.coeffs.b.dptr, a, (const uint32_t*)p->mixpows.b.dptr, (uint32_t)D);
-        if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: eval_check launch failed");
+        PV(circuit_eval_check(c, cc, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b, p->groups[2].evaluated.b, p->mixpows.b,
+                              p->betas.b, zinv));
         PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
         PV(bx_zk_shift(c, CK.coeffs.b, BX_CHECK_SIZE));         // viewed as 16 polynomials of size N
         PV(bx_batch_expand_into_evaluate_ntt(c, CK.evaluated.b, CK.coeffs.b, BX_CHECK_SIZE, 2));

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/bx_prover.h"
+#include "circuit.hpp"
 #include "fp.hpp"
 #include "poseidon2_params.hpp"
 #include "transcript.hpp"
@@ -35,6 +36,15 @@ struct Reader {
         if (pos + k > n) throw Fail{"seal truncated"};
         const uint32_t* r = p + pos;
         pos += k;
+        return r;
+    }
+    // field elements and digest words: only the canonical representative is a valid encoding.  (x + P hashes, adds and
+    // multiplies like x in the lazily reduced arithmetic, so without this check seals would be malleable and the
+    // 64-bit contracts of fp_mad_lazy would not hold for words taken from the seal.)
+    const uint32_t* take_elems(size_t k) {
+        const uint32_t* r = take(k);
+        for (size_t i = 0; i < k; ++i)
+            if (r[i] >= P) throw Fail{"non-canonical field element in the seal"};
         return r;
     }
 };
@@ -69,7 +79,7 @@ struct TreeV {
         layers = ilog2u(rows);
         top_layer = top_layer_of(layers);
         size_t ts = top_size();
-        const uint32_t* t = rd.take(8 * ts);
+        const uint32_t* t = rd.take_elems(8 * ts);
         top.assign(t, t + 8 * ts);
         // fold the top layer to the root
         std::vector<uint32_t> layer(top);
@@ -82,12 +92,12 @@ struct TreeV {
     }
     // reads `cols` values + the path from the seal, checks them against the top layer; returns the column values
     const uint32_t* verify_open(Reader& rd, const HostPoseidon2& h, size_t idx) const {
-        const uint32_t* vals = rd.take(cols);
+        const uint32_t* vals = rd.take_elems(cols);
         uint32_t cur[8];
         h.hash_elems(cur, vals, cols);
         size_t node = idx + rows;
         while (node >= 2 * top_size()) {
-            const uint32_t* sib = rd.take(8);
+            const uint32_t* sib = rd.take_elems(8);
             uint32_t pair[16];
             if (node & 1) {
                 memcpy(pair, sib, 32);
@@ -111,16 +121,18 @@ void verify(const uint32_t* seal, size_t words) {
     Reader rd{seal, words};
 
     // ---- header ----
-    const uint32_t* hdr = rd.take(4);
+    const uint32_t* hdr = rd.take(6);
     const uint32_t po2 = hdr[0];
     const uint32_t widths[4] = {hdr[1], hdr[2], hdr[3], BX_CHECK_SIZE};
     VCHECK(po2 >= 9 && po2 <= 24, "header: po2 out of range");
     VCHECK(widths[0] >= 1 && widths[1] >= 1 && widths[2] >= 1 && widths[0] < 65536 && widths[1] < 65536 && widths[2] < 65536,
            "header: bad group widths");
+    VCHECK(hdr[4] >= 1 && hdr[4] <= BX_CIRCUIT_MAX_TERMS && hdr[5] >= 1 && hdr[5] <= BX_CIRCUIT_MAX_DEGREE, "header: bad circuit knobs");
+    const Circuit cc(po2, widths[0], widths[1], widths[2], hdr[4], hdr[5]);
     {
-        uint32_t enc[4], dg[8];
-        for (int i = 0; i < 4; ++i) enc[i] = fp_encode(hdr[i]);
-        h.hash_elems(dg, enc, 4);
+        uint32_t enc[6], dg[8];
+        for (int i = 0; i < 6; ++i) enc[i] = fp_encode(hdr[i]);
+        h.hash_elems(dg, enc, 6);
         T.commit(dg);
     }
     const size_t N = (size_t)1 << po2, D = 4 * N;
@@ -128,7 +140,7 @@ void verify(const uint32_t* seal, size_t words) {
     TreeV trees[4];
     trees[0].read_and_commit(rd, T, h, D, widths[0]);
     trees[1].read_and_commit(rd, T, h, D, widths[1]);
-    (void)T.random_ext();  // accum mix
+    const Fp4 beta = T.random_ext();  // the accumulators' mix
     trees[2].read_and_commit(rd, T, h, D, widths[2]);
     const Fp4 poly_mix = T.random_ext();
     trees[3].read_and_commit(rd, T, h, D, widths[3]);
@@ -137,12 +149,11 @@ void verify(const uint32_t* seal, size_t words) {
     std::vector<std::vector<uint32_t>> taps(4);
     size_t total_taps = 0;
     for (int g = 0; g < 4; ++g) {
-        taps[g].assign(widths[g], 1);
-        if (g == 1 || g == 2)
-            for (uint32_t c = 0; c < widths[g]; c += 4) taps[g][c] = 2;
+        taps[g].resize(widths[g]);
+        for (uint32_t c = 0; c < widths[g]; ++c) taps[g][c] = cc.taps_of(g, c);
         for (uint32_t t : taps[g]) total_taps += t;
     }
-    const uint32_t* coeff_u = rd.take(4 * total_taps);
+    const uint32_t* coeff_u = rd.take_elems(4 * total_taps);
     {
         uint32_t dg[8];
         h.hash_elems(dg, coeff_u, 4 * total_taps);
@@ -151,29 +162,81 @@ void verify(const uint32_t* seal, size_t words) {
     const uint32_t back_one = fp_inv(rou(po2));
     const Fp4 Zb = f4_scale(Z, back_one);
     const Fp4 Z4 = f4_scale(f4_pow(Z, 4), fp_inv(MONT_THREE));
-    // ---- the check identity at Z:  sum_k X^k sum_q Z^(rev2 q) g_{4k+q}(Z^4/3)  ==  sum_c poly_mix^c (v_c^3 + v_c) ----
+    // ---- the constraint identity at Z:  check(Z) * ((3Z)^N - 1)  ==  sum_i poly_mix^i C_i(taps)  with
+    //      check(Z) = sum_k X^k sum_q Z^(rev2 q) g_{4k+q}(Z^4/3) from the check group's taps ----
     {
-        Fp4 rhs = f4_zero(), cur = f4_one();
+        // tap values: where[g][c] = offset of column c's first ext element in coeff_u
+        std::vector<std::vector<size_t>> where(4);
         size_t u = 0;
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 4; ++g) {
+            where[g].resize(widths[g]);
             for (uint32_t c = 0; c < widths[g]; ++c) {
-                Fp4 v = ld(coeff_u + u);
-                if (taps[g][c] == 2) v = f4_add(v, f4_mul(ld(coeff_u + u + 4), Z));  // u(Z) = c0 + c1 Z
+                where[g][c] = u;
                 u += 4 * taps[g][c];
-                Fp4 t = f4_add(f4_mul(f4_mul(v, v), v), v);
-                rhs = f4_add(rhs, f4_mul(cur, t));
-                cur = f4_mul(cur, poly_mix);
             }
+        }
+        auto at = [&](int g, uint32_t c, int back) -> Fp4 {  // the column's polynomial at Z (back 0) or Z * w_N^-1 (back 1)
+            const uint32_t* w = coeff_u + where[g][c];
+            if (taps[g][c] == 1) {
+                VCHECK(back == 0, "internal: back tap of a single-tap column");
+                return ld(w);
+            }
+            return f4_add(ld(w), f4_mul(ld(w + 4), back ? Zb : Z));  // u(x) = c0 + c1 x
+        };
+        auto csel = [&](unsigned i) -> Fp4 {
+            int col = cc.csel_col(i);
+            return col < 0 ? f4_one() : at(0, (uint32_t)col, 0);
+        };
+        Fp4 rhs = f4_zero(), cur = f4_one();
+        for (uint32_t j = 0; j < cc.J; ++j) {
+            Fp4 pool[Circuit::POOL];
+            pool[0] = at(1, j, 0);
+            pool[1] = j % 4 == 0 ? at(1, j, 1) : pool[0];
+            for (uint32_t s = 1; s <= 4; ++s) pool[1 + s] = j >= s ? at(1, cc.F + j - s, 0) : csel(s - j - 1);
+            pool[6] = csel(j);
+            Fp4 sum = f4_zero();
+            for (uint32_t t = 0; t < cc.T; ++t) {
+                Fp4 prod = pool[Circuit::pool_idx(t, 0)];
+                for (uint32_t f = 1; f < cc.G; ++f) prod = f4_mul(prod, pool[Circuit::pool_idx(t, f)]);
+                sum = f4_add(sum, prod);
+            }
+            rhs = f4_add(rhs, f4_mul(cur, f4_sub(at(1, cc.F + j, 0), sum)));
+            cur = f4_mul(cur, poly_mix);
+        }
+        auto acc_at = [&](uint32_t e, int back) -> Fp4 {  // the ext-valued accumulator: sum_k X^k * column(4e+k)
+            Fp4 r = f4_zero();
+            for (int k = 0; k < 4; ++k) {
+                Fp4 xk = f4_zero();
+                xk.c[k] = MONT_ONE;
+                r = f4_add(r, f4_mul(xk, at(2, 4 * e + k, back)));
+            }
+            return r;
+        };
+        const Fp4 first = at(0, 0, 0);
+        Fp4 be = beta;
+        for (uint32_t e = 0; e < cc.E; ++e) {
+            Fp4 inner = f4_add(first, f4_mul(f4_sub(f4_one(), first), acc_at(e, 1)));
+            Fp4 cons = f4_sub(acc_at(e, 0), f4_mul(inner, f4_add(be, at(1, cc.acc_src(e), 0))));
+            rhs = f4_add(rhs, f4_mul(cur, cons));
+            cur = f4_mul(cur, poly_mix);
+            if (e & 1) be = f4_mul(be, beta);  // beta^(floor(e/2)+1)
+        }
+        for (uint32_t p = 0; p < cc.pairs; ++p) {
+            Fp4 cons = f4_mul(at(0, 1, 0), f4_sub(acc_at(2 * p + 1, 0), acc_at(2 * p, 0)));
+            rhs = f4_add(rhs, f4_mul(cur, cons));
+            cur = f4_mul(cur, poly_mix);
+        }
         Fp4 lhs = f4_zero();
         const Fp4 zp[4] = {f4_one(), Z, f4_mul(Z, Z), f4_mul(f4_mul(Z, Z), Z)};
         for (int k = 0; k < 4; ++k) {
             Fp4 plane = f4_zero();
-            for (int q = 0; q < 4; ++q) plane = f4_add(plane, f4_mul(zp[bit_reverse((uint32_t)q, 2)], ld(coeff_u + u + 4 * (4 * k + q))));
+            for (int q = 0; q < 4; ++q) plane = f4_add(plane, f4_mul(zp[bit_reverse((uint32_t)q, 2)], at(3, (uint32_t)(4 * k + q), 0)));
             Fp4 xk = f4_zero();
             xk.c[k] = MONT_ONE;  // the basis element X^k
             lhs = f4_add(lhs, f4_mul(xk, plane));
         }
-        VCHECK(eq(lhs, rhs), "check polynomial identity fails at Z");
+        const Fp4 vanish = f4_sub(f4_pow(f4_scale(Z, MONT_THREE), (uint64_t)N), f4_one());
+        VCHECK(eq(f4_mul(lhs, vanish), rhs), "constraint identity fails at Z");
     }
     const Fp4 mix = T.random_ext();
     // mixed u polynomials per combo (as the prover subtracts them) and per-column mix powers
@@ -207,7 +270,7 @@ void verify(const uint32_t* seal, size_t words) {
         size /= BX_FRI_FOLD;
     }
     const size_t final_size = size;
-    const uint32_t* fin = rd.take(4 * final_size);  // SoA planes, natural coefficient order
+    const uint32_t* fin = rd.take_elems(4 * final_size);  // SoA planes, natural coefficient order
     {
         uint32_t dg[8];
         h.hash_elems(dg, fin, 4 * final_size);

@@ -90,6 +90,7 @@ def load_library():
         "bx_gather_sample": [ctx, BxBuf, BxBuf, sz, sz, sz],
         "bx_poly_divide": [ctx, BxBuf, u32p, BxBuf],
         "bx_prefix_products": [ctx, BxBuf],
+        "bx_batch_prefix_products": [ctx, BxBuf, sz],
         "bx_scatter": [ctx, BxBuf, BxBuf, BxBuf, BxBuf],
         "bx_timer_start": [ctx],
         "bx_timer_stop": [ctx, C.POINTER(C.c_float)],
@@ -296,6 +297,9 @@ class HipHal:
 
     def prefix_products(self, io):
         self._check(self.lib.bx_prefix_products(self.ctx, io.raw))
+
+    def batch_prefix_products(self, io, count):
+        self._check(self.lib.bx_batch_prefix_products(self.ctx, io.raw, count))
 
     def scatter(self, into, index, offsets, values):
         self._check(self.lib.bx_scatter(self.ctx, into.raw, index.raw, offsets.raw, values.raw))

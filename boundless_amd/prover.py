@@ -15,7 +15,8 @@ from .hal import HalError, HipHal, load_library
 
 
 class SegmentParams(C.Structure):
-    _fields_ = [("po2", C.c_uint32), ("w_code", C.c_uint32), ("w_data", C.c_uint32), ("w_accum", C.c_uint32)]
+    _fields_ = [("po2", C.c_uint32), ("w_code", C.c_uint32), ("w_data", C.c_uint32), ("w_accum", C.c_uint32),
+                ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32)]
 
 
 @dataclass
@@ -85,13 +86,14 @@ class HipProverServer:
 
     DEFAULT_WIDTHS = (16, 256, 64)  # SURVEY.md §8d synthetic segment
 
-    def __init__(self, device=0, po2=20, widths=DEFAULT_WIDTHS, hal=None):
+    def __init__(self, device=0, po2=20, widths=DEFAULT_WIDTHS, hal=None, terms=0, degree=0):
+        """terms / degree: the synthetic circuit's knobs (product terms per constraint, factors per term); 0 = defaults."""
         self.hal = hal or HipHal(device)
         self.lib = load_library()
         _declare(self.lib)
         self.po2 = po2
         self.widths = tuple(widths)
-        shape = SegmentParams(po2, *self.widths)
+        shape = SegmentParams(po2, *self.widths, terms, degree)
         handle = C.c_void_p()
         msg = self.lib.bx_prover_create(self.hal.ctx, C.byref(shape), C.byref(handle))
         if msg:

@@ -128,8 +128,13 @@ const char* bx_gather_sample(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t idx, si
 /* Hal::prefix_products(io): io[i] = io[i] * io[i-1] over AoS ext elements (inclusive running product; the circuit's
  * accumulate step uses it for its grand products). */
 const char* bx_prefix_products(bx_ctx* ctx, bx_buf io_ext);
+/* Extension: `count` independent sequences of io_ext.len/4/count ext elements each, laid out back to back, scanned in one
+ * set of launches (the accumulate step runs one sequence per accumulator). */
+const char* bx_batch_prefix_products(bx_ctx* ctx, bx_buf io_ext, size_t count);
 /* Hal::scatter(into, index, offsets, values): for cycle c < index.len - 1, every entry e in [index[c], index[c+1])
- * writes into[offsets[e]] = values[e].  All four are device buffers. */
+ * writes into[offsets[e]] = values[e].  All four are device buffers.  Asynchronous: an offset outside `into` or an index
+ * range outside offsets/values is detected on the device and reported by the next blocking call on the ctx (bx_d2h,
+ * bx_sync), which returns the error string. */
 const char* bx_scatter(bx_ctx* ctx, bx_buf into, bx_buf index_u32, bx_buf offsets_u32, bx_buf values);
 /* DEEP quotient (upstream: core/poly.rs poly_divide, run per combo): in-place synthetic division of the
  * natural-order AoS ext polynomial by (x - z); the remainder (4 words) is written to rem_out_dev. */

@@ -9,15 +9,43 @@
  * `ProverServer::prove_segment` (risc0-zkvm 3.0.4, Cargo.lock:9187) drives risc0-zkp's `Prover`:
  * commit_group x3 -> eval_check -> check commit -> DEEP taps/mix/divide -> fri_prove -> seal (Vec<u32>).
  *
- * What is and is not reproduced (DESIGN.md §2)
- * --------------------------------------------
- * The rv32im circuit (witness generation, eval_check constraint polynomial, tap set) is machine-generated code in
- * crates the reference does not vendor, so a real zkVM segment cannot be built offline.  bx_prove_segment runs the
- * *circuit-independent* prover pipeline — every HAL kernel, the Poseidon2 Fiat–Shamir transcript, Merkle commits,
- * DEEP quotients, FRI rounds and the 50 queries, in upstream's order and with upstream's constants — over a
- * synthetic segment: witness columns are filled from a seed by a device kernel (stand-in for witgen) and the
- * check polynomial is a fixed cubic mix of the committed columns (stand-in for eval_check).  The seal is a
- * deterministic function of (params, seed) and is bit-identical to the CPU oracle's seal (oracle/bx_oracle_prover.c).
+ * What is and is not reproduced (DESIGN.md §1-2)
+ * ---------------------------------------------
+ * The rv32im circuit (witness generation, the eval_check constraint polynomial, the accumulate step, the tap set) is
+ * machine-generated code in crates the reference does not vendor, so a real zkVM segment cannot be proved offline.
+ * bx_prove_segment runs upstream's prover pipeline — every HAL kernel, the Poseidon2 Fiat-Shamir transcript, Merkle
+ * commits, DEEP quotients, FRI rounds and the 50 queries, in upstream's order and with upstream's constants — over a
+ * SYNTHETIC CIRCUIT of the same anatomy: a witness stage (free cells, scatter-placed permuted copies, derived columns),
+ * an accumulate stage (grand products through Hal::prefix_products, keyed by a transcript challenge), and an eval_check
+ * stage whose constraints really vanish on the trace domain and are divided by the vanishing polynomial.  The seal is a
+ * STARK proof of that circuit: bx_verify_segment accepts it only if the constraint identity holds at the random point Z.
+ * It is a deterministic function of (params, seed) and bit-identical to the CPU oracle's seal (oracle/bx_oracle_prover.c).
+ * It is NOT a risc0 receipt: no image id, no claim, no ZK blinding rows.
+ *
+ * The synthetic circuit (normative; N = 2^po2 rows, all row indices cyclic mod N)
+ * -------------------------------------------------------------------------------
+ *   knobs      T = cons_terms (product terms per derived-column constraint), G = cons_degree (factors per term, <= 5)
+ *   seeds      gseed_g = seed + (g+1) * 0x9E3779B97F4A7C15;  word(s,c,r) = splitmix64(s ^ (c << 32 | r)) >> 33, minus P if >= P
+ *   code       column 0 = first (1 at row 0, else 0); column 1 = last (1 at row N-1); column c >= 2 = word(gseed_0, c, r).
+ *              csel(i) = code column 2 + i mod (w_code - 2) when w_code >= 3, else the constant 1.
+ *   data       F = ceil(w_data / 2) free columns, J = w_data - F derived columns.
+ *              free column c: word(gseed_1, c, r), except the permuted copies: for pair p < pairs,
+ *                  data[4p+3][perm_p(r)] = data[4p+2][r],  perm_p(r) = (r * 2654435761 + 12345 + p) mod N
+ *              (placed with Hal::scatter).  pairs = the number of p with 2p+1 < E and 4p+3 < F (0 when w_code < 2).
+ *              derived column F+j: with pool_j = [ u = data[j][r],  ub = data[j][r-1] if j % 4 == 0 else u,
+ *                  p_s = data[F+j-s][r] (s = 1..4; csel(s-j-1)[r] when j < s),  k = csel(j)[r] ]
+ *                  data[F+j][r] = sum_{t<T} prod_{f<G} pool_j[idx(t,f)],  idx(t,f) = (3t + floor(t/7) + f(2(t mod 3)+1)) mod 7
+ *   accum      drawn after the data commit: beta (ext).  E = floor(w_accum / 4) ext accumulators, accumulator e in columns
+ *              4e..4e+3 (component k in column 4e+k):  acc_e(r) = prod_{i<=r} (beta_e + data[src(e)][i]),  beta_e = beta^(floor(e/2)+1)   (Hal::prefix_products)
+ *              src(e) = 4p+2 / 4p+3 for e = 2p / 2p+1 when p < pairs, else e mod F.  Columns >= 4E: word(gseed_2 ^ (beta.c0<<32|beta.c1), c, r).
+ *   taps       every column at Z; one row back (Z * w_N^-1) as well: data columns with c % 4 == 0, accum columns c < 4E.
+ *   constraints, in mixing order (constraint i is weighted poly_mix^i):
+ *              j < J :  data[F+j][r] - sum_t prod_f pool_j[idx(t,f)]                                          = 0
+ *              e < E :  acc_e(r) - (first(r) + (1 - first(r)) * acc_e(r-1)) * (beta_e + data[src(e)][r])        = 0
+ *              p < pairs :  last(r) * (acc_{2p+1}(r) - acc_{2p}(r))                                             = 0
+ *   check      check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1), evaluated on the 4N domain x = w_4N^row from the
+ *              committed evaluations (which are F(3x): the coset shift lives in the coefficients), then split into the
+ *              16 check columns exactly as upstream splits its check polynomial.
  *
  * Threading/ownership follow the reference: one prover per ctx (= per GPU, compose.yml:113), one call at a time,
  * blocking, errors returned as strings (never abort: bento/crates/workflow/src/lib.rs:381-436 retries on Err).
@@ -38,7 +66,14 @@ typedef struct bx_segment_params {
     uint32_t w_code;
     uint32_t w_data;
     uint32_t w_accum;
+    uint32_t cons_terms;  /* T: product terms per derived-column constraint; 0 = BX_CIRCUIT_DEFAULT_TERMS */
+    uint32_t cons_degree; /* G: factors per term (multiplicative degree), 1..5; 0 = BX_CIRCUIT_DEFAULT_DEGREE */
 } bx_segment_params;
+#define BX_CIRCUIT_DEFAULT_TERMS 16
+#define BX_CIRCUIT_DEFAULT_DEGREE 3
+#define BX_CIRCUIT_MAX_TERMS 64
+#define BX_CIRCUIT_MAX_DEGREE 5
+#define BX_SEAL_HEADER_WORDS 6 /* po2, w_code, w_data, w_accum, T, G */
 
 /* Allocates every device buffer the pipeline needs for this shape (nothing is allocated per proof). */
 const char* bx_prover_create(bx_ctx* ctx, const bx_segment_params* shape, bx_prover** out);

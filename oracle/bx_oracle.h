@@ -96,6 +96,11 @@ void bxo_scatter(uint32_t* into, const uint32_t* index, const uint32_t* offsets,
 /* ---- segment-prover pipeline (bx_oracle_prover.c): returns a malloc'ed seal (free with bxo_free) or NULL ---- */
 uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
                             size_t* seal_words, uint32_t roots_out[32]);
+/* same with the circuit's knobs: product terms per derived-column constraint and factors per term (0 = defaults) */
+uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
+                               uint64_t seed, size_t* seal_words, uint32_t roots_out[32]);
+/* test hook: add 1 to witness cell (group, col, row) before it is committed, making the proved statement false (group < 0: off) */
+void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
 void bxo_free(void* p);
 
 #ifdef __cplusplus

@@ -4,9 +4,10 @@
  * Sequential restatement, on host arrays and with the oracle's own HAL functions (bx_oracle.c), of
  *   risc0_zkp::prove::Prover::{commit_group, finalize}, prove::fri::fri_prove, prove::merkle::MerkleTreeProver,
  *   prove::write_iop::WriteIOP and core::hash::poseidon2::Poseidon2Rng            [EXT: risc0-zkp 3.0.3]
- * as driven by ProverServer::prove_segment (bento/crates/workflow/src/tasks/prove.rs:41-49).  The witness fill
- * and the check polynomial are the synthetic stand-ins documented in include/bx_prover.h; everything else keeps
- * upstream's order and constants.  Written straight-line (one query at a time, one layer at a time) so that it
+ * as driven by ProverServer::prove_segment (bento/crates/workflow/src/tasks/prove.rs:41-49).  The circuit is the
+ * synthetic AIR specified in include/bx_prover.h ("The synthetic circuit": witness generation with derived columns and
+ * scatter-placed permuted copies, grand-product accumulators, a constraint polynomial divided by the vanishing
+ * polynomial); everything else keeps upstream's order and constants.  Written straight-line (one query at a time, one layer at a time) so that it
  * shares no structure with the product's batched device code.  Seal parity vs the Rust prover: UNPINNED (no
  * circuit, no vectors in the reference); this oracle pins the product against an independent implementation.
  */
@@ -92,6 +93,45 @@ static uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
     return v >= BXO_P ? v - BXO_P : v;
 }
 
+/* ---- the synthetic circuit (include/bx_prover.h, "The synthetic circuit") ---- */
+#define DEFAULT_TERMS 16
+#define DEFAULT_DEGREE 3
+#define POOL 7
+typedef struct {
+    uint32_t po2, wc, wd, wa, T, G;
+    size_t n;
+    uint32_t F, J, E, pairs;
+} circ_t;
+static void circ_init(circ_t* c, uint32_t po2, uint32_t wc, uint32_t wd, uint32_t wa, uint32_t terms, uint32_t degree) {
+    c->po2 = po2; c->wc = wc; c->wd = wd; c->wa = wa;
+    c->T = terms ? terms : DEFAULT_TERMS;
+    c->G = degree ? degree : DEFAULT_DEGREE;
+    c->n = (size_t)1 << po2;
+    c->F = (wd + 1) / 2;
+    c->J = wd - c->F;
+    c->E = wa / 4;
+    c->pairs = 0;
+    while (2 * c->pairs + 1 < c->E && 4 * c->pairs + 3 < c->F) c->pairs++;
+    if (wc < 2) c->pairs = 0; /* the closing constraint needs the `last` selector */
+}
+/* which pool entry is factor f of term t */
+static unsigned pool_idx(unsigned t, unsigned f) { return (3 * t + t / 7 + f * (2 * (t % 3) + 1)) % POOL; }
+/* code column standing behind csel(i); -1 = the constant one */
+static int csel_col(const circ_t* c, unsigned i) { return c->wc >= 3 ? (int)(2 + i % (c->wc - 2)) : -1; }
+/* data column an accumulator runs over */
+static uint32_t acc_src(const circ_t* c, uint32_t e) {
+    uint32_t p = e / 2;
+    if (p < c->pairs) return (e & 1) ? 4 * p + 3 : 4 * p + 2;
+    return e % c->F;
+}
+/* the row permutation of pair p: data[4p+3][perm(r)] = data[4p+2][r] */
+static size_t perm_row(const circ_t* c, uint32_t p, size_t r) { return (r * 2654435761ull + 12345u + p) & (c->n - 1); }
+static uint32_t taps_of(const circ_t* c, int g, uint32_t col) {
+    if (g == 1) return col % 4 == 0 ? 2 : 1;
+    if (g == 2) return col < 4 * c->E ? 2 : 1;
+    return 1;
+}
+
 /* ---- MerkleTreeProver ---- */
 typedef struct {
     size_t rows, cols;
@@ -161,60 +201,216 @@ static void group_free(group_t* g) {
     free(g->taps);
 }
 
+/* Test hook: corrupt one witness cell (group, column, row) after witness generation, so that the statement being proved
+ * is false; group < 0 switches the fault off.  The verifier must then refuse the seal at the constraint identity. */
+static int fault_group = -1;
+static uint32_t fault_col, fault_row;
+void bxo_set_witness_fault(int group, uint32_t col, uint32_t row) {
+    fault_group = group;
+    fault_col = col;
+    fault_row = row;
+}
+
 /* Returns a malloc'ed seal (caller frees with bxo_free) or NULL on an internal consistency failure. */
-uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
-                            size_t* seal_words, uint32_t roots_out[32]) {
+uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
+                               uint64_t seed, size_t* seal_words, uint32_t roots_out[32]) {
     bxo_init();
     const size_t n = (size_t)1 << po2, dom = 4 * n;
     const uint32_t widths[4] = {w_code, w_data, w_accum, CHECK_SIZE};
+    circ_t cc;
+    circ_init(&cc, po2, w_code, w_data, w_accum, terms, degree);
     iop_t io;
     memset(&io, 0, sizeof io);
     group_t grp[4];
     memset(grp, 0, sizeof grp);
+    uint32_t *code_w = NULL, *data_w = NULL; /* witness copies of the code and data groups (commit_group works in place) */
 
     /* header */
     {
-        uint32_t hdr[4] = {po2, w_code, w_data, w_accum}, enc[4], dg[8];
-        for (int i = 0; i < 4; i++) enc[i] = bxo_fp_encode(hdr[i]);
-        iop_write(&io, hdr, 4);
-        bxo_hash_elem_slice(dg, enc, 4, 1);
+        uint32_t hdr[6] = {po2, w_code, w_data, w_accum, cc.T, cc.G}, enc[6], dg[8];
+        for (int i = 0; i < 6; i++) enc[i] = bxo_fp_encode(hdr[i]);
+        iop_write(&io, hdr, 6);
+        bxo_hash_elem_slice(dg, enc, 6, 1);
         iop_commit(&io, dg);
     }
-    /* trace groups */
+    /* ---- witness generation + trace commitments (code, data, then accum which depends on the transcript) ---- */
+    e4 beta = {{0, 0, 0, 0}};
     for (int g = 0; g < 3; g++) {
         group_t* G = &grp[g];
         G->width = widths[g];
         uint64_t gseed = seed + GOLDEN * (uint64_t)(g + 1);
         if (g == 2) {
-            e4 am = iop_random_ext(&io);
-            gseed ^= ((uint64_t)am.c[0] << 32) | am.c[1];
+            beta = iop_random_ext(&io); /* the accumulators' mix */
+            gseed ^= ((uint64_t)beta.c[0] << 32) | beta.c[1];
         }
-        G->coeffs = (uint32_t*)malloc((size_t)G->width * n * 4);
-        for (uint32_t c = 0; c < G->width; c++)
-            for (size_t r = 0; r < n; r++) G->coeffs[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
+        uint32_t* w = G->coeffs = (uint32_t*)malloc((size_t)G->width * n * 4); /* the witness, column-major */
+        if (g == 0) {
+            /* code: selectors first / last, then public pseudo-random control words */
+            for (uint32_t c = 0; c < G->width; c++)
+                for (size_t r = 0; r < n; r++)
+                    w[(size_t)c * n + r] = c == 0 ? (r == 0 ? bxo_fp_encode(1) : 0)
+                                           : c == 1 ? (r == n - 1 ? bxo_fp_encode(1) : 0)
+                                                    : synth_word(gseed, c, (uint32_t)r);
+        } else if (g == 1) {
+            /* free columns */
+            for (uint32_t c = 0; c < cc.F; c++)
+                for (size_t r = 0; r < n; r++) w[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
+            /* permuted copies, placed with the oracle's scatter (one entry per cycle) */
+            for (uint32_t p = 0; p < cc.pairs; p++) {
+                uint32_t* index = (uint32_t*)malloc((n + 1) * 4);
+                uint32_t* offsets = (uint32_t*)malloc(n * 4);
+                for (size_t r = 0; r <= n; r++) index[r] = (uint32_t)r;
+                for (size_t r = 0; r < n; r++) offsets[r] = (uint32_t)((size_t)(4 * p + 3) * n + perm_row(&cc, p, r));
+                bxo_scatter(w, index, offsets, w + (size_t)(4 * p + 2) * n, n);
+                free(index);
+                free(offsets);
+            }
+            /* derived columns: data[F+j][r] = sum_t prod_f pool_j[idx(t,f)] */
+            for (uint32_t j = 0; j < cc.J; j++) {
+                uint32_t* out = w + (size_t)(cc.F + j) * n;
+                _Pragma("omp parallel for schedule(static) num_threads(bxo_get_threads())")
+                for (size_t r = 0; r < n; r++) {
+                    uint32_t pool[POOL];
+                    pool[0] = w[(size_t)j * n + r];
+                    pool[1] = j % 4 == 0 ? w[(size_t)j * n + (r + n - 1) % n] : pool[0];
+                    for (uint32_t s_ = 1; s_ <= 4; s_++) {
+                        if (j >= s_) pool[1 + s_] = w[(size_t)(cc.F + j - s_) * n + r];
+                        else {
+                            int cs = csel_col(&cc, s_ - j - 1);
+                            pool[1 + s_] = cs < 0 ? bxo_fp_encode(1) : code_w[(size_t)cs * n + r];
+                        }
+                    }
+                    int ck = csel_col(&cc, j);
+                    pool[6] = ck < 0 ? bxo_fp_encode(1) : code_w[(size_t)ck * n + r];
+                    uint32_t sum = 0;
+                    for (uint32_t t = 0; t < cc.T; t++) {
+                        uint32_t prod = pool[pool_idx(t, 0)];
+                        for (uint32_t f = 1; f < cc.G; f++) prod = bxo_fp_mul(prod, pool[pool_idx(t, f)]);
+                        sum = bxo_fp_add(sum, prod);
+                    }
+                    out[r] = sum;
+                }
+            }
+        } else {
+            /* accumulators: acc_e(r) = prod_{i<=r} (beta^(e+1) + data[src(e)][i]), one ext element per row, through the
+             * oracle's prefix_products; component k goes to column 4e+k.  Leftover columns are noise. */
+            e4 be = beta; /* beta^(floor(e/2)+1): the two accumulators of a pair share their challenge */
+            uint32_t* run = (uint32_t*)malloc(n * 16);
+            for (uint32_t e = 0; e < cc.E; e++) {
+                const uint32_t* x = data_w + (size_t)acc_src(&cc, e) * n;
+                for (size_t r = 0; r < n; r++) {
+                    run[4 * r + 0] = bxo_fp_add(be.c[0], x[r]);
+                    run[4 * r + 1] = be.c[1];
+                    run[4 * r + 2] = be.c[2];
+                    run[4 * r + 3] = be.c[3];
+                }
+                bxo_prefix_products(run, n);
+                for (int k = 0; k < 4; k++)
+                    for (size_t r = 0; r < n; r++) w[(size_t)(4 * e + k) * n + r] = run[4 * r + k];
+                if (e & 1) be = e4mul(be, beta);
+            }
+            free(run);
+            for (uint32_t c = 4 * cc.E; c < G->width; c++)
+                for (size_t r = 0; r < n; r++) w[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
+        }
+        if (fault_group == g && fault_col < G->width && fault_row < n) {
+            uint32_t* cell = &w[(size_t)fault_col * n + fault_row];
+            *cell = bxo_fp_add(*cell, bxo_fp_encode(1));
+        }
+        /* commit_group interpolates in place, so keep what later stages of witness generation read */
+        if (g == 0) {
+            code_w = (uint32_t*)malloc((size_t)G->width * n * 4);
+            memcpy(code_w, w, (size_t)G->width * n * 4);
+        } else if (g == 1) {
+            data_w = (uint32_t*)malloc((size_t)G->width * n * 4);
+            memcpy(data_w, w, (size_t)G->width * n * 4);
+        }
         G->taps = (uint32_t*)malloc(G->width * 4);
-        for (uint32_t c = 0; c < G->width; c++) G->taps[c] = (g != 0 && c % 4 == 0) ? 2 : 1;
+        for (uint32_t c = 0; c < G->width; c++) G->taps[c] = taps_of(&cc, g, c);
         commit_group(G, n, &io);
         if (roots_out) memcpy(roots_out + 8 * g, G->tree.nodes + 8, 32);
     }
-    /* check polynomial: check(r) = sum_c mix^c (e_c^3 + e_c) over all trace columns, on the 4N domain */
+    free(code_w);
+    free(data_w);
+    /* ---- eval_check: check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1) on the 4N domain x = w_4N^row ---- */
     group_t* CK = &grp[3];
     {
         CK->width = CHECK_SIZE;
         e4 poly_mix = iop_random_ext(&io);
         uint32_t* check = (uint32_t*)calloc(16 * n, 4); /* 4 planes x 4N */
-        e4 cur = e4one();
-        for (int g = 0; g < 3; g++)
-            for (uint32_t c = 0; c < grp[g].width; c++) {
-                const uint32_t* e = grp[g].evaluated + (size_t)c * dom;
-                _Pragma("omp parallel for schedule(static) num_threads(bxo_get_threads())")
-                for (size_t r = 0; r < dom; r++) {
-                    uint32_t v = e[r];
-                    uint32_t t = bxo_fp_add(bxo_fp_mul(bxo_fp_mul(v, v), v), v);
-                    for (int k = 0; k < 4; k++) check[(size_t)k * dom + r] = bxo_fp_add(check[(size_t)k * dom + r], bxo_fp_mul(cur.c[k], t));
-                }
-                cur = e4mul(cur, poly_mix);
+        const size_t n_cons = (size_t)cc.J + cc.E + cc.pairs;
+        e4* mixpow = (e4*)malloc((n_cons + 1) * sizeof(e4));
+        mixpow[0] = e4one();
+        for (size_t i = 1; i <= n_cons; i++) mixpow[i] = e4mul(mixpow[i - 1], poly_mix);
+        e4* betas = (e4*)malloc((cc.E + 1) * sizeof(e4));
+        betas[0] = beta;
+        for (uint32_t e = 1; e < cc.E; e++) betas[e] = (e & 1) ? betas[e - 1] : e4mul(betas[e - 1], beta);
+        /* 1 / ((3x)^N - 1) takes four values on the domain: (3 w_4N^row)^N = 3^N w_4^(row mod 4) */
+        uint32_t zinv[4];
+        {
+            uint32_t t3n = bxo_fp_pow(bxo_fp_encode(3), n), w4 = bxo_rou_fwd(2), cur = bxo_fp_encode(1);
+            for (int m = 0; m < 4; m++) {
+                zinv[m] = bxo_fp_inv(bxo_fp_sub(bxo_fp_mul(t3n, cur), bxo_fp_encode(1)));
+                cur = bxo_fp_mul(cur, w4);
             }
+        }
+        const uint32_t* ecode = grp[0].evaluated;
+        const uint32_t* edata = grp[1].evaluated;
+        const uint32_t* eacc = grp[2].evaluated;
+        const uint32_t one = bxo_fp_encode(1);
+        _Pragma("omp parallel for schedule(static) num_threads(bxo_get_threads())")
+        for (size_t i = 0; i < dom; i++) {
+            const size_t ib = (i + dom - 4) % dom; /* one row back: x * w_N^-1 = w_4N^(row - 4) */
+            e4 tot = {{0, 0, 0, 0}};
+            for (uint32_t j = 0; j < cc.J; j++) {
+                uint32_t pool[POOL];
+                pool[0] = edata[(size_t)j * dom + i];
+                pool[1] = j % 4 == 0 ? edata[(size_t)j * dom + ib] : pool[0];
+                for (uint32_t s_ = 1; s_ <= 4; s_++) {
+                    if (j >= s_) pool[1 + s_] = edata[(size_t)(cc.F + j - s_) * dom + i];
+                    else {
+                        int cs = csel_col(&cc, s_ - j - 1);
+                        pool[1 + s_] = cs < 0 ? one : ecode[(size_t)cs * dom + i];
+                    }
+                }
+                int ck = csel_col(&cc, j);
+                pool[6] = ck < 0 ? one : ecode[(size_t)ck * dom + i];
+                uint32_t sum = 0;
+                for (uint32_t t = 0; t < cc.T; t++) {
+                    uint32_t prod = pool[pool_idx(t, 0)];
+                    for (uint32_t f = 1; f < cc.G; f++) prod = bxo_fp_mul(prod, pool[pool_idx(t, f)]);
+                    sum = bxo_fp_add(sum, prod);
+                }
+                uint32_t cons = bxo_fp_sub(edata[(size_t)(cc.F + j) * dom + i], sum);
+                for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], bxo_fp_mul(mixpow[j].c[k], cons));
+            }
+            const uint32_t first = ecode[i], last = cc.wc >= 2 ? ecode[dom + i] : 0;
+            for (uint32_t e = 0; e < cc.E; e++) {
+                e4 a, ab, inner, fac, cons;
+                for (int k = 0; k < 4; k++) {
+                    a.c[k] = eacc[(size_t)(4 * e + k) * dom + i];
+                    ab.c[k] = eacc[(size_t)(4 * e + k) * dom + ib];
+                }
+                inner = e4scale(ab, bxo_fp_sub(one, first));
+                inner.c[0] = bxo_fp_add(inner.c[0], first);
+                fac = betas[e];
+                fac.c[0] = bxo_fp_add(fac.c[0], edata[(size_t)acc_src(&cc, e) * dom + i]);
+                cons = e4sub(a, e4mul(inner, fac));
+                cons = e4mul(mixpow[cc.J + e], cons);
+                for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], cons.c[k]);
+            }
+            for (uint32_t p = 0; p < cc.pairs; p++) {
+                e4 d;
+                for (int k = 0; k < 4; k++)
+                    d.c[k] = bxo_fp_sub(eacc[(size_t)(4 * (2 * p + 1) + k) * dom + i], eacc[(size_t)(4 * (2 * p) + k) * dom + i]);
+                d = e4mul(mixpow[cc.J + cc.E + p], e4scale(d, last));
+                for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], d.c[k]);
+            }
+            tot = e4scale(tot, zinv[i & 3]);
+            for (int k = 0; k < 4; k++) check[(size_t)k * dom + i] = tot.c[k];
+        }
+        free(mixpow);
+        free(betas);
         bxo_batch_interpolate_ntt(check, 4, dom);
         CK->coeffs = check; /* now viewed as 16 polynomials of size n */
         CK->taps = (uint32_t*)malloc(CHECK_SIZE * 4);
@@ -364,5 +560,9 @@ uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint
     }
     *seal_words = io.len;
     return io.seal;
+}
+uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
+                            size_t* seal_words, uint32_t roots_out[32]) {
+    return bxo_prove_segment_ex(po2, w_code, w_data, w_accum, 0, 0, seed, seal_words, roots_out);
 }
 void bxo_free(void* p) { free(p); }

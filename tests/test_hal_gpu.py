@@ -495,10 +495,38 @@ def test_scatter_vs_oracle(hal, oracle):
     assert np.array_equal(dst.view(), ref)
     from boundless_amd.hal import HalError
 
+    # scatter is asynchronous: a bad offset / index range is detected on the device and reported by the next blocking call
     bad = offsets.copy()
     bad[3] = into_len + 7
-    with pytest.raises(HalError):
-        hal.scatter(dst, hal.copy_from(index), hal.copy_from(bad), hal.copy_from(values))
+    hal.scatter(dst, hal.copy_from(index), hal.copy_from(bad), hal.copy_from(values))
+    with pytest.raises(HalError, match="offset is outside"):
+        hal.sync()
+    hal.sync()  # the flag is cleared once reported
+    bad_index = index.copy()
+    bad_index[-1] = total + 1
+    hal.scatter(dst, hal.copy_from(bad_index), hal.copy_from(offsets), hal.copy_from(values))
+    with pytest.raises(HalError, match="index range"):
+        dst.view()
+    # a sub-range [index[0], index[last]) of the entries: only those are written
+    dst2 = hal.copy_from(init)
+    hal.scatter(dst2, hal.copy_from(index[5:21]), hal.copy_from(offsets), hal.copy_from(values))
+    ref2 = init.copy()
+    oracle.bxo_scatter(ref2, c(index[5:21]), offsets, c(values), 15)
+    assert np.array_equal(dst2.view(), ref2)
+
+
+@pytest.mark.parametrize("n,count", [(2, 3), (64, 2), (1000, 5), (4096, 16), ((1 << 16) + 1, 3)])
+def test_batch_prefix_products_vs_oracle(hal, oracle, n, count):
+    """`count` independent sequences back to back (the accumulate step's shape): each equals the single-sequence result."""
+    x = rnd(n + count, 4 * n * count)
+    buf = hal.copy_from(x)
+    hal.batch_prefix_products(buf, count)
+    ref = x.copy()
+    for k in range(count):
+        seq = np.ascontiguousarray(ref[4 * n * k: 4 * n * (k + 1)])
+        oracle.bxo_prefix_products(seq, n)
+        ref[4 * n * k: 4 * n * (k + 1)] = seq
+    assert np.array_equal(buf.view(), ref)
 
 
 def test_torch_memory_and_stream_interop(hal, oracle):

@@ -10,13 +10,13 @@ def test_oracle_prover_runs_and_is_deterministic():
     c, _ = ol.prove_segment(10, 4, 8, 4, 1235)
     assert np.array_equal(a, b) and np.array_equal(ra, rb)
     assert not np.array_equal(a, c)
-    assert a[:4].tolist() == [10, 4, 8, 4]
-    # layout: header 4 | 4 trace tops (32 digests each) | coeff_u | fri tops | final coeffs | 50 queries
+    assert a[:6].tolist() == [10, 4, 8, 4, 16, 3]  # po2, widths, the circuit's default knobs (terms, degree)
+    # layout: header 6 | 4 trace tops (32 digests each) | coeff_u | fri tops | final coeffs | 50 queries
     n = 1 << 10
-    taps = 4 + (8 + 2) + (4 + 1) + 16
+    taps = 4 + (8 + 2) + (4 + 4) + 16  # data columns 0 and 4 and the accumulator's four columns are also opened one row back
     rows_fri = 4 * n // 16
     per_query = sum(w + 8 * (12 - 5) for w in (4, 8, 4, 16)) + (64 + 8 * (8 - 5))
-    expect = 4 + 4 * 32 * 8 + 4 * taps + 32 * 8 + 4 * (n // 16) + 50 * per_query
+    expect = 6 + 4 * 32 * 8 + 4 * taps + 32 * 8 + 4 * (n // 16) + 50 * per_query
     assert rows_fri == 256 and a.size == expect
 
 
@@ -27,3 +27,11 @@ def test_oracle_prover_threads_do_not_change_the_seal():
     L.bxo_set_threads(0)
     b, _ = ol.prove_segment(9, 2, 3, 2, 9)
     assert np.array_equal(a, b)
+
+
+def test_circuit_knobs_change_the_seal_and_are_part_of_the_header():
+    a, _ = ol.prove_segment(10, 4, 8, 4, 7)
+    b, _ = ol.prove_segment(10, 4, 8, 4, 7, terms=16, degree=3)  # the defaults, spelled out
+    c, _ = ol.prove_segment(10, 4, 8, 4, 7, terms=5, degree=4)
+    assert np.array_equal(a, b)
+    assert c[:6].tolist() == [10, 4, 8, 4, 5, 4] and not np.array_equal(a[6:], c[6:])

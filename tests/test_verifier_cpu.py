@@ -11,10 +11,23 @@ from boundless_amd.prover import verify_seal
 from oracle import oracle_lib as ol
 
 
-@pytest.mark.parametrize("po2,widths,seed", [(9, (1, 1, 1), 3), (10, (4, 8, 4), 1234), (12, (3, 17, 5), 99), (13, (2, 9, 6), 5)])
+@pytest.mark.parametrize("po2,widths,seed", [(9, (1, 1, 1), 3), (10, (4, 8, 4), 1234), (12, (3, 17, 5), 99), (13, (2, 9, 6), 5),
+                                             (11, (16, 40, 12), 8), (10, (2, 16, 8), 2), (10, (1, 16, 8), 2)])
 def test_honest_seal_is_accepted(po2, widths, seed):
     seal, _ = ol.prove_segment(po2, *widths, seed)
     verify_seal(seal)
+
+
+def _regions(n):
+    """Word offsets into the seal of the (10, 4/8/4) segment, one or two per region."""
+    taps = 4 + (8 + 2) + (4 + 4) + 16
+    h = 6
+    return {
+        "header": 1, "header_terms": 4, "code_top": h + 5, "data_top": h + 256 + 9, "accum_top": h + 512 + 3, "check_top": h + 768 + 100,
+        "coeff_u": h + 1024 + 7, "coeff_u_2tap": h + 1024 + 4 * 4 + 5, "coeff_u_check": h + 1024 + 4 * (taps - 3), "fri_top": h + 1024 + 4 * taps + 11,
+        "final": h + 1024 + 4 * taps + 256 + 5, "query_first": h + 1024 + 4 * taps + 256 + 256 + 2,
+        "query_sibling": h + 1024 + 4 * taps + 256 + 256 + 4 + 3, "last": n - 1,
+    }
 
 
 def test_tampering_anywhere_is_rejected():
@@ -23,12 +36,7 @@ def test_tampering_anywhere_is_rejected():
     n = seal.size
     rng = np.random.default_rng(0)
     # header, code top layer, data top layer, coeff_u, FRI top, final coefficients, query openings, last word
-    taps = 4 + (8 + 2) + (4 + 1) + 16
-    offs = {
-        "header": 1, "code_top": 4 + 5, "data_top": 4 + 256 + 9, "accum_top": 4 + 512 + 3, "check_top": 4 + 768 + 100,
-        "coeff_u": 4 + 1024 + 7, "coeff_u_check": 4 + 1024 + 4 * (taps - 3), "fri_top": 4 + 1024 + 4 * taps + 11,
-        "final": 4 + 1024 + 4 * taps + 256 + 5, "query_first": 4 + 1024 + 4 * taps + 256 + 256 + 2, "last": n - 1,
-    }
+    offs = _regions(n)
     for name, off in offs.items():
         bad = seal.copy()
         bad[off] = (int(bad[off]) + 1) % ol.P
@@ -43,6 +51,57 @@ def test_tampering_anywhere_is_rejected():
         verify_seal(seal[:-1])
     with pytest.raises(HalError):
         verify_seal(np.concatenate([seal, seal[:1]]))
+
+
+def test_non_canonical_words_are_rejected():
+    """x + P behaves like x in the lazily reduced arithmetic (hashes, sums and products agree), so the verifier has to refuse
+    every word >= P explicitly: otherwise a seal could be re-encoded without invalidating it (round-1 advisor finding)."""
+    seal, _ = ol.prove_segment(10, 4, 8, 4, 1234)
+    n = seal.size
+    offs = {k: v for k, v in _regions(n).items() if not k.startswith("header")}
+    rng = np.random.default_rng(1)
+    for off in list(offs.values()) + rng.integers(6, n, 200).tolist():
+        bad = seal.copy()
+        bad[off] = int(bad[off]) + ol.P  # < 2^32 for every canonical word
+        with pytest.raises(HalError, match="non-canonical|header"):
+            verify_seal(bad)
+    bad = seal.copy()
+    bad[10] = 0xFFFFFFFF  # the INVALID marker of unset cells is not a field element either
+    with pytest.raises(HalError, match="non-canonical"):
+        verify_seal(bad)
+
+
+def test_a_seal_of_a_different_circuit_is_rejected():
+    """The circuit's knobs are part of the statement: a proof for (terms, degree) = (5, 4) does not verify as one for the defaults."""
+    seal, _ = ol.prove_segment(10, 4, 8, 4, 1234, terms=5, degree=4)
+    verify_seal(seal)
+    bad = seal.copy()
+    bad[4], bad[5] = 16, 3
+    with pytest.raises(HalError):
+        verify_seal(bad)
+    for hdr in ((0, 3), (65, 3), (16, 6), (16, 0)):
+        bad = seal.copy()
+        bad[4], bad[5] = hdr
+        with pytest.raises(HalError, match="header"):
+            verify_seal(bad)
+
+
+@pytest.mark.parametrize("group,col,row", [(1, 5, 17), (1, 2, 0), (1, 0, 1023), (2, 1, 500), (2, 4, 1023), (0, 0, 3), (0, 1, 9), (1, 3, 77)])
+def test_a_proof_of_a_false_statement_is_rejected(group, col, row):
+    """Soundness, end to end: the oracle proves honestly a witness in which ONE cell is wrong (a derived cell, a free cell a
+    constraint reads, a cell of a permuted copy, an accumulator cell, a selector).  Merkle openings, DEEP and FRI are all
+    consistent with that witness; only the constraint identity at Z can catch it."""
+    L = ol.lib()
+    widths = (4, 16, 8)  # F = 8, J = 8, two accumulators = one pair: columns 2 and 3 are a permuted copy of each other
+    try:
+        L.bxo_set_witness_fault(group, col, row)
+        seal, _ = ol.prove_segment(10, *widths, 4321)
+    finally:
+        L.bxo_set_witness_fault(-1, 0, 0)
+    with pytest.raises(HalError, match="constraint identity"):
+        verify_seal(seal)
+    good, _ = ol.prove_segment(10, *widths, 4321)
+    verify_seal(good)
 
 
 def test_seal_of_another_segment_shape_is_rejected():
