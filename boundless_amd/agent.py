@@ -17,7 +17,8 @@ import numpy as np
 from .hal import HalError, load_library
 from .prover import Segment, SegmentReceipt
 
-RECUR_RECEIPT_PATH = "recursion_receipts"
+RECUR_RECEIPT_PATH = "recursion_receipts"  # the reference's key (tasks/mod.rs:23): written only by an opaque (real) prover
+SYNTHETIC_RECEIPT_PATH = "synthetic_receipts"  # where seals of the synthetic circuit go (include/bx_agent.h)
 SEGMENTS_PATH = "segments"
 TASK_STATES = ("ready", "running", "done", "failed")
 
@@ -37,8 +38,14 @@ _PROVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint
                         C.c_size_t, C.POINTER(C.c_size_t))
 
 
+_PROVE_BLOB_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
+                             C.POINTER(C.c_size_t))
+_FREE_BLOB_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))
+
+
 class _ProverOps(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("seal_words", _SEAL_WORDS_FN), ("prove_segment", _PROVE_FN)]
+    _fields_ = [("user", C.c_void_p), ("seal_words", _SEAL_WORDS_FN), ("prove_segment", _PROVE_FN),
+                ("prove_blob", _PROVE_BLOB_FN), ("free_blob", _FREE_BLOB_FN)]
 
 
 class _ReadyTask(C.Structure):
@@ -54,7 +61,9 @@ class _TaskInfo(C.Structure):
 class _AgentConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("inflight", C.c_uint32), ("w_code", C.c_uint32), ("w_data", C.c_uint32),
                 ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("no_verify", C.c_int32),
-                ("task_stream", C.c_char * 64)]
+                ("task_stream", C.c_char * 64), ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16), ("synthetic", C.c_int32),
+                ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32), ("po2_min", C.c_uint32), ("po2_max", C.c_uint32),
+                ("max_shapes", C.c_uint32)]
 
 
 def _lib():
@@ -76,6 +85,8 @@ def _lib():
         "bx_agent_destroy": ([vp], cp), "bx_agent_poll_work": ([vp, C.c_int64, C.POINTER(C.c_uint64)], cp),
         "bx_agent_stop": ([vp], None), "bx_agent_process_one": ([vp, C.POINTER(_ReadyTask), C.POINTER(C.c_int)], cp),
         "bx_agent_metrics": ([vp, cp, sz], sz),
+        "bx_agent_lane_count": ([vp], C.c_uint32), "bx_agent_lane_device": ([vp, C.c_uint32], C.c_int32),
+        "bx_agent_lane_tasks_done": ([vp, C.c_uint32], C.c_uint64),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(lib, name)
@@ -92,7 +103,7 @@ def _check(msg):
 # ---------------------------------------------------------------------------------------------------------------- wire
 def serialize_segment(seg: Segment) -> bytes:
     """Stand-in for `bincode(risc0_zkvm::Segment)` (tasks/mod.rs:40-47): bx_segment_encode."""
-    out = (C.c_uint8 * 20)()
+    out = (C.c_uint8 * 28)()
     _lib().bx_segment_encode(seg.index, seg.po2, seg.seed & (2**64 - 1), out)
     return bytes(out)
 
@@ -107,9 +118,11 @@ def deserialize_segment(blob: bytes) -> Segment:
 
 
 def deserialize_receipt(blob: bytes) -> SegmentReceipt:
-    """index u64 | po2 u32 | seal_words u32 | seal (include/bx_agent.h)"""
-    index, po2, n = struct.unpack_from("<QII", blob)
-    return SegmentReceipt(seal=np.frombuffer(blob, dtype="<u4", count=n, offset=16).copy(), index=index, po2=po2)
+    """"BXSYNRCP" | index u64 | po2 u32 | seal_words u32 | seal (include/bx_agent.h)"""
+    if blob[:8] != b"BXSYNRCP":
+        raise ValueError("not a synthetic receipt blob")
+    index, po2, n = struct.unpack_from("<QII", blob, 8)
+    return SegmentReceipt(seal=np.frombuffer(blob, dtype="<u4", count=n, offset=24).copy(), index=index, po2=po2)
 
 
 # -------------------------------------------------------------------------------------------------------------- stores
@@ -200,21 +213,50 @@ class TaskDb:
 
 # --------------------------------------------------------------------------------------------------------------- agent
 class Agent:
-    """One per process / GPU (lib.rs:180-195).  `prover=None` = the HIP segment prover on `device` with `inflight` lanes;
-    a Python object with `prove_segment(Segment) -> SegmentReceipt` may be injected instead (tests, no GPU)."""
+    """One per process (lib.rs:180-195).  `prover=None` = the HIP segment prover with `inflight` lanes on `device`, or on each
+    of `devices` (one agent, several GPUs, one shared task db = the work-stealing queue).  A Python object with
+    `prove_segment(Segment) -> SegmentReceipt` may be injected instead (tests, no GPU); `blob_prover` (bytes -> bytes) is the
+    opaque mode a real prover would use (reference keys).  The built-in and injected provers speak the SYNTHETIC wire format
+    and need `synthetic=True` (the default here; the C ABI's default is off, see include/bx_agent.h)."""
 
     def __init__(self, prover=None, device=0, inflight=None, widths=(16, 256, 64), redis_ttl=8 * 60 * 60, poll_time=1.0,
-                 verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20):
+                 verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20, devices=None, synthetic=True,
+                 terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None):
         self._lib = _lib()
         self.store = store or HotStore()
         self.taskdb = taskdb or TaskDb()
         self.prover = prover
-        cfg = _AgentConfig(device=device, inflight=inflight or (1 if prover is not None else 3), w_code=widths[0],
+        injected = prover is not None or blob_prover is not None
+        cfg = _AgentConfig(device=device, inflight=inflight or (1 if injected else 3), w_code=widths[0],
                            w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, no_verify=int(not verify),
-                           task_stream=task_stream.encode())
+                           task_stream=task_stream.encode(), synthetic=int(bool(synthetic)), cons_terms=terms, cons_degree=degree,
+                           po2_min=po2_range[0], po2_max=po2_range[1], max_shapes=max_shapes)
+        if devices:
+            cfg.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = d
         self._errs = {}
+        self._blobs = {}
         ops_ptr = None
-        if prover is not None:
+        if blob_prover is not None:
+            def prove_blob(_user, lane, seg, n, out, out_len):
+                try:
+                    rec = bytes(blob_prover(bytes(bytearray(seg[:n]))))
+                    buf = (C.c_uint8 * max(len(rec), 1)).from_buffer_copy(rec or b"\0")
+                    self._blobs[lane] = buf  # owned here until free_blob
+                    out[0] = C.cast(buf, C.POINTER(C.c_uint8))
+                    out_len[0] = len(rec)
+                    return None
+                except Exception as e:  # noqa: BLE001
+                    self._errs[lane] = C.create_string_buffer(f"{e}".encode())
+                    return C.cast(self._errs[lane], C.c_void_p).value
+
+            def free_blob(_user, _ptr):
+                return None
+
+            self._ops = _ProverOps(None, _SEAL_WORDS_FN(), _PROVE_FN(), _PROVE_BLOB_FN(prove_blob), _FREE_BLOB_FN(free_blob))
+            ops_ptr = C.cast(C.pointer(self._ops), C.c_void_p)
+        elif prover is not None:
             def seal_words(_user, _lane, _po2):
                 return seal_cap
 
@@ -231,11 +273,16 @@ class Agent:
                     self._errs[lane] = C.create_string_buffer(f"{e}".encode())
                     return C.cast(self._errs[lane], C.c_void_p).value
 
-            self._ops = _ProverOps(None, _SEAL_WORDS_FN(seal_words), _PROVE_FN(prove))
+            self._ops = _ProverOps(None, _SEAL_WORDS_FN(seal_words), _PROVE_FN(prove), _PROVE_BLOB_FN(), _FREE_BLOB_FN())
             ops_ptr = C.cast(C.pointer(self._ops), C.c_void_p)
         self._h = C.c_void_p()
         _check(self._lib.bx_agent_create(C.byref(cfg), C.byref(self.store.ops), C.byref(self.taskdb.ops), ops_ptr,
                                          C.byref(self._h)))
+
+    def lane_stats(self):
+        """[(device, tasks completed)] per lane: which GPU's lanes claimed how much of the shared queue."""
+        n = self._lib.bx_agent_lane_count(self._h)
+        return [(self._lib.bx_agent_lane_device(self._h, i), self._lib.bx_agent_lane_tasks_done(self._h, i)) for i in range(n)]
 
     def poll_work(self, max_idle_polls=None):
         """`Agent::poll_work`: returns the number of tasks completed; raises only when the task db itself fails."""

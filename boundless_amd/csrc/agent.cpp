@@ -7,8 +7,10 @@
 //   redis helpers         bento/crates/workflow/src/redis.rs:19-63   (operation names + redis_operations metrics)
 //   metric definitions    bento/crates/workflow-common/src/metrics.rs:61-70,108-117
 // Redis/Postgres themselves are out of scope; they are the callback tables of include/bx_agent.h.  The `lift` step needs the
-// recursion circuit (not available offline), so the verified segment receipt itself is what gets stored under
-// the recursion-receipt key.
+// recursion circuit (not available offline) and the built-in prover proves the SYNTHETIC circuit of
+// bx_prover.h: its seals are stored under job:{id}:synthetic_receipts:{task}, never under the reference's recursion-receipt
+// key, and only when the agent was created with cfg.synthetic = 1.  A real prover plugs in through
+// bx_segment_prover_ops::prove_blob (raw bytes in, raw bytes out) and then the reference's keys are used.
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -17,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -332,13 +335,17 @@ static int mem_get(void* user, const char* key, uint8_t** value, size_t* len, ch
 static void mem_free_value(void*, uint8_t* v) { free(v); }
 static int mem_set_ex(void* user, const char* key, const uint8_t* value, size_t len, uint64_t ttl, char*, size_t) {
     auto* s = (bx_mem_store*)user;
-    std::lock_guard<std::mutex> g(s->mu);
-    bx_mem_store::Val v;
-    v.bytes.assign(value, value + len);
-    v.expires = ttl != 0;
-    if (ttl) v.deadline = Clock::now() + std::chrono::seconds(ttl);
-    s->kv[key] = std::move(v);
-    return 0;
+    try {  // these tables are a C interface: an allocation failure is a transport error, not an exception
+        std::lock_guard<std::mutex> g(s->mu);
+        bx_mem_store::Val v;
+        v.bytes.assign(value, value + len);
+        v.expires = ttl != 0;
+        if (ttl) v.deadline = Clock::now() + std::chrono::seconds(ttl);
+        s->kv[key] = std::move(v);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
 }
 static int mem_unlink(void* user, const char* key, char*, size_t) {
     auto* s = (bx_mem_store*)user;
@@ -392,14 +399,22 @@ static int tdb_done(void* user, const char* job, const char* task, const char* o
     std::lock_guard<std::mutex> g(t->mu);
     auto* r = t->find_locked(job, task);
     if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
+    try {
+        r->output = output ? output : "null";
+    } catch (...) {
+        return -1;
+    }
     r->state = BX_TASK_DONE;
-    r->output = output ? output : "null";
     return 1;
 }
 static int tdb_failed(void* user, const char* job, const char* task, const char* error, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
     std::lock_guard<std::mutex> g(t->mu);
-    return t->fail_locked(t->find_locked(job, task), error);
+    try {
+        return t->fail_locked(t->find_locked(job, task), error);
+    } catch (...) {
+        return -1;
+    }
 }
 // 1_taskdb.sql:361-391
 static int tdb_retry(void* user, const char* job, const char* task, char*, size_t) {
@@ -429,7 +444,13 @@ static int tdb_current_retries(void* user, const char* job, const char* task, in
 namespace {
 struct Lane {
     bx_ctx* ctx = nullptr;
-    std::map<uint32_t, bx_prover*> provers;  // one per segment size seen (buffers are allocated once per shape)
+    int32_t device = -1;
+    // one prover (= one set of device buffers, several GB at po2 20) per segment size seen, least recently used first;
+    // at most cfg.max_shapes are kept
+    std::vector<std::pair<uint32_t, bx_prover*>> provers;
+    std::atomic<uint64_t> done{0};
+    Lane() = default;
+    Lane(const Lane&) = delete;
 };
 
 // a proved segment on its way through the host half of the task
@@ -439,6 +460,7 @@ struct Pending {
     std::string job_prefix, segment_key;
     uint64_t seg_index = 0;
     uint32_t po2 = 0;
+    bool opaque = false;  // proved through prove_blob: `wire` already holds the receipt bytes to store
     std::vector<uint32_t> seal;
     size_t words = 0;
     double prove_s = 0;
@@ -485,47 +507,70 @@ struct Finisher {
 };
 }  // namespace
 
+struct bx_agent;
 struct bx_agent {
     bx_agent_config cfg;
     bx_hot_store_ops store;
     bx_taskdb_ops taskdb;
     bx_segment_prover_ops prover;
     bool hip = false;
-    std::vector<Lane> lanes;
+    std::vector<std::unique_ptr<Lane>> lanes;
     Metrics metrics;
     std::atomic<int> stop{0};
     std::mutex create_mu;  // device buffer allocation of a new shape is serialised across lanes
 
     // ---- default prover ops: the HIP segment prover, one ctx per lane ----
-    const char* hip_prover_for(uint32_t lane_idx, uint32_t po2, bx_prover** out) {
-        Lane& lane = lanes[lane_idx];
-        auto it = lane.provers.find(po2);
-        if (it != lane.provers.end()) {
-            *out = it->second;
-            return nullptr;
+    // Errors of bx_init / bx_prover_create are kept per lane (the text is owned by the failing call) and surface as the
+    // task's error instead of a bare "no prover".
+    const char* hip_prover_for(uint32_t lane_idx, uint32_t po2, bx_prover** out, std::string* err) {
+        Lane& lane = *lanes[lane_idx];
+        if (po2 < cfg.po2_min || po2 > cfg.po2_max) {
+            *err = "segment po2 " + std::to_string(po2) + " is outside the sizes this agent accepts [" + std::to_string(cfg.po2_min) + ", " +
+                   std::to_string(cfg.po2_max) + "]";
+            return err->c_str();
         }
+        for (size_t i = 0; i < lane.provers.size(); ++i)
+            if (lane.provers[i].first == po2) {
+                auto hit = lane.provers[i];
+                lane.provers.erase(lane.provers.begin() + (long)i);
+                lane.provers.push_back(hit);  // most recently used last
+                *out = hit.second;
+                return nullptr;
+            }
         std::lock_guard<std::mutex> g(create_mu);
         if (!lane.ctx) {
-            if (const char* e = bx_init(cfg.device, &lane.ctx)) return e;
+            if (const char* e = bx_init(lane.device, &lane.ctx)) {
+                *err = std::string("bx_init(device ") + std::to_string(lane.device) + "): " + e;
+                return err->c_str();
+            }
         }
-        bx_segment_params shape{po2, cfg.w_code, cfg.w_data, cfg.w_accum};
+        while (lane.provers.size() >= cfg.max_shapes) {  // evict before allocating the new buffer set
+            (void)bx_prover_destroy(lane.provers.front().second);
+            lane.provers.erase(lane.provers.begin());
+        }
+        bx_segment_params shape{po2, cfg.w_code, cfg.w_data, cfg.w_accum, cfg.cons_terms, cfg.cons_degree};
         bx_prover* p = nullptr;
-        if (const char* e = bx_prover_create(lane.ctx, &shape, &p)) return e;
-        lane.provers[po2] = p;
+        if (const char* e = bx_prover_create(lane.ctx, &shape, &p)) {
+            *err = std::string("bx_prover_create(po2 ") + std::to_string(po2) + "): " + e;
+            return err->c_str();
+        }
+        lane.provers.emplace_back(po2, p);
         *out = p;
         return nullptr;
     }
+    static inline thread_local std::string hip_err;
     static size_t hip_seal_words(void* user, uint32_t lane, uint32_t po2) {
         auto* a = (bx_agent*)user;
         bx_prover* p = nullptr;
-        if (a->hip_prover_for(lane, po2, &p)) return 0;
+        if (a->hip_prover_for(lane, po2, &p, &hip_err)) return 0;
+        hip_err.clear();
         return bx_prover_seal_words(p);
     }
     static const char* hip_prove(void* user, uint32_t lane, uint64_t, uint32_t po2, uint64_t seed, uint32_t* seal, size_t cap,
                                  size_t* words) {
         auto* a = (bx_agent*)user;
         bx_prover* p = nullptr;
-        if (const char* e = a->hip_prover_for(lane, po2, &p)) return e;
+        if (const char* e = a->hip_prover_for(lane, po2, &p, &hip_err)) return e;
         return bx_prove_segment(p, seed, seal, cap, words);
     }
 
@@ -576,13 +621,28 @@ struct bx_agent {
         std::vector<uint8_t> blob;
         std::string e = store_get(out->segment_key, &blob);
         if (!e.empty()) return "segment data not found for segment key: " + out->segment_key + ": " + e;
+        out->opaque = prover.prove_blob != nullptr;
+        if (out->opaque) {  // a real prover: bytes in, bytes out (prove.rs:36-109 happens inside the callback)
+            auto prove_start = Clock::now();
+            uint8_t* rec = nullptr;
+            size_t rec_len = 0;
+            if (const char* pe = prover.prove_blob(prover.user, lane_idx, blob.data(), blob.size(), &rec, &rec_len)) return pe;
+            out->wire.assign(rec, rec + rec_len);
+            if (prover.free_blob) prover.free_blob(prover.user, rec);
+            out->prove_s = secs_since(prove_start);
+            metrics.record_task_operation("prove", "prove_segment", "success", out->prove_s);
+            return "";
+        }
         uint64_t seed = 0;
         if (const char* de = bx_segment_decode(blob.data(), blob.size(), &out->seg_index, &out->po2, &seed)) return de;
 
         auto prove_start = Clock::now();
         if (!prover.prove_segment) return "[BENTO-PROVE-002] Missing prover from prove task";
         size_t cap = prover.seal_words(prover.user, lane_idx, out->po2);
-        if (cap == 0) return "prove_segment: no prover for a segment of po2 " + std::to_string(out->po2);
+        if (cap == 0) {
+            if (hip && !hip_err.empty()) return "prove_segment: " + hip_err;
+            return "prove_segment: no prover for a segment of po2 " + std::to_string(out->po2);
+        }
         if (out->seal.size() < cap) out->seal.resize(cap);
         out->words = 0;
         if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->seg_index, out->po2, seed, out->seal.data(), cap,
@@ -594,18 +654,26 @@ struct bx_agent {
     }
     //   second half: verify -> store under the recursion-receipt key -> unlink the segment
     std::string finish_stage(Pending* p) {
-        if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
-            if (const char* ve = bx_verify_segment(p->seal.data(), p->words))
-                return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
+        std::string output_key;
+        if (p->opaque) {
+            // the callback returned the serialized lifted receipt: reference key (RECUR_RECEIPT_PATH, tasks/mod.rs:23)
+            output_key = p->job_prefix + ":" BX_RECUR_RECEIPT_PATH ":" + p->task.task_id;
+        } else {
+            if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
+                if (const char* ve = bx_verify_segment(p->seal.data(), p->words))
+                    return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
+            }
+            // a synthetic seal is not a lifted receipt: it never goes under the key Join workers read
+            output_key = p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + p->task.task_id;
+            p->wire.resize(BX_RECEIPT_HEADER_BYTES + 4 * p->words);
+            memcpy(p->wire.data(), BX_RECEIPT_MAGIC, 8);
+            put_le(p->wire.data() + 8, p->seg_index, 8);
+            put_le(p->wire.data() + 16, p->po2, 4);
+            put_le(p->wire.data() + 20, p->words, 4);
+            for (size_t i = 0; i < p->words; ++i) put_le(p->wire.data() + BX_RECEIPT_HEADER_BYTES + 4 * i, p->seal[i], 4);
         }
         metrics.record_task_operation("prove", "prove_segment", "success", p->prove_s);  // helpers::record_task, prove.rs:57
 
-        std::string output_key = p->job_prefix + ":recursion_receipts:" + p->task.task_id;  // RECUR_RECEIPT_PATH, tasks/mod.rs:23
-        p->wire.resize(BX_RECEIPT_HEADER_BYTES + 4 * p->words);
-        put_le(p->wire.data(), p->seg_index, 8);
-        put_le(p->wire.data() + 8, p->po2, 4);
-        put_le(p->wire.data() + 12, p->words, 4);
-        for (size_t i = 0; i < p->words; ++i) put_le(p->wire.data() + BX_RECEIPT_HEADER_BYTES + 4 * i, p->seal[i], 4);
         std::string e = store_set(output_key, p->wire, cfg.redis_ttl);
         if (!e.empty()) return "Failed to set receipt key with expiry: " + e;
 
@@ -681,17 +749,33 @@ struct bx_agent {
             if (fatal_out->empty()) *fatal_out = m;
             stop.store(1);
         };
+        // neither thread lets a C++ exception escape (bad_alloc from a seal / string / vector growth would otherwise
+        // reach std::terminate): it becomes the task's error, or the loop's fatal error when even that cannot be recorded
         std::thread finisher([&] {
             while (Pending* p = fin.take()) {
-                bool fatal = false;
-                std::string err = complete(p, &fatal);
-                if (err.empty()) {
-                    done->fetch_add(1);
-                } else if (fatal) {
-                    set_fatal(err);
-                } else {
-                    std::string f = handle_failure(p->task, err);
-                    if (!f.empty()) set_fatal(f);
+                try {
+                    bool fatal = false;
+                    std::string err;
+                    try {
+                        err = complete(p, &fatal);
+                    } catch (const std::exception& e) {
+                        err = std::string("[BENTO-WF-115] Prove failed: exception in the host half: ") + e.what();
+                    }
+                    if (err.empty()) {
+                        done->fetch_add(1);
+                        lanes[lane]->done.fetch_add(1);
+                    } else if (fatal) {
+                        set_fatal(err);
+                    } else {
+                        std::string f = handle_failure(p->task, err);
+                        if (!f.empty()) set_fatal(f);
+                    }
+                } catch (...) {
+                    try {
+                        set_fatal("lane finisher: exception while recording a task result");
+                    } catch (...) {
+                        stop.store(1);
+                    }
                 }
                 fin.release();
             }
@@ -719,9 +803,19 @@ struct bx_agent {
             }
             idle = 0;
             Pending* p = &slots[cur];
-            std::string err = dispatch(lane, task, p);
+            std::string err;
+            try {
+                err = dispatch(lane, task, p);
+            } catch (const std::exception& e) {
+                err = std::string("[BENTO-WF-115] Prove failed: exception in the device half: ") + e.what();
+            }
             if (!err.empty()) {
-                std::string f = handle_failure(task, err);
+                std::string f;
+                try {
+                    f = handle_failure(task, err);
+                } catch (const std::exception& e) {
+                    f = std::string("exception while recording a task failure: ") + e.what();
+                }
                 if (!f.empty()) {
                     set_fatal(f);
                     break;
@@ -753,16 +847,20 @@ size_t bx_mem_store_key_count(bx_mem_store* s) {
     return s->kv.size();
 }
 const char* bx_mem_store_keys(bx_mem_store* s, char* out, size_t cap) {
-    if (!s || !out || cap == 0) return "bx_mem_store_keys: NULL argument";
-    std::lock_guard<std::mutex> g(s->mu);
-    s->sweep_locked();
-    std::string all;
-    for (auto& kv : s->kv) {
-        if (!all.empty()) all += "\n";
-        all += kv.first;
+    try {
+        if (!s || !out || cap == 0) return "bx_mem_store_keys: NULL argument";
+        std::lock_guard<std::mutex> g(s->mu);
+        s->sweep_locked();
+        std::string all;
+        for (auto& kv : s->kv) {
+            if (!all.empty()) all += "\n";
+            all += kv.first;
+        }
+        snprintf(out, cap, "%s", all.c_str());
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_mem_store_keys: out of memory";
     }
-    snprintf(out, cap, "%s", all.c_str());
-    return nullptr;
 }
 
 const char* bx_mem_taskdb_create(bx_mem_taskdb** out) {
@@ -776,29 +874,37 @@ bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t) {
 }
 const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
                                       int32_t max_retries) {
-    if (!t || !stream || !job || !task || !def) return "bx_mem_taskdb_create_task: NULL argument";
-    std::lock_guard<std::mutex> g(t->mu);
-    if (t->find_locked(job, task)) return fail(std::string("task already exists: ") + job + ":" + task);
-    bx_mem_taskdb::Row r;
-    r.stream = stream;
-    r.job = job;
-    r.task = task;
-    r.def = def;
-    r.max_retries = max_retries;
-    t->rows.push_back(std::move(r));
-    return nullptr;
+    try {
+        if (!t || !stream || !job || !task || !def) return "bx_mem_taskdb_create_task: NULL argument";
+        std::lock_guard<std::mutex> g(t->mu);
+        if (t->find_locked(job, task)) return fail(std::string("task already exists: ") + job + ":" + task);
+        bx_mem_taskdb::Row r;
+        r.stream = stream;
+        r.job = job;
+        r.task = task;
+        r.def = def;
+        r.max_retries = max_retries;
+        t->rows.push_back(std::move(r));
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_mem_taskdb_create_task: out of memory";
+    }
 }
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const char* task, bx_task_info* out) {
-    if (!t || !job || !task || !out) return "bx_mem_taskdb_task_info: NULL argument";
-    std::lock_guard<std::mutex> g(t->mu);
-    auto* r = t->find_locked(job, task);
-    if (!r) return fail(std::string("no such task: ") + job + ":" + task);
-    out->state = r->state;
-    out->retries = r->retries;
-    out->max_retries = r->max_retries;
-    snprintf(out->error, sizeof out->error, "%s", r->error.c_str());
-    snprintf(out->output, sizeof out->output, "%s", r->output.c_str());
-    return nullptr;
+    try {
+        if (!t || !job || !task || !out) return "bx_mem_taskdb_task_info: NULL argument";
+        std::lock_guard<std::mutex> g(t->mu);
+        auto* r = t->find_locked(job, task);
+        if (!r) return fail(std::string("no such task: ") + job + ":" + task);
+        out->state = r->state;
+        out->retries = r->retries;
+        out->max_retries = r->max_retries;
+        snprintf(out->error, sizeof out->error, "%s", r->error.c_str());
+        snprintf(out->output, sizeof out->output, "%s", r->output.c_str());
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_mem_taskdb_task_info: out of memory";
+    }
 }
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state) {
     if (!t) return 0;
@@ -810,15 +916,18 @@ size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state) {
 
 // ---- wire ----
 void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]) {
-    put_le(out, index, 8);
-    put_le(out + 8, po2, 4);
-    put_le(out + 12, seed, 8);
+    memcpy(out, BX_SEGMENT_MAGIC, 8);
+    put_le(out + 8, index, 8);
+    put_le(out + 16, po2, 4);
+    put_le(out + 20, seed, 8);
 }
 const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed) {
-    if (!blob || len != BX_SEGMENT_WIRE_BYTES) return "Failed to deserialize segment data from redis";
-    if (index) *index = get_le(blob, 8);
-    if (po2) *po2 = (uint32_t)get_le(blob + 8, 4);
-    if (seed) *seed = get_le(blob + 12, 8);
+    if (!blob || len != BX_SEGMENT_WIRE_BYTES || memcmp(blob, BX_SEGMENT_MAGIC, 8) != 0)
+        return "Failed to deserialize segment data from redis: not a synthetic segment blob (the built-in prover proves the "
+               "synthetic circuit only; a bincode(Segment) needs a prover plugged in through prove_blob)";
+    if (index) *index = get_le(blob + 8, 8);
+    if (po2) *po2 = (uint32_t)get_le(blob + 16, 4);
+    if (seed) *seed = get_le(blob + 20, 8);
     return nullptr;
 }
 
@@ -830,36 +939,60 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
     if (!taskdb->request_work || !taskdb->update_task_done || !taskdb->update_task_failed || !taskdb->update_task_retry ||
         !taskdb->current_retries)
         return "bx_agent_create: task db ops incomplete";
-    if (prover && (!prover->prove_segment || !prover->seal_words)) return "bx_agent_create: prover ops incomplete";
-    auto* a = new (std::nothrow) bx_agent();
-    if (!a) return "bx_agent_create: out of memory";
-    a->cfg = *cfg;
-    a->cfg.task_stream[sizeof a->cfg.task_stream - 1] = 0;
-    if (!a->cfg.task_stream[0]) snprintf(a->cfg.task_stream, sizeof a->cfg.task_stream, "prove");
-    if (a->cfg.inflight == 0) a->cfg.inflight = 3;
-    if (a->cfg.inflight > 16) {
-        delete a;
-        return "bx_agent_create: inflight must be <= 16";
-    }
-    if (!a->cfg.w_code) a->cfg.w_code = 16;
-    if (!a->cfg.w_data) a->cfg.w_data = 256;
-    if (!a->cfg.w_accum) a->cfg.w_accum = 64;
-    if (!a->cfg.redis_ttl) a->cfg.redis_ttl = 8 * 60 * 60;
-    if (!(a->cfg.poll_time > 0)) a->cfg.poll_time = 1.0;
-    a->store = *store;
-    a->taskdb = *taskdb;
-    a->lanes.resize(a->cfg.inflight);
-    if (prover) {
-        a->prover = *prover;
-    } else {
-        a->hip = true;
-        a->prover = bx_segment_prover_ops{a, bx_agent::hip_seal_words, bx_agent::hip_prove};
-        // like Agent::new (lib.rs:241-252) the device context is created up front so a missing GPU fails here, loudly
-        if (const char* e = bx_init(a->cfg.device, &a->lanes[0].ctx)) {
-            std::string m = std::string("bx_agent_create: ") + e;
+    if (prover && !prover->prove_blob && (!prover->prove_segment || !prover->seal_words)) return "bx_agent_create: prover ops incomplete";
+    const bool opaque = prover && prover->prove_blob;
+    if (!opaque && !cfg->synthetic)
+        return "bx_agent_create: the built-in prover proves the synthetic circuit of bx_prover.h, not rv32im segments: set "
+               "cfg.synthetic = 1 to run it (seals go to job:{id}:synthetic_receipts:{task}), or plug a real prover in through "
+               "bx_segment_prover_ops::prove_blob";
+    bx_agent* a = nullptr;
+    try {
+        a = new bx_agent();
+        a->cfg = *cfg;
+        a->cfg.task_stream[sizeof a->cfg.task_stream - 1] = 0;
+        if (!a->cfg.task_stream[0]) snprintf(a->cfg.task_stream, sizeof a->cfg.task_stream, "prove");
+        if (a->cfg.inflight == 0) a->cfg.inflight = 3;
+        if (a->cfg.inflight > 16 || a->cfg.n_devices > 16) {
             delete a;
-            return fail(m);
+            return "bx_agent_create: inflight and n_devices must be <= 16";
         }
+        if (!a->cfg.w_code) a->cfg.w_code = 16;
+        if (!a->cfg.w_data) a->cfg.w_data = 256;
+        if (!a->cfg.w_accum) a->cfg.w_accum = 64;
+        if (!a->cfg.redis_ttl) a->cfg.redis_ttl = 8 * 60 * 60;
+        if (!(a->cfg.poll_time > 0)) a->cfg.poll_time = 1.0;
+        if (!a->cfg.po2_min) a->cfg.po2_min = 9;
+        if (!a->cfg.po2_max) a->cfg.po2_max = 22;
+        if (!a->cfg.max_shapes) a->cfg.max_shapes = 2;
+        if (a->cfg.n_devices == 0) {
+            a->cfg.n_devices = 1;
+            a->cfg.devices[0] = a->cfg.device;
+        }
+        a->store = *store;
+        a->taskdb = *taskdb;
+        // lane l proves on device devices[l / inflight]
+        for (uint32_t l = 0; l < a->cfg.n_devices * a->cfg.inflight; ++l) {
+            a->lanes.emplace_back(new Lane());
+            a->lanes.back()->device = a->cfg.devices[l / a->cfg.inflight];
+        }
+        if (prover) {
+            a->prover = *prover;
+        } else {
+            a->hip = true;
+            a->prover = bx_segment_prover_ops{a, bx_agent::hip_seal_words, bx_agent::hip_prove, nullptr, nullptr};
+            // like Agent::new (lib.rs:241-252) the device contexts are created up front so a missing GPU fails here, loudly
+            for (uint32_t d = 0; d < a->cfg.n_devices; ++d) {
+                Lane& first = *a->lanes[(size_t)d * a->cfg.inflight];
+                if (const char* e = bx_init(first.device, &first.ctx)) {
+                    std::string m = std::string("bx_agent_create: device ") + std::to_string(first.device) + ": " + e;
+                    (void)bx_agent_destroy(a);
+                    return fail(m);
+                }
+            }
+        }
+    } catch (const std::exception& e) {
+        if (a) (void)bx_agent_destroy(a);
+        return fail(std::string("bx_agent_create: ") + e.what());
     }
     *out = a;
     return nullptr;
@@ -868,17 +1001,26 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
 const char* bx_agent_destroy(bx_agent* a) {
     if (!a) return nullptr;
     const char* first = nullptr;
-    for (auto& lane : a->lanes) {
-        for (auto& kv : lane.provers)
-            if (const char* e = bx_prover_destroy(kv.second))
-                if (!first) first = fail(e);
-        if (lane.ctx)
-            if (const char* e = bx_free(lane.ctx))
-                if (!first) first = fail(e);
+    try {
+        for (auto& lp : a->lanes) {
+            Lane& lane = *lp;
+            for (auto& kv : lane.provers)
+                if (const char* e = bx_prover_destroy(kv.second))
+                    if (!first) first = fail(e);
+            if (lane.ctx)
+                if (const char* e = bx_free(lane.ctx))
+                    if (!first) first = fail(e);
+        }
+    } catch (...) {
+        first = "bx_agent_destroy: exception";
     }
     delete a;
     return first;
 }
+
+uint32_t bx_agent_lane_count(const bx_agent* a) { return a ? (uint32_t)a->lanes.size() : 0; }
+int32_t bx_agent_lane_device(const bx_agent* a, uint32_t lane) { return a && lane < a->lanes.size() ? a->lanes[lane]->device : -1; }
+uint64_t bx_agent_lane_tasks_done(const bx_agent* a, uint32_t lane) { return a && lane < a->lanes.size() ? a->lanes[lane]->done.load() : 0; }
 
 void bx_agent_stop(bx_agent* a) {
     if (a) a->stop.store(1, std::memory_order_relaxed);
@@ -887,9 +1029,10 @@ void bx_agent_stop(bx_agent* a) {
 const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* tasks_done) {
     if (!a) return "bx_agent_poll_work: NULL agent";
     std::atomic<uint64_t> done{0};
-    std::vector<std::string> fatal(a->lanes.size());
+    std::vector<std::string> fatal;
     std::vector<std::thread> threads;
     try {
+        fatal.resize(a->lanes.size());
         for (uint32_t l = 1; l < a->lanes.size(); ++l)
             threads.emplace_back([a, l, max_idle_polls, &done, &fatal] { a->lane_loop(l, max_idle_polls, &done, &fatal[l]); });
     } catch (...) {
@@ -897,7 +1040,12 @@ const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* ta
         for (auto& t : threads) t.join();
         return "bx_agent_poll_work: could not start lane threads";
     }
-    a->lane_loop(0, max_idle_polls, &done, &fatal[0]);
+    try {
+        a->lane_loop(0, max_idle_polls, &done, &fatal[0]);
+    } catch (const std::exception& e) {
+        a->stop.store(1);
+        fatal[0] = std::string("bx_agent_poll_work: ") + e.what();
+    }
     for (auto& t : threads) t.join();
     if (tasks_done) *tasks_done = done.load();
     for (auto& f : fatal)
@@ -907,22 +1055,34 @@ const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* ta
 
 const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok) {
     if (!a || !task) return "bx_agent_process_one: NULL argument";
-    Pending p;
-    bool fatal = false;
-    std::string err = a->dispatch(0, *task, &p);
-    if (err.empty()) err = a->complete(&p, &fatal);
-    if (ok) *ok = err.empty();
-    if (err.empty()) return nullptr;
-    if (fatal) return fail(err);
-    std::string f = a->handle_failure(*task, err);
-    return f.empty() ? nullptr : fail(f);
+    try {
+        Pending p;
+        bool fatal = false;
+        std::string err = a->dispatch(0, *task, &p);
+        if (err.empty()) err = a->complete(&p, &fatal);
+        if (ok) *ok = err.empty();
+        if (err.empty()) {
+            a->lanes[0]->done.fetch_add(1);
+            return nullptr;
+        }
+        if (fatal) return fail(err);
+        std::string f = a->handle_failure(*task, err);
+        return f.empty() ? nullptr : fail(f);
+    } catch (const std::exception& e) {
+        if (ok) *ok = 0;
+        return fail(std::string("bx_agent_process_one: ") + e.what());
+    }
 }
 
 size_t bx_agent_metrics(bx_agent* a, char* out, size_t cap) {
     if (!a) return 0;
-    std::string s = a->metrics.exposition();
-    if (out && cap) snprintf(out, cap, "%s", s.c_str());
-    return s.size() + 1;
+    try {
+        std::string s = a->metrics.exposition();
+        if (out && cap) snprintf(out, cap, "%s", s.c_str());
+        return s.size() + 1;
+    } catch (...) {
+        return 0;
+    }
 }
 
 }  // extern "C"

@@ -6,6 +6,11 @@
 //
 // All three stages are VALU-bound (no HBM or MFMA roofline applies): a derived cell / a constraint costs T*(G-1)
 // Montgomery products, the loads around it are one coalesced dword per lane and column.
+// The signed multiply-adds are left to the compiler in this translation unit (poseidon2.hip pins them as single asm
+// statements because its loop-carried cells get widened): here the terms of a cell share their inner products (7 pool entries
+// give at most 28 distinct pairs), and only un-pinned code lets hipcc find them: 446 instead of 605 instructions per cell
+// for (T, G) = (48, 3), and none of the s_nops it places between adjacent asm statements.
+#define BX_PLAIN_MAD 1
 #include "circuit.hpp"
 #include "ctx.hpp"
 #include "circuit_dev.hpp"
@@ -188,8 +193,9 @@ static inline unsigned grid_for(size_t n, unsigned bs = 256, size_t cap = 1 << 1
 
 #define BX_CIRCUIT_DISPATCH(KERNEL, ...)                                              \
     do {                                                                              \
-        if (cc.T == 16 && cc.G == 3) hipLaunchKernelGGL((KERNEL<16, 3>), __VA_ARGS__); \
-        else if (cc.T == 32 && cc.G == 3) hipLaunchKernelGGL((KERNEL<32, 3>), __VA_ARGS__); \
+        if (cc.T == 64 && cc.G == 4) hipLaunchKernelGGL((KERNEL<64, 4>), __VA_ARGS__); \
+        else if (cc.T == 48 && cc.G == 3) hipLaunchKernelGGL((KERNEL<48, 3>), __VA_ARGS__); \
+        else if (cc.T == 16 && cc.G == 3) hipLaunchKernelGGL((KERNEL<16, 3>), __VA_ARGS__); \
         else if (cc.T == 8 && cc.G == 2) hipLaunchKernelGGL((KERNEL<8, 2>), __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<0, 0>), __VA_ARGS__);                          \
     } while (0)

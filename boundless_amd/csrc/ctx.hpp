@@ -59,6 +59,7 @@ struct bx_ctx {
     uint32_t h_rc[BX_POSEIDON2_RC_COUNT];
     uint32_t h_diag[24];
     uint32_t* d_p2 = nullptr;
+    int live_provers = 0;  // bx_prover objects created on this ctx and not yet destroyed
 
     // deferred device-side errors (e.g. a scatter offset out of range): kernels OR bits into *d_flag, the blocking entry
     // points (bx_d2h, bx_sync) copy it to the pinned *h_flag with their own synchronisation and report it

@@ -6,6 +6,7 @@
 // height.  `finish` folds what is left — joins from the smallest peak upwards, unions from the oldest pair downwards —
 // and appends the Finalize task that depends on the single join root and the single union root.  Task numbers, heights
 // and dependency lists reproduce the reference's unit tests (mod.rs:254-453), restated in tests/test_planner_agent_cpu.py.
+#include <exception>
 #include <deque>
 #include <string>
 #include <vector>
@@ -78,54 +79,66 @@ const char* bx_planner_create(bx_planner** out) {
 void bx_planner_destroy(bx_planner* p) { delete p; }
 
 const char* bx_planner_enqueue_segment(bx_planner* p, uint64_t* task_number) {
-    if (!p) return "bx_planner: NULL planner";
-    if (p->finished) return p->fail("Cannot add segment to finished plan");  // PlannerErr::PlanFinalized
-    uint64_t n = p->push(BX_PLAN_SEGMENT, 0, {}, {});
-    p->merge(p->peaks, n, true);
-    if (task_number) *task_number = n;
-    return nullptr;
+    try {
+        if (!p) return "bx_planner: NULL planner";
+        if (p->finished) return p->fail("Cannot add segment to finished plan");  // PlannerErr::PlanFinalized
+        uint64_t n = p->push(BX_PLAN_SEGMENT, 0, {}, {});
+        p->merge(p->peaks, n, true);
+        if (task_number) *task_number = n;
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_planner_enqueue_segment: out of memory";
+    }
 }
 
 const char* bx_planner_enqueue_keccak(bx_planner* p, uint64_t* task_number) {
-    if (!p) return "bx_planner: NULL planner";
-    if (p->finished) return p->fail("Cannot add segment to finished plan");
-    uint64_t n = p->push(BX_PLAN_KECCAK, 0, {}, {});
-    p->merge(p->keccak_peaks, n, false);
-    if (task_number) *task_number = n;
-    return nullptr;
+    try {
+        if (!p) return "bx_planner: NULL planner";
+        if (p->finished) return p->fail("Cannot add segment to finished plan");
+        uint64_t n = p->push(BX_PLAN_KECCAK, 0, {}, {});
+        p->merge(p->keccak_peaks, n, false);
+        if (task_number) *task_number = n;
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_planner_enqueue_keccak: out of memory";
+    }
 }
 
 const char* bx_planner_finish(bx_planner* p, uint64_t* task_number) {
-    if (!p) return "bx_planner: NULL planner";
-    if (p->peaks.empty()) return p->fail("Planning not yet started");  // PlannerErr::PlanNotStartedString
-    if (!p->finished) {
-        std::vector<uint64_t> kdeps;
-        if (!p->keccak_peaks.empty()) {
-            while (p->keccak_peaks.size() >= 2) {  // unions: oldest pair first
-                uint64_t p0 = p->keccak_peaks.front();
-                p->keccak_peaks.pop_front();
-                uint64_t p1 = p->keccak_peaks.front();
-                p->keccak_peaks.pop_front();
-                uint32_t h = 1 + std::max(p->height(p0), p->height(p1));
-                p->keccak_peaks.push_front(p->push(BX_PLAN_UNION, h, {}, {p1, p0}));
+    try {
+        if (!p) return "bx_planner: NULL planner";
+        if (p->peaks.empty()) return p->fail("Planning not yet started");  // PlannerErr::PlanNotStartedString
+        if (!p->finished) {
+            std::vector<uint64_t> kdeps;
+            if (!p->keccak_peaks.empty()) {
+                while (p->keccak_peaks.size() >= 2) {  // unions: oldest pair first
+                    uint64_t p0 = p->keccak_peaks.front();
+                    p->keccak_peaks.pop_front();
+                    uint64_t p1 = p->keccak_peaks.front();
+                    p->keccak_peaks.pop_front();
+                    uint32_t h = 1 + std::max(p->height(p0), p->height(p1));
+                    p->keccak_peaks.push_front(p->push(BX_PLAN_UNION, h, {}, {p1, p0}));
+                }
+                kdeps.push_back(p->keccak_peaks.front());
             }
-            kdeps.push_back(p->keccak_peaks.front());
+            while (p->peaks.size() >= 2) {  // joins: smallest pair first
+                uint64_t p0 = p->peaks.back();
+                p->peaks.pop_back();
+                uint64_t p1 = p->peaks.back();
+                p->peaks.pop_back();
+                uint32_t h = 1 + std::max(p->height(p0), p->height(p1));
+                p->peaks.push_back(p->push(BX_PLAN_JOIN, h, {p1, p0}, {}));
+            }
+            uint32_t h = 1 + p->height(p->peaks.front());
+            if (!kdeps.empty()) h = std::max(h, 1 + p->height(kdeps[0]));
+            p->last = p->push(BX_PLAN_FINALIZE, h, {p->peaks.front()}, kdeps);
+            p->finished = true;
         }
-        while (p->peaks.size() >= 2) {  // joins: smallest pair first
-            uint64_t p0 = p->peaks.back();
-            p->peaks.pop_back();
-            uint64_t p1 = p->peaks.back();
-            p->peaks.pop_back();
-            uint32_t h = 1 + std::max(p->height(p0), p->height(p1));
-            p->peaks.push_back(p->push(BX_PLAN_JOIN, h, {p1, p0}, {}));
-        }
-        uint32_t h = 1 + p->height(p->peaks.front());
-        if (!kdeps.empty()) h = std::max(h, 1 + p->height(kdeps[0]));
-        p->last = p->push(BX_PLAN_FINALIZE, h, {p->peaks.front()}, kdeps);
-        p->finished = true;
+        if (task_number) *task_number = p->last;
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_planner_finish: out of memory";
     }
-    if (task_number) *task_number = p->last;
-    return nullptr;
 }
 
 const char* bx_planner_next_task(bx_planner* p, bx_plan_task* out, int* has) {

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         __syncthreads();
     }
     if (tid == 0) {
-        const uint64_t ex = brev_log ? (uint64_t)(__brev(seg) >> (32 - (brev_log - 15))) * (brev_log > 15) : (uint64_t)base;
+        // bit-reversed storage: the segment's exponent is rev(seg) over the brev_log - 15 segment bits (none at 2^15)
+        const uint64_t ex = brev_log ? (brev_log > 15 ? (uint64_t)(__brev(seg) >> (32 - (brev_log - 15))) : 0ull) : (uint64_t)base;
         st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(xpow), f4_pow(x0, ex)));
     }
 }

@@ -240,6 +240,9 @@ using namespace bx;
 extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213, const uint32_t* diag24) {
     if (!c) return "bx_poseidon2_set_params: null ctx";
     BX_REQUIRE(c, rc213 && diag24, "poseidon2_set_params: null table");
+    // a prover snapshots the table for its host transcript at create time and bx_verify_segment uses the compiled-in one:
+    // changing the device table under a live prover would make its trees and its transcript disagree
+    BX_REQUIRE(c, c->live_provers == 0, "poseidon2_set_params: destroy the provers of this ctx first (their transcripts hold the old table)");
     BX_HIP(c, hipSetDevice(c->device));
     for (int i = 0; i < 213; ++i) c->h_rc[i] = rc213[i] % P;
     for (int i = 0; i < 24; ++i) c->h_diag[i] = diag24[i] % P;

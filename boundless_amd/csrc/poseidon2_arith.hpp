@@ -77,8 +77,8 @@ constexpr i64 SREDC_MAX = ((i64)0x7fffffff - (i64)(P / 2) - 2) * ((i64)1 << 32);
 // multiply-add costs ~18 % at the kernel's 3 waves per SIMD (profiles/r01_microbench3_mad_forms.jsonl).  Rotating the pair
 // and keeping dependent statements a stage apart removes most of them (467 -> 198 in hash_fold); the rest are spread thinly
 // enough that removing them is below measurement noise.
-// The host versions are the definitions.
-#if defined(__HIP_DEVICE_COMPILE__)
+// The host versions are the definitions; a translation unit may define BX_PLAIN_MAD to get them on the device too (circuit.hip).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
 #define BX_MAD_ASM(op, args, ...)                                                                  \
     do {                                                                                           \
         switch (alt & 3) {                                                                         \
@@ -90,7 +90,7 @@ constexpr i64 SREDC_MAX = ((i64)0x7fffffff - (i64)(P / 2) - 2) * ((i64)1 << 32);
     } while (0)
 #endif
 BX_HD i64 smad(i32 a, i32 b, i64 c, int alt = 0) {  // a*b + c, all signed
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %2, %3", "v"(a), "v"(b), "v"(c));
     return r;
@@ -100,7 +100,7 @@ BX_HD i64 smad(i32 a, i32 b, i64 c, int alt = 0) {  // a*b + c, all signed
 #endif
 }
 BX_HD i64 smul(i32 a, i32 b, int alt = 0) {  // a*b
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "v"(b));
     return r;
@@ -110,7 +110,7 @@ BX_HD i64 smul(i32 a, i32 b, int alt = 0) {  // a*b
 #endif
 }
 BX_HD i64 smad_k(i32 a, uint32_t k, i64 c, int alt = 0) {  // a*k + c, k a wave-uniform constant < 2^31 (scalar operand)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %2, %3", "v"(a), "s"(k), "v"(c));
     return r;
@@ -120,7 +120,7 @@ BX_HD i64 smad_k(i32 a, uint32_t k, i64 c, int alt = 0) {  // a*k + c, k a wave-
 #endif
 }
 BX_HD i64 smul_k(i32 a, uint32_t k, int alt = 0) {  // a*k
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "s"(k));
     return r;
@@ -131,7 +131,7 @@ BX_HD i64 smul_k(i32 a, uint32_t k, int alt = 0) {  // a*k
 }
 template <int K>
 BX_HD i64 smadc(i32 a, i64 c, int alt = 0) {  // a*K + c, K an inline constant
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %3, %2", "v"(a), "v"(c), "n"(K));
     return r;
@@ -142,7 +142,7 @@ BX_HD i64 smadc(i32 a, i64 c, int alt = 0) {  // a*K + c, K an inline constant
 }
 template <int K>
 BX_HD i64 smulc(i32 a, int alt = 0) {  // a*K
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_i64_i32", "%1, %2, 0", "v"(a), "n"(K));
     return r;
@@ -152,7 +152,7 @@ BX_HD i64 smulc(i32 a, int alt = 0) {  // a*K
 #endif
 }
 BX_HD i64 add_u32(i64 c, uint32_t k, int alt = 0) {  // c + k, k an unsigned wave-uniform word (round constant)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_u64_u32", "%1, 1, %2", "s"(k), "v"(c));
     return r;
@@ -162,7 +162,7 @@ BX_HD i64 add_u32(i64 c, uint32_t k, int alt = 0) {  // c + k, k an unsigned wav
 #endif
 }
 BX_HD i64 umul_k(uint32_t a, uint32_t k, int alt = 0) {  // a*k, both unsigned
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i64 r;
     BX_MAD_ASM("v_mad_u64_u32", "%1, %2, 0", "v"(a), "s"(k));
     return r;
@@ -172,7 +172,7 @@ BX_HD i64 umul_k(uint32_t a, uint32_t k, int alt = 0) {  // a*k, both unsigned
 #endif
 }
 BX_HD i32 mont_m(i64 t) {  // m = -t * P^-1 mod 2^32 as a signed word (pinned so that a stage's 24 low products stay together)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BX_PLAIN_MAD)
     i32 m;
     asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"((uint32_t)t), "s"(NEG_P_INV));
     return m;

@@ -293,6 +293,7 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     p->seal_bound = bound;
     memset(p->last_roots, 0, sizeof p->last_roots);
     BX_TRY(bx_sync(c));
+    c->live_provers += 1;
     *out = p.release();
     return nullptr;
 }
@@ -301,6 +302,7 @@ extern "C" const char* bx_prover_destroy(bx_prover* p) {
     if (!p) return nullptr;
     (void)hipSetDevice(p->c->device);
     (void)hipStreamSynchronize(p->c->stream);
+    p->c->live_provers -= 1;
     delete p;
     return nullptr;
 }

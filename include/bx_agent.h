@@ -19,10 +19,11 @@
  * ships in-memory implementations of both for tests, the bench's queue mode and single-box runs.
  *
  * The agent owns the device context(s) for the process lifetime, like `Agent.prover` (lib.rs:192,241-252).  Unlike the
- * reference (one task in flight per process, several agent processes per GPU to overlap), one bx_agent runs
- * `inflight` prover lanes on its GPU — each lane a host thread with its own bx_ctx/stream/prover claiming tasks
- * independently — because the segment prover is VALU-issue-bound with latency-bound tails and 3 lanes fill the chip
- * (DESIGN.md §5).  Every callback may therefore be invoked from several threads at once and must be thread-safe.
+ * reference (one task in flight per process, one agent process per GPU), one bx_agent runs `inflight` prover lanes on
+ * each of its GPUs — each lane a host thread with its own bx_ctx/stream/prover claiming tasks independently — because the
+ * segment prover is VALU-issue-bound with latency-bound tails and 3 lanes fill a chip; with
+ * `n_devices` > 1 the lanes of all GPUs of the node claim from the same task db, which is BASELINE configs[2]'s
+ * "batch work-stolen across 8 GPUs" in native code.  Every callback may be invoked from several threads at once.
  *
  * Conventions as in bx_hal.h: every call returns NULL on success or a message owned by the object it was called on
  * (valid until the next call on that object from the same thread); nothing aborts, no exception crosses the ABI.
@@ -121,11 +122,23 @@ const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const 
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
 
 /* ---------------------------------------------------------------------------------- segment / receipt wire ---- */
-/* Stand-ins for bincode(risc0_zkvm::Segment) / bincode(receipt) (tasks/mod.rs:40-47), which need risc0's type layouts:
- *   segment  = index u64 | po2 u32 | seed u64                      (20 bytes, little endian)
- *   receipt  = index u64 | po2 u32 | seal_words u32 | seal u32[]   (16 + 4*n bytes, little endian) */
-#define BX_SEGMENT_WIRE_BYTES 20
-#define BX_RECEIPT_HEADER_BYTES 16
+/* The reference moves bincode(risc0_zkvm::Segment) in and bincode(receipt) out (tasks/mod.rs:40-47); both need risc0's type
+ * layouts and a real circuit.  Two modes, chosen by the prover table:
+ *   opaque     ops->prove_blob != NULL: the agent hands the stored bytes to the prover untouched and stores what it
+ *              returns under the reference's key  job:{id}:recursion_receipts:{task}  (tasks/mod.rs:23).  This is the
+ *              drop-in path for a real prover.
+ *   synthetic  otherwise (the built-in HIP prover, or an injected prove_segment): blobs are the tagged stand-ins below and
+ *              the seal goes to  job:{id}:synthetic_receipts:{task}  — a different key on purpose, so that a Join worker
+ *              of a real cluster can never pick a synthetic seal up as a lifted SuccinctReceipt.  Needs cfg.synthetic = 1.
+ *   segment  = "BXSYNSEG" | index u64 | po2 u32 | seed u64                      (28 bytes, little endian)
+ *   receipt  = "BXSYNRCP" | index u64 | po2 u32 | seal_words u32 | seal u32[]   (24 + 4*n bytes, little endian)
+ * A blob without the tag (e.g. a real bincode Segment) fails the task with a message naming the mismatch. */
+#define BX_SEGMENT_WIRE_BYTES 28
+#define BX_RECEIPT_HEADER_BYTES 24
+#define BX_SEGMENT_MAGIC "BXSYNSEG"
+#define BX_RECEIPT_MAGIC "BXSYNRCP"
+#define BX_SYNTHETIC_RECEIPT_PATH "synthetic_receipts"
+#define BX_RECUR_RECEIPT_PATH "recursion_receipts"
 void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]);
 /* error: "Failed to deserialize segment data from redis" */
 const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed);
@@ -138,6 +151,11 @@ typedef struct bx_segment_prover_ops {
     size_t (*seal_words)(void* user, uint32_t lane, uint32_t po2); /* seal capacity in words, 0 = unsupported shape */
     const char* (*prove_segment)(void* user, uint32_t lane, uint64_t index, uint32_t po2, uint64_t seed, uint32_t* seal_out,
                                  size_t seal_cap, size_t* seal_words);
+    /* Opaque mode (optional, may be NULL): everything tasks::prove::prover does between the GET and the SETEX
+     * (prove.rs:36-109: deserialize, prove_segment, verify, lift, verify, serialize) on the raw stored bytes.  *receipt is
+     * owned by the prover until free_blob.  When set, seal_words / prove_segment are not used. */
+    const char* (*prove_blob)(void* user, uint32_t lane, const uint8_t* segment, size_t len, uint8_t** receipt, size_t* receipt_len);
+    void (*free_blob)(void* user, uint8_t* receipt);
 } bx_segment_prover_ops;
 
 typedef struct bx_agent_config {
@@ -148,6 +166,17 @@ typedef struct bx_agent_config {
     double poll_time;        /* idle sleep between empty claims, seconds; <= 0 = 1 s (`poll_time`) */
     int32_t no_verify;       /* 0 = verify each seal before storing it, as the reference does (prove.rs:53-55); 1 = skip */
     char task_stream[64];    /* worker type passed to request_work; "" = "prove" */
+    /* ---- one agent, several GPUs: n_devices * inflight lanes claim from the ONE task db (request_work is the work-stealing
+     * queue, 9_request_work.sql:126-153); 0 = the single `device` above.  The reference starts one process per GPU
+     * (compose.yml:113); here the lanes of all devices live in one process and share nothing but the two callback tables. */
+    uint32_t n_devices;
+    int32_t devices[16];
+    int32_t synthetic;       /* 1 = accept the synthetic wire format and write synthetic_receipts (see above); without it an
+                              * agent whose prover table has no prove_blob refuses to start */
+    uint32_t cons_terms, cons_degree; /* the synthetic circuit's knobs for the built-in prover (0 = defaults) */
+    uint32_t po2_min, po2_max;        /* segment sizes the built-in prover accepts; 0 = 9 / 22.  Others fail the task */
+    uint32_t max_shapes;     /* buffer sets (one per segment size, several GB at po2 20) cached per lane, least recently used
+                              * evicted; 0 = 2 */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;
@@ -165,6 +194,11 @@ const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok
 /* Prometheus text exposition of task_operations_total, task_duration_seconds, redis_operations_total and
  * redis_operation_duration_seconds with the reference's labels and buckets; returns the needed size. */
 size_t bx_agent_metrics(bx_agent* a, char* out, size_t cap);
+/* Lanes of the agent (n_devices * inflight; lane l belongs to devices[l / inflight]), the device of a lane (informational
+ * with an injected prover, which receives the lane index) and how many tasks the lane completed. */
+uint32_t bx_agent_lane_count(const bx_agent* a);
+int32_t bx_agent_lane_device(const bx_agent* a, uint32_t lane);
+uint64_t bx_agent_lane_tasks_done(const bx_agent* a, uint32_t lane);
 
 #ifdef __cplusplus
 }

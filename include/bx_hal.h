@@ -86,7 +86,9 @@ const char* bx_zk_shift(bx_ctx* ctx, bx_buf io, size_t count);
 /* ---- Hal hash family (Poseidon2 suite: BabyBear t=24, rate 16, 8+21 rounds, x^7) ---- */
 /* Replace the permutation parameters (canonical, non-Montgomery integers): 213 round constants laid out as
  * 4x24 external | 21 internal | 4x24 external, and the 24-entry internal diagonal (matrix = 1*1^T + diag).
- * The library default is the published BabyBear t=24 instance used by the reference's `poseidon2` hashfn. */
+ * The library default is the published BabyBear t=24 instance used by the reference's `poseidon2` hashfn.
+ * Refused while a bx_prover exists on the ctx (its host transcript holds the table it was created with), and seals made
+ * under a non-default table are not accepted by bx_verify_segment, which uses the default. */
 const char* bx_poseidon2_set_params(bx_ctx* ctx, const uint32_t* rc213, const uint32_t* diag24);
 const char* bx_poseidon2_get_params(bx_ctx* ctx, uint32_t* rc213, uint32_t* diag24);
 /* Hal::hash_rows(output, matrix): out_digests.len/8 rows; cols = matrix.len/rows. */

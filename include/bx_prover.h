@@ -69,8 +69,8 @@ typedef struct bx_segment_params {
     uint32_t cons_terms;  /* T: product terms per derived-column constraint; 0 = BX_CIRCUIT_DEFAULT_TERMS */
     uint32_t cons_degree; /* G: factors per term (multiplicative degree), 1..5; 0 = BX_CIRCUIT_DEFAULT_DEGREE */
 } bx_segment_params;
-#define BX_CIRCUIT_DEFAULT_TERMS 16
-#define BX_CIRCUIT_DEFAULT_DEGREE 3
+#define BX_CIRCUIT_DEFAULT_TERMS 64
+#define BX_CIRCUIT_DEFAULT_DEGREE 4
 #define BX_CIRCUIT_MAX_TERMS 64
 #define BX_CIRCUIT_MAX_DEGREE 5
 #define BX_SEAL_HEADER_WORDS 6 /* po2, w_code, w_data, w_accum, T, G */

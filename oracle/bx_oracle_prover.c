@@ -94,8 +94,8 @@ static uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
 }
 
 /* ---- the synthetic circuit (include/bx_prover.h, "The synthetic circuit") ---- */
-#define DEFAULT_TERMS 16
-#define DEFAULT_DEGREE 3
+#define DEFAULT_TERMS 64
+#define DEFAULT_DEGREE 4
 #define POOL 7
 typedef struct {
     uint32_t po2, wc, wd, wa, T, G;

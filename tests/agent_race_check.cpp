@@ -1,11 +1,15 @@
 // Race / leak check of the native feed loop (boundless_amd/csrc/agent.cpp): built by tests/test_agent_sanitizers_cpu.py with
 // -fsanitize=thread (and again with address,undefined) from agent.cpp + planner.cpp + this file, no GPU and no HIP runtime.
-// 6 lanes x 2 threads each hammer the in-memory hot store / task db with a prover that fails at random; every task must end
-// `done` exactly once or `failed` after its retries, and the sanitizer must stay silent.
+// 3 "devices" x 2 lanes x 2 threads each hammer the ONE in-memory hot store / task db with a prover that fails at random;
+// every task must end `done` exactly once or `failed` after its retries, and the sanitizer must stay silent.  The lanes of
+// device 1 are ten times slower: since every lane claims when idle from the shared task db (the work-stealing queue of
+// BASELINE configs[2], in native code), they end up with a small share of the batch and nobody waits for them.
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 
 #include "bx_agent.h"
 
@@ -26,6 +30,7 @@ static size_t seal_words(void*, uint32_t, uint32_t) { return 64; }
 static const char* prove(void*, uint32_t lane, uint64_t index, uint32_t, uint64_t seed, uint32_t* seal, size_t cap, size_t* words) {
     uint64_t n = g_calls.fetch_add(1);
     if (cap < 64) return "cap";
+    std::this_thread::sleep_for(std::chrono::microseconds(lane / 2 == 1 ? 5000 : 100));  // device 1 is the slow GPU
     if ((n * 2654435761u >> 7) % 5 == 0) return "hipErrorLaunchFailure (injected)";
     for (uint32_t i = 0; i < 64; ++i) seal[i] = (uint32_t)(seed + index + i + lane * 0);
     seal[0] = ((n >> 3) % 7 == 0) ? 9u : 7u;  // some seals fail verification -> retried from the finisher thread
@@ -50,9 +55,19 @@ int main() {
     }
     bx_agent_config cfg;
     memset(&cfg, 0, sizeof cfg);
-    cfg.inflight = 6;
+    cfg.inflight = 2;
+    cfg.n_devices = 3;
+    cfg.devices[0] = 0, cfg.devices[1] = 1, cfg.devices[2] = 2;
+    cfg.synthetic = 1;
     cfg.poll_time = 0.001;
-    bx_segment_prover_ops pops{nullptr, seal_words, prove};
+    bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};
+    {   // without the opt-in the synthetic wire format is refused
+        bx_agent_config off = cfg;
+        off.synthetic = 0;
+        bx_agent* none = nullptr;
+        const char* e = bx_agent_create(&off, &sops, &tops, &pops, &none);
+        if (!e || !strstr(e, "synthetic")) return 1;
+    }
     bx_agent* agent = nullptr;
     if (const char* e = bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) {
         fprintf(stderr, "create: %s\n", e);
@@ -67,6 +82,18 @@ int main() {
     size_t n_other = bx_mem_taskdb_count(db, BX_TASK_READY) + bx_mem_taskdb_count(db, BX_TASK_RUNNING);
     char metrics[1 << 15];
     bx_agent_metrics(agent, metrics, sizeof metrics);
+    uint64_t per_dev[3] = {0, 0, 0}, lane_sum = 0;
+    if (bx_agent_lane_count(agent) != 6) return 1;
+    for (uint32_t l = 0; l < 6; ++l) {
+        if (bx_agent_lane_device(agent, l) != (int32_t)(l / 2)) return 1;
+        per_dev[l / 2] += bx_agent_lane_tasks_done(agent, l);
+        lane_sum += bx_agent_lane_tasks_done(agent, l);
+    }
+    if (lane_sum != done || per_dev[1] * 2 > per_dev[0] || per_dev[1] * 2 > per_dev[2] || per_dev[1] == 0) {
+        fprintf(stderr, "work stealing: per device %llu %llu %llu of %llu\n", (unsigned long long)per_dev[0], (unsigned long long)per_dev[1],
+                (unsigned long long)per_dev[2], (unsigned long long)done);
+        return 1;
+    }
     if (bx_agent_destroy(agent)) return 1;
     // every stored receipt has its segment unlinked; failed tasks keep (or never had) their segment blob
     size_t keys = bx_mem_store_key_count(store);
@@ -77,7 +104,7 @@ int main() {
         return 1;
     }
     if (!strstr(metrics, "task_operations_total{task_name=\"prove\",operation_type=\"complete\",status=\"success\"}")) return 1;
-    printf("agent_race_check ok: done %zu failed %zu prove calls %llu keys %zu\n", n_done, n_failed,
-           (unsigned long long)g_calls.load(), keys);
+    printf("agent_race_check ok: done %zu failed %zu prove calls %llu keys %zu, per device %llu/%llu/%llu\n", n_done, n_failed,
+           (unsigned long long)g_calls.load(), keys, (unsigned long long)per_dev[0], (unsigned long long)per_dev[1], (unsigned long long)per_dev[2]);
     return 0;
 }

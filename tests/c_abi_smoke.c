@@ -81,6 +81,7 @@ int main(void) {
     cfg.inflight = 2;
     cfg.w_code = 4, cfg.w_data = 8, cfg.w_accum = 4;
     cfg.poll_time = 0.01;
+    cfg.synthetic = 1; /* the built-in prover proves the synthetic circuit and says so in its key names */
     bx_agent* agent = NULL;
     CHECK(bx_agent_create(&cfg, &sops, &tops, NULL, &agent));
     uint64_t done = 0;

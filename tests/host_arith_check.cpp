@@ -9,6 +9,7 @@
 
 #include "fp.hpp"
 #include "poseidon2_arith.hpp"
+#include "circuit_dev.hpp"
 #include "poseidon2_params.hpp"
 #include "transcript.hpp"
 
@@ -32,7 +33,31 @@ static uint32_t redc_exact(u128 v) { return (uint32_t)((v % P) * RINV % P); }
         }                                                                 \
     } while (0)
 
+// the circuit's cell value sum_t prod_f pool[idx(t,f)] through the signed three-level form (every sredc operand is asserted
+// against SREDC_MAX by BX_CHECK_BOUNDS) against the plain canonical loop, pools drawn from the extreme words and at random
+template <int TT, int GG>
+static int check_cons_sum() {
+    const uint32_t edge[] = {0, 1, P - 1, P / 2, P / 2 + 1, P / 2 - 1, MONT_ONE, P - MONT_ONE};
+    uint32_t pool[Circuit::POOL];
+    for (int iter = 0; iter < 60000; ++iter) {
+        for (unsigned i = 0; i < Circuit::POOL; ++i) {
+            const uint64_t r = rnd64();
+            // a third of the pools all-extreme (worst magnitudes: +-P/2 everywhere), a third mixed, a third random
+            pool[i] = iter % 3 == 0 ? edge[3 + r % 3] : iter % 3 == 1 ? ((r & 1) ? edge[(r >> 8) % 8] : (uint32_t)((r >> 8) % P)) : (uint32_t)((r >> 8) % P);
+        }
+        const uint32_t want = cons_sum<0, 0>(pool, TT, GG), got = cons_sum<TT, GG>(pool, TT, GG);
+        if (got != want || got >= P) {
+            fprintf(stderr, "cons_sum<%d,%d> mismatch: got %u want %u\n", TT, GG, got, want);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int main() {
+    if (check_cons_sum<64, 4>() || check_cons_sum<48, 3>() || check_cons_sum<16, 3>() || check_cons_sum<32, 3>() || check_cons_sum<8, 2>() || check_cons_sum<5, 1>() ||
+        check_cons_sum<7, 4>() || check_cons_sum<64, 5>() || check_cons_sum<1, 1>() || check_cons_sum<25, 2>())
+        return 1;
     REQUIRE((u128)RINV * ((u128)1 << 32) % P == 1);
     // ---- canonical field ops at the edges and at random ----
     const uint32_t edge[] = {0, 1, 2, P - 1, P - 2, (P - 1) / 2, MONT_ONE, R2, R3, 0x7fffffffu % P};

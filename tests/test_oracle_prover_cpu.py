@@ -10,7 +10,7 @@ def test_oracle_prover_runs_and_is_deterministic():
     c, _ = ol.prove_segment(10, 4, 8, 4, 1235)
     assert np.array_equal(a, b) and np.array_equal(ra, rb)
     assert not np.array_equal(a, c)
-    assert a[:6].tolist() == [10, 4, 8, 4, 16, 3]  # po2, widths, the circuit's default knobs (terms, degree)
+    assert a[:6].tolist() == [10, 4, 8, 4, 64, 4]  # po2, widths, the circuit's default knobs (terms, degree)
     # layout: header 6 | 4 trace tops (32 digests each) | coeff_u | fri tops | final coeffs | 50 queries
     n = 1 << 10
     taps = 4 + (8 + 2) + (4 + 4) + 16  # data columns 0 and 4 and the accumulator's four columns are also opened one row back
@@ -31,7 +31,7 @@ def test_oracle_prover_threads_do_not_change_the_seal():
 
 def test_circuit_knobs_change_the_seal_and_are_part_of_the_header():
     a, _ = ol.prove_segment(10, 4, 8, 4, 7)
-    b, _ = ol.prove_segment(10, 4, 8, 4, 7, terms=16, degree=3)  # the defaults, spelled out
+    b, _ = ol.prove_segment(10, 4, 8, 4, 7, terms=64, degree=4)  # the defaults, spelled out
     c, _ = ol.prove_segment(10, 4, 8, 4, 7, terms=5, degree=4)
     assert np.array_equal(a, b)
     assert c[:6].tolist() == [10, 4, 8, 4, 5, 4] and not np.array_equal(a[6:], c[6:])

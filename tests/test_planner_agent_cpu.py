@@ -4,6 +4,8 @@ import json
 import numpy as np
 import pytest
 
+from boundless_amd.hal import HalError
+
 from boundless_amd import agent as ag
 from boundless_amd import planner as pl
 from boundless_amd.prover import Segment, SegmentReceipt
@@ -117,9 +119,11 @@ class FakeProver:
 def test_task_json_and_wire_roundtrip():
     seg = Segment.synthetic(5, po2=20)
     blob = ag.serialize_segment(seg)
-    assert len(blob) == 20 and ag.deserialize_segment(blob) == seg
+    assert len(blob) == 28 and blob[:8] == b"BXSYNSEG" and ag.deserialize_segment(blob) == seg
     with pytest.raises(ValueError, match="Failed to deserialize segment data from redis"):
         ag.deserialize_segment(blob[:-1])
+    with pytest.raises(ValueError, match="not a synthetic segment blob"):  # e.g. a real bincode(Segment): refused loudly
+        ag.deserialize_segment(b"\x00" * 28)
     a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
     # serde's externally tagged TaskType (workflow-common/src/lib.rs:160-178): anything but one known variant is invalid
     for bad in ('{"Prove":{"idx":7}}', '{"Prove":{"index":-1}}', '{"Prove":{"index":1.5}}', '[]', '{"Prove":{"index":1},"x":{}}',
@@ -137,8 +141,9 @@ def test_prove_task_key_scheme_cleanup_and_metrics():
     a.store.set_key_with_expiry(f"job:{job}:segments:3", ag.serialize_segment(Segment.synthetic(3, po2=12)), 60)
     a.taskdb.create_task(job, "task-3", {"Prove": {"index": 3}})
     assert a.poll_work(max_idle_polls=1) == 1
-    assert a.store.keys() == [f"job:{job}:recursion_receipts:task-3"]  # receipt stored, segment unlinked
-    rec = ag.deserialize_receipt(a.store.get(f"job:{job}:recursion_receipts:task-3"))
+    # receipt stored, segment unlinked.  A synthetic seal never goes under the key Join workers read (recursion_receipts)
+    assert a.store.keys() == [f"job:{job}:synthetic_receipts:task-3"]
+    rec = ag.deserialize_receipt(a.store.get(f"job:{job}:synthetic_receipts:task-3"))
     assert rec.index == 3 and rec.po2 == 12 and np.array_equal(rec.seal, np.arange(10, dtype=np.uint32) + Segment.synthetic(3).seed % 7)
     row = a.taskdb.task(job, "task-3")
     assert (row.state, row.retries, row.output) == ("done", 0, "null")
@@ -258,5 +263,65 @@ def test_hot_store_expiry_and_several_lanes():
         a.taskdb.create_task("m", f"p{i}", {"Prove": {"index": i}})
     assert a.poll_work(max_idle_polls=2) == 32
     assert a.taskdb.count("done") == 32 and p.calls == 32
-    assert a.store.keys() == sorted(f"job:m:recursion_receipts:p{i}" for i in range(32))
+    assert a.store.keys() == sorted(f"job:m:synthetic_receipts:p{i}" for i in range(32))
+    assert sum(n for _, n in a.lane_stats()) == 32 and len(a.lane_stats()) == 4
+    a.close()
+
+
+def test_the_synthetic_prover_is_opt_in_and_a_real_prover_gets_the_reference_keys():
+    """Round-1 advisor finding: nothing stopped the agent from being pointed at a real `prove` stream.  Now the synthetic wire
+    format needs cfg.synthetic, non-synthetic blobs fail loudly, and only an opaque prover (bytes in, bytes out: what a real
+    `impl ProverServer` shim provides) writes job:{id}:recursion_receipts:{task} (tasks/mod.rs:23)."""
+    with pytest.raises(HalError, match="synthetic"):
+        ag.Agent(prover=FakeProver(), synthetic=False)
+    # a blob that is not a synthetic segment (here: what a real executor would have stored) fails the task, names the reason
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
+    a.store.set_key_with_expiry("job:j:segments:0", b"\x01\x02" * 40000)
+    a.taskdb.create_task("j", "t", {"Prove": {"index": 0}}, max_retries=0)
+    assert a.poll_work(max_idle_polls=1) == 0
+    assert "not a synthetic segment blob" in a.taskdb.task("j", "t").error
+    assert a.store.keys() == ["job:j:segments:0"]
+    a.close()
+    # opaque mode: the stored bytes go to the prover untouched, its bytes are stored under the reference's key
+    seen = []
+
+    def real_prover(blob):
+        seen.append(blob)
+        return b"lifted:" + blob[::-1]
+
+    b = ag.Agent(blob_prover=real_prover, synthetic=False, poll_time=0.01, inflight=2)
+    for i in range(5):
+        b.store.set_key_with_expiry(f"job:r:segments:{i}", bytes([i]) * (1000 + i))
+        b.taskdb.create_task("r", f"p{i}", {"Prove": {"index": i}})
+    assert b.poll_work(max_idle_polls=2) == 5
+    assert b.store.keys() == [f"job:r:recursion_receipts:p{i}" for i in range(5)]
+    assert b.store.get("job:r:recursion_receipts:p3") == b"lifted:" + bytes([3]) * 1003
+    assert sorted(seen) == sorted(bytes([i]) * (1000 + i) for i in range(5))
+    b.close()
+
+
+def test_one_agent_several_devices_share_one_queue():
+    """bx_agent_config.n_devices: lanes of every GPU of the node claim from the same task db (BASELINE configs[2] in native
+    code; the reference runs one agent process per GPU against one Postgres queue, compose.yml:113)."""
+    import time
+
+    class Slow:
+        def __init__(self):
+            self.calls = 0
+
+        def prove_segment(self, seg):
+            self.calls += 1
+            time.sleep(0.002)
+            return SegmentReceipt(seal=np.arange(4, dtype=np.uint32), index=seg.index, po2=seg.po2)
+
+    a = ag.Agent(prover=Slow(), verify=False, poll_time=0.005, inflight=2, devices=[0, 1, 2, 3])
+    for i in range(64):
+        a.store.set_key_with_expiry(f"job:b:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=10)))
+        a.taskdb.create_task("b", f"p{i}", {"Prove": {"index": i}})
+    assert a.poll_work(max_idle_polls=3) == 64
+    stats = a.lane_stats()
+    assert [d for d, _ in stats] == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert sum(n for _, n in stats) == 64 and a.taskdb.count("done") == 64
+    per_dev = [sum(n for d, n in stats if d == k) for k in range(4)]
+    assert all(n > 0 for n in per_dev), per_dev  # every device's lanes got work from the one queue
     a.close()

@@ -108,9 +108,9 @@ def test_agent_feed_loop_with_the_hip_prover():
             a.store.set_key_with_expiry(f"job:J:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=12)), 600)
             a.taskdb.create_task("J", f"prove-{i}", {"Prove": {"index": i}})
         assert a.poll_work(max_idle_polls=2) == n
-        assert a.store.keys() == [f"job:J:recursion_receipts:prove-{i}" for i in range(n)]
+        assert a.store.keys() == [f"job:J:synthetic_receipts:prove-{i}" for i in range(n)]
         for i in range(n):
-            rec = ag.deserialize_receipt(a.store.get(f"job:J:recursion_receipts:prove-{i}"))
+            rec = ag.deserialize_receipt(a.store.get(f"job:J:synthetic_receipts:prove-{i}"))
             assert rec.index == i and rec.po2 == 12
             verify_seal(rec.seal)
             want, _ = ol.prove_segment(12, 4, 12, 4, Segment.synthetic(i, po2=12).seed)
@@ -121,7 +121,7 @@ def test_agent_feed_loop_with_the_hip_prover():
         a.store.set_key_with_expiry("job:K:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=10)), 600)
         a.taskdb.create_task("K", "p", {"Prove": {"index": 0}})
         assert a.poll_work(max_idle_polls=2) == 1
-        rec = ag.deserialize_receipt(a.store.get("job:K:recursion_receipts:p"))
+        rec = ag.deserialize_receipt(a.store.get("job:K:synthetic_receipts:p"))
         want, _ = ol.prove_segment(10, 4, 12, 4, Segment.synthetic(0, po2=10).seed)
         assert np.array_equal(rec.seal, want)
     finally:

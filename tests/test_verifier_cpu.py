@@ -76,7 +76,7 @@ def test_a_seal_of_a_different_circuit_is_rejected():
     seal, _ = ol.prove_segment(10, 4, 8, 4, 1234, terms=5, degree=4)
     verify_seal(seal)
     bad = seal.copy()
-    bad[4], bad[5] = 16, 3
+    bad[4], bad[5] = 64, 4
     with pytest.raises(HalError):
         verify_seal(bad)
     for hdr in ((0, 3), (65, 3), (16, 6), (16, 0)):
