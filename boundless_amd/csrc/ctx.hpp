@@ -77,6 +77,7 @@ struct bx_ctx {
     long ntt_tile_a_log = 12;  // log2 elements per pass-A workgroup (fast path)
     long ntt_tile_b_log = 13;  // log2 elements per pass-B workgroup (fast path)
     long ntt_cols_per_wg = 8;  // forward pass A (2^12 tiles): columns sharing one load of the tile's twist + twiddles
+    long ntt_group_cols = 0;   // forward transform: columns per pass-A + pass-B group (0 = all columns per pass)
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
     long hash_rows_block = 256;
     long fold_fuse_below = 1 << 15;  // Merkle layers with at most this many inputs are folded 9 levels per launch

@@ -268,6 +268,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
     } else if (!strcmp(name, "ntt_cols_per_wg")) {
         BX_REQUIRE(c, value >= 1 && value <= 16, "ntt_cols_per_wg out of range [1,16]");
         c->ntt_cols_per_wg = value;
+    } else if (!strcmp(name, "ntt_group_cols")) {
+        BX_REQUIRE(c, value >= 0 && value <= 4096, "ntt_group_cols out of range [0,4096]");
+        c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
     } else if (!strcmp(name, "deep_bitrev")) {

@@ -390,6 +390,22 @@ static const char* forward(bx_ctx* c, uint32_t* out, const uint32_t* in, size_t 
     uint32_t* twist = nullptr;
     if (sp.m_lo) BX_TRY(get_twist(c, m, sp.m_hi, false, &twist));
     bool done_a = false, done_b = false;
+    // Column groups (SURVEY hard part 5): run pass A and pass B back to back on `ntt_group_cols` columns at a time so that
+    // pass B finds what pass A just wrote in the 256 MB Infinity Cache instead of HBM (0 = one pass A and one pass B over all
+    // columns).  Measured on the 2^22 LDE, see DESIGN.md §4 "NTT traffic".
+    if (c->ntt_fast && c->ntt_group_cols > 0 && sp.m_lo && (size_t)c->ntt_group_cols < count) {
+        const size_t g = (size_t)c->ntt_group_cols;
+        bool all = true;
+        for (size_t c0 = 0; c0 < count && all; c0 += g) {
+            const size_t n = count - c0 < g ? count - c0 : g;
+            bool oa = false, ob = false;
+            BX_TRY(fast_pass_a(c, false, out + c0 * M, in + c0 * (M >> expand_bits), twist, MONT_ONE, n, m, sp.m_hi, expand_bits, skip_bits, &oa));
+            if (oa) BX_TRY(fast_pass_b(c, false, out + c0 * M, n, m, sp.m_hi, &ob));
+            all = oa && ob;
+            if (!all && c0 != 0) return set_msg(c, "ntt: column-group path became unavailable mid-way");
+        }
+        if (all) return nullptr;
+    }
     if (c->ntt_fast) BX_TRY(fast_pass_a(c, false, out, in, twist, MONT_ONE, count, m, sp.m_hi, expand_bits, skip_bits, &done_a));
     if (!done_a) {
         unsigned R = 1u << sp.m_hi;

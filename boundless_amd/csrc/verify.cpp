@@ -341,6 +341,16 @@ void verify(const uint32_t* seal, size_t words) {
 
 }  // namespace
 
+// The compiled-in Poseidon2 table (canonical integers): what bx_init loads into every new ctx and what the verifier uses.
+// Needs no ctx and no GPU, so that the fixture manifest (tests/golden/MANIFEST.json) can pin its SHA-256 on any host.
+extern "C" const char* bx_poseidon2_default_params(uint32_t* rc213, uint32_t* diag24) {
+    if (!rc213 || !diag24) return "bx_poseidon2_default_params: null table";
+    const uint32_t* rc = POSEIDON2_RC;
+    for (int i = 0; i < 213; ++i) rc213[i] = rc[i];
+    for (int i = 0; i < 24; ++i) diag24[i] = POSEIDON2_DIAG[i];
+    return nullptr;
+}
+
 extern "C" const char* bx_verify_segment(const uint32_t* seal, size_t seal_words) {
     static thread_local char err[256];
     if (!seal) return "bx_verify_segment: null seal";

@@ -91,6 +91,9 @@ const char* bx_zk_shift(bx_ctx* ctx, bx_buf io, size_t count);
  * under a non-default table are not accepted by bx_verify_segment, which uses the default. */
 const char* bx_poseidon2_set_params(bx_ctx* ctx, const uint32_t* rc213, const uint32_t* diag24);
 const char* bx_poseidon2_get_params(bx_ctx* ctx, uint32_t* rc213, uint32_t* diag24);
+/* The library's compiled-in default table, same layout; host only (no ctx, no GPU).  Its SHA-256 is pinned in
+ * tests/golden/MANIFEST.json. */
+const char* bx_poseidon2_default_params(uint32_t* rc213, uint32_t* diag24);
 /* Hal::hash_rows(output, matrix): out_digests.len/8 rows; cols = matrix.len/rows. */
 const char* bx_hash_rows(bx_ctx* ctx, bx_buf out_digests, bx_buf matrix);
 /* Hal::hash_fold(io, input_size, output_size): io[out+i] = H(io[in+2i] || io[in+2i+1]), digest indices. */

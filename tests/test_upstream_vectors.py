@@ -1,0 +1,177 @@
+"""Parity against risc0's OWN vectors — skipped until someone drops them into tests/golden/upstream/ (see its README).
+
+Today parity with the Rust prover is unpinned (no vector exists in the reference tree, no network): this loader is what
+flips it to pinned the day the files are supplied, without touching any code.  The CPU half checks the C oracle (and the
+fixture manifest) on every host; the GPU half checks the HIP HAL through the C ABI.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UP = os.path.join(ROOT, "tests", "golden", "upstream")
+
+
+def load(name):
+    p = os.path.join(UP, name)
+    if not os.path.exists(p):
+        pytest.skip(f"tests/golden/upstream/{name} not supplied (parity with risc0 unpinned)")
+    return json.load(open(p))
+
+
+def c(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------------ manifest (always runs)
+def test_manifest_pins_every_fixture_and_the_poseidon2_table():
+    """SURVEY App. A.4 asked for the constant table's SHA-256 in a fixture manifest: tests/golden/MANIFEST.json holds it with
+    the provenance of the 213 + 24 words; the compiled-in table of the product, the oracle's and the KAT fixture's must all
+    hash to it, and every golden file must be the one the manifest names."""
+    import ctypes as C
+
+    from boundless_amd.hal import load_library
+
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST.json")))
+    lib = load_library()
+    lib.bx_poseidon2_default_params.restype = C.c_char_p
+    rc, dg = np.zeros(213, np.uint32), np.zeros(24, np.uint32)
+    assert lib.bx_poseidon2_default_params(rc.ctypes.data_as(C.c_void_p), dg.ctypes.data_as(C.c_void_p)) is None
+    want = man["poseidon2_babybear_t24"]
+
+    def sha(*arrs):
+        return hashlib.sha256(b"".join(a.astype("<u4").tobytes() for a in arrs)).hexdigest()
+
+    assert sha(rc) == want["sha256_round_constants"] and sha(dg) == want["sha256_internal_diag"] and sha(rc, dg) == want["sha256_table"]
+    rc_o, dg_o = np.zeros(213, np.uint32), np.zeros(24, np.uint32)
+    ol.lib().bxo_poseidon2_get_params(rc_o, dg_o)
+    assert sha(rc_o, dg_o) == want["sha256_table"], "the oracle derives a different table"
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon2_kat.json")))
+    assert sha(c(kat["round_constants"]), c(kat["internal_diag"])) == want["sha256_table"]
+    for name, digest in man["files"].items():
+        assert hashlib.sha256(open(os.path.join(ROOT, "tests", "golden", name), "rb").read()).hexdigest() == digest, name
+    assert (rc < ol.P).all() and (dg < ol.P).all()
+
+
+# ------------------------------------------------------------------------------------------------------ CPU: oracle vs upstream
+def test_upstream_poseidon2_constants_equal_the_compiled_in_table():
+    up = load("poseidon2_consts.json")
+    rc, dg = np.zeros(213, np.uint32), np.zeros(24, np.uint32)
+    ol.lib().bxo_poseidon2_get_params(rc, dg)
+    assert up["round_constants"] == rc.tolist(), "default round constants are not upstream's"
+    assert up["internal_diag"] == dg.tolist(), "default internal diagonal is not upstream's"
+
+
+def test_upstream_poseidon2_vectors_vs_oracle():
+    up = load("poseidon2_vectors.json")
+    L = ol.lib()
+    for v in up.get("permutation", []):
+        cells = ol.encode(v["in"])
+        L.bxo_poseidon2_mix(cells)
+        assert ol.decode(cells).tolist() == v["out"]
+    for v in up.get("hash_elem_slice", []):
+        dg = np.zeros(8, np.uint32)
+        x = ol.encode(v["in"]) if v["in"] else np.zeros(1, np.uint32)
+        L.bxo_hash_elem_slice(dg, x, len(v["in"]), 1)
+        assert ol.decode(dg).tolist() == v["digest"]
+    for v in up.get("hash_pair", []):
+        out = np.zeros(8, np.uint32)
+        L.bxo_hash_pair(out, ol.encode(v["a"]), ol.encode(v["b"]))
+        assert ol.decode(out).tolist() == v["out"]
+
+
+def test_upstream_ntt_vectors_vs_oracle():
+    L = ol.lib()
+    for case in load("ntt_vectors.json")["cases"]:
+        n = case["size"]
+        io = ol.encode(case["evals_natural"])
+        L.bxo_batch_interpolate_ntt(io, 1, n)
+        assert ol.decode(io).tolist() == case["interpolate_out"]
+        if "evaluate_out" in case:
+            bits = case.get("expand_bits", 2)
+            out = np.zeros(n << bits, np.uint32)
+            L.bxo_batch_expand_into_evaluate_ntt(out, io, 1, n, bits)
+            assert ol.decode(out).tolist() == case["evaluate_out"]
+
+
+def test_upstream_fri_fold_vectors_vs_oracle():
+    L = ol.lib()
+    for case in load("fri_fold_vectors.json")["cases"]:
+        out = np.zeros(4 * case["count"], np.uint32)
+        L.bxo_fri_fold(out, ol.encode(case["in_soa"]), ol.encode(case["mix"]), case["count"])
+        assert ol.decode(out).tolist() == case["out_soa"]
+
+
+def test_upstream_zk_shift_vectors_vs_oracle():
+    L = ol.lib()
+    for case in load("zk_shift_vectors.json")["cases"]:
+        io = ol.encode(case["in"])
+        L.bxo_zk_shift(io, 1, case["size"])
+        assert ol.decode(io).tolist() == case["out"]
+
+
+def test_upstream_mix_poly_coeffs_vectors_vs_oracle():
+    L = ol.lib()
+    for case in load("mix_poly_coeffs_vectors.json")["cases"]:
+        out = ol.encode(case["init_ext_aos"])
+        L.bxo_mix_poly_coeffs(out, ol.encode(case["mix_start"]), ol.encode(case["mix"]), ol.encode(case["in"]), c(case["combos"]),
+                              case["input_size"], case["count"])
+        assert ol.decode(out).tolist() == case["out_ext_aos"]
+
+
+# ------------------------------------------------------------------------------------------------------ GPU: HIP HAL vs upstream
+@pytest.fixture(scope="module")
+def hal():
+    from boundless_amd.hal import HipHal
+
+    h = HipHal(0)
+    yield h
+    h.close()
+
+
+@pytest.mark.gpu
+def test_upstream_poseidon2_vectors_vs_hal(hal):
+    up = load("poseidon2_vectors.json")
+    for v in up.get("hash_elem_slice", []):
+        if not v["in"]:
+            continue
+        d = hal.alloc_digest(1)
+        hal.hash_rows(d, hal.copy_from(ol.encode(v["in"])))  # a 1-row matrix of len(in) columns
+        assert ol.decode(d.view()).tolist() == v["digest"]
+    for v in up.get("hash_pair", []):
+        host = np.zeros(32, np.uint32)
+        host[16:24], host[24:32] = ol.encode(v["a"]), ol.encode(v["b"])
+        io = hal.copy_from(host)
+        hal.hash_fold(io, 2, 1)
+        assert ol.decode(io.view()[8:16]).tolist() == v["out"]
+
+
+@pytest.mark.gpu
+def test_upstream_ntt_vectors_vs_hal(hal):
+    for case in load("ntt_vectors.json")["cases"]:
+        n = case["size"]
+        io = hal.copy_from(ol.encode(case["evals_natural"]))
+        hal.batch_interpolate_ntt(io, 1)
+        assert ol.decode(io.view()).tolist() == case["interpolate_out"]
+        if "evaluate_out" in case:
+            bits = case.get("expand_bits", 2)
+            out = hal.alloc(n << bits)
+            hal.batch_expand_into_evaluate_ntt(out, io, 1, bits)
+            assert ol.decode(out.view()).tolist() == case["evaluate_out"]
+
+
+@pytest.mark.gpu
+def test_upstream_fri_fold_and_zk_shift_vectors_vs_hal(hal):
+    for case in load("fri_fold_vectors.json")["cases"]:
+        out = hal.alloc(4 * case["count"])
+        hal.fri_fold(out, hal.copy_from(ol.encode(case["in_soa"])), ol.encode(case["mix"]))
+        assert ol.decode(out.view()).tolist() == case["out_soa"]
+    for case in load("zk_shift_vectors.json")["cases"]:
+        io = hal.copy_from(ol.encode(case["in"]))
+        hal.zk_shift(io, 1)
+        assert ol.decode(io.view()).tolist() == case["out"]
