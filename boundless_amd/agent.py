@@ -85,6 +85,9 @@ def _lib():
         "bx_agent_destroy": ([vp], cp), "bx_agent_poll_work": ([vp, C.c_int64, C.POINTER(C.c_uint64)], cp),
         "bx_agent_stop": ([vp], None), "bx_agent_process_one": ([vp, C.POINTER(_ReadyTask), C.POINTER(C.c_int)], cp),
         "bx_agent_metrics": ([vp, cp, sz], sz),
+        "bx_rest_client_create": ([cp, C.c_uint64, C.c_uint64, C.POINTER(vp)], cp), "bx_rest_client_destroy": ([vp], None),
+        "bx_rest_taskdb_ops": ([vp], _TaskDbOps), "bx_rest_hot_store_ops": ([vp], _HotStoreOps),
+        "bx_rest_client_requests": ([vp], C.c_uint64),
         "bx_agent_lane_count": ([vp], C.c_uint32), "bx_agent_lane_device": ([vp, C.c_uint32], C.c_int32),
         "bx_agent_lane_tasks_done": ([vp, C.c_uint32], C.c_uint64),
     }
@@ -209,6 +212,34 @@ class TaskDb:
             self._lib.bx_mem_taskdb_destroy(self._h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------- REST worker tables
+class _Ops:
+    def __init__(self, ops):
+        self.ops = ops
+
+
+class RestWorker:
+    """The next-generation Bento worker protocol (prover/crates/api/src/lib.rs:922-1040; client prover/crates/workflow/src/assets.rs)
+    as the agent's two callback tables (include/bx_rest.h): `Agent(store=w.store, taskdb=w.taskdb, ...)` makes the native feed
+    loop claim tasks from and move blobs through a Bento API over HTTP."""
+
+    def __init__(self, base_url, claim_wait_secs=0, io_timeout_secs=0):
+        self._lib = _lib()
+        self._h = C.c_void_p()
+        _check(self._lib.bx_rest_client_create(base_url.encode(), claim_wait_secs, io_timeout_secs, C.byref(self._h)))
+        self.store = _Ops(self._lib.bx_rest_hot_store_ops(self._h))
+        self.taskdb = _Ops(self._lib.bx_rest_taskdb_ops(self._h))
+
+    @property
+    def requests(self):
+        return self._lib.bx_rest_client_requests(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bx_rest_client_destroy(self._h)
+            self._h = None
 
 
 # --------------------------------------------------------------------------------------------------------------- agent

@@ -1,0 +1,474 @@
+// rest_worker.cpp — worker-side client of the next-generation Bento REST protocol, as the agent's callback tables
+// (include/bx_rest.h).  Restates prover/crates/workflow/src/assets.rs:88-420 (URLs, request/response shapes, status handling)
+// against the routes of prover/crates/api/src/lib.rs:922-1040.  Host code only: POSIX sockets, no third-party HTTP stack
+// (the image has no libcurl headers); one connection per call.
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bx_rest.h"
+
+struct bx_rest_client {
+    std::string host, port, prefix;  // prefix: path part of the base URL without a trailing '/'
+    uint64_t claim_wait = 0, io_timeout = 30;
+    std::atomic<uint64_t> requests{0};
+};
+
+namespace {
+
+thread_local std::string tl_err;
+const char* fail(const std::string& m) {
+    tl_err = m;
+    return tl_err.c_str();
+}
+void put_err(char* buf, size_t cap, const std::string& m) {
+    if (buf && cap) snprintf(buf, cap, "%s", m.c_str());
+}
+
+// RFC 3986 path-segment encoding; ':' and '@' stay (keys are "job:{uuid}:segments:{i}"), '/' stays when keep_slash (wildcard routes)
+std::string enc_path(const std::string& s, bool keep_slash) {
+    static const char* hex = "0123456789ABCDEF";
+    std::string o;
+    for (unsigned char ch : s) {
+        const bool ok = (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '-' || ch == '.' ||
+                        ch == '_' || ch == '~' || ch == ':' || ch == '@' || (keep_slash && ch == '/');
+        if (ok) {
+            o += (char)ch;
+        } else {
+            o += '%';
+            o += hex[ch >> 4];
+            o += hex[ch & 15];
+        }
+    }
+    return o;
+}
+std::string json_escape(const char* s) {
+    std::string o = "\"";
+    for (const unsigned char* p = (const unsigned char*)s; *p; ++p) {
+        switch (*p) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            default:
+                if (*p < 0x20) {
+                    char b[8];
+                    snprintf(b, sizeof b, "\\u%04x", *p);
+                    o += b;
+                } else {
+                    o += (char)*p;
+                }
+        }
+    }
+    return o + "\"";
+}
+
+// ---- a JSON reader that only needs to find the members of one object and hand back their raw text ----
+struct JScan {
+    const char* p;
+    const char* end;
+    bool ok = true;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+    }
+    bool str(std::string* out) {  // at '"': decodes the escapes that can occur in ids and error strings
+        if (p >= end || *p != '"') return ok = false;
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return ok = false;
+                switch (*p) {
+                    case 'n': if (out) *out += '\n'; break;
+                    case 't': if (out) *out += '\t'; break;
+                    case 'r': if (out) *out += '\r'; break;
+                    case 'b': if (out) *out += '\b'; break;
+                    case 'f': if (out) *out += '\f'; break;
+                    case 'u': {
+                        if (end - p < 5) return ok = false;
+                        unsigned v = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                        if (out) {  // BMP code point -> UTF-8
+                            if (v < 0x80) *out += (char)v;
+                            else if (v < 0x800) { *out += (char)(0xC0 | (v >> 6)); *out += (char)(0x80 | (v & 63)); }
+                            else { *out += (char)(0xE0 | (v >> 12)); *out += (char)(0x80 | ((v >> 6) & 63)); *out += (char)(0x80 | (v & 63)); }
+                        }
+                        p += 4;
+                        break;
+                    }
+                    default: if (out) *out += *p;
+                }
+                ++p;
+            } else {
+                if (out) *out += *p;
+                ++p;
+            }
+        }
+        if (p >= end) return ok = false;
+        ++p;
+        return true;
+    }
+    bool skip() {  // any value
+        ws();
+        if (p >= end) return ok = false;
+        if (*p == '"') return str(nullptr);
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = open == '{' ? '}' : ']';
+            ++p;
+            ws();
+            if (p < end && *p == close) { ++p; return true; }
+            for (;;) {
+                ws();
+                if (open == '{') {
+                    if (!str(nullptr)) return false;
+                    ws();
+                    if (p >= end || *p != ':') return ok = false;
+                    ++p;
+                }
+                if (!skip()) return false;
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == close) { ++p; return true; }
+                return ok = false;
+            }
+        }
+        const char* s = p;
+        while (p < end && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') ++p;
+        return p > s ? true : (ok = false);
+    }
+};
+// members of the top-level object of `text` as (key, raw value text); false when `text` is not an object
+bool json_members(const std::string& text, std::vector<std::pair<std::string, std::string>>* out) {
+    JScan j{text.data(), text.data() + text.size()};
+    j.ws();
+    if (j.p >= j.end || *j.p != '{') return false;
+    ++j.p;
+    j.ws();
+    if (j.p < j.end && *j.p == '}') return true;
+    for (;;) {
+        j.ws();
+        std::string key;
+        if (!j.str(&key)) return false;
+        j.ws();
+        if (j.p >= j.end || *j.p != ':') return false;
+        ++j.p;
+        j.ws();
+        const char* v0 = j.p;
+        if (!j.skip()) return false;
+        out->emplace_back(key, std::string(v0, j.p));
+        j.ws();
+        if (j.p < j.end && *j.p == ',') { ++j.p; continue; }
+        if (j.p < j.end && *j.p == '}') return true;
+        return false;
+    }
+}
+const std::string* member(const std::vector<std::pair<std::string, std::string>>& m, const char* key) {
+    for (auto& kv : m)
+        if (kv.first == key) return &kv.second;
+    return nullptr;
+}
+bool json_string_value(const std::string& raw, std::string* out) {
+    JScan j{raw.data(), raw.data() + raw.size()};
+    return j.str(out);
+}
+
+// ---- one HTTP/1.1 exchange ----
+struct Response {
+    int status = 0;
+    std::string body;
+};
+
+bool send_all(int fd, const char* p, size_t n) {
+    while (n) {
+        ssize_t k = send(fd, p, n, MSG_NOSIGNAL);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+
+// returns "" or the transport error
+std::string http_call(bx_rest_client* c, const char* method, const std::string& path_and_query, const char* content_type, const uint8_t* body,
+                      size_t body_len, uint64_t extra_wait, Response* out) {
+    c->requests.fetch_add(1);
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_UNSPEC;
+    hints.ai_socktype = SOCK_STREAM;
+    int gai = getaddrinfo(c->host.c_str(), c->port.c_str(), &hints, &res);
+    if (gai != 0) return std::string("resolve ") + c->host + ": " + gai_strerror(gai);
+    int fd = -1;
+    std::string last = "no address";
+    for (addrinfo* ai = res; ai; ai = ai->ai_next) {
+        fd = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
+        if (fd < 0) continue;
+        timeval tv{(time_t)(c->io_timeout + extra_wait), 0};
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        int one = 1;
+        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        if (connect(fd, ai->ai_addr, ai->ai_addrlen) == 0) break;
+        last = strerror(errno);
+        close(fd);
+        fd = -1;
+    }
+    freeaddrinfo(res);
+    if (fd < 0) return "connect " + c->host + ":" + c->port + ": " + last;
+
+    std::string head = std::string(method) + " " + c->prefix + path_and_query + " HTTP/1.1\r\nHost: " + c->host + ":" + c->port +
+                       "\r\nConnection: close\r\nAccept: */*\r\n";
+    if (body || !strcmp(method, "POST") || !strcmp(method, "PUT")) {
+        if (content_type) head += std::string("Content-Type: ") + content_type + "\r\n";
+        head += "Content-Length: " + std::to_string(body_len) + "\r\n";
+    }
+    head += "\r\n";
+    if (!send_all(fd, head.data(), head.size()) || (body_len && !send_all(fd, (const char*)body, body_len))) {
+        std::string e = std::string("send: ") + strerror(errno);
+        close(fd);
+        return e;
+    }
+    std::string raw;
+    char buf[1 << 16];
+    for (;;) {
+        ssize_t k = recv(fd, buf, sizeof buf, 0);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            std::string e = std::string("receive: ") + strerror(errno);
+            close(fd);
+            return e;
+        }
+        if (k == 0) break;
+        raw.append(buf, (size_t)k);
+    }
+    close(fd);
+    size_t he = raw.find("\r\n\r\n");
+    if (he == std::string::npos || raw.compare(0, 5, "HTTP/") != 0) return "malformed HTTP response";
+    size_t sp = raw.find(' ');
+    out->status = sp == std::string::npos ? 0 : atoi(raw.c_str() + sp + 1);
+    std::string headers = raw.substr(0, he);
+    for (auto& ch : headers) ch = (char)tolower((unsigned char)ch);
+    std::string payload = raw.substr(he + 4);
+    if (headers.find("transfer-encoding: chunked") != std::string::npos) {
+        std::string de;
+        size_t pos = 0;
+        for (;;) {
+            size_t le = payload.find("\r\n", pos);
+            if (le == std::string::npos) return "malformed chunked body";
+            size_t n = strtoul(payload.substr(pos, le - pos).c_str(), nullptr, 16);
+            if (n == 0) break;
+            if (le + 2 + n > payload.size()) return "truncated chunked body";
+            de.append(payload, le + 2, n);
+            pos = le + 2 + n + 2;
+        }
+        out->body.swap(de);
+    } else {
+        size_t cl = headers.find("content-length:");
+        if (cl != std::string::npos) {
+            size_t n = strtoull(headers.c_str() + cl + 15, nullptr, 10);
+            if (payload.size() < n) return "truncated body";
+            payload.resize(n);
+        }
+        out->body.swap(payload);
+    }
+    return "";
+}
+
+std::string task_url(const char* job, const char* task, const char* action) {
+    return "/worker/gpu/tasks/" + enc_path(job, false) + "/" + enc_path(task, false) + "/" + action;
+}
+// POST .../{action} -> {"updated": bool}; 1 / 0 / -1
+int task_update(bx_rest_client* c, const char* job, const char* task, const char* action, const std::string* body, char* eb, size_t cap) {
+    Response r;
+    std::string e = http_call(c, "POST", task_url(job, task, action), body ? "application/json" : nullptr,
+                              body ? (const uint8_t*)body->data() : nullptr, body ? body->size() : 0, 0, &r);
+    if (!e.empty()) return put_err(eb, cap, std::string("task ") + action + " " + job + ":" + task + ": " + e), -1;
+    if (r.status >= 400 || r.status < 200)
+        return put_err(eb, cap, std::string("task ") + action + " update failed for " + job + ":" + task + ": HTTP " + std::to_string(r.status) + " " + r.body.substr(0, 160)), -1;
+    std::vector<std::pair<std::string, std::string>> m;
+    const std::string* u = json_members(r.body, &m) ? member(m, "updated") : nullptr;
+    if (!u) return put_err(eb, cap, std::string("failed to decode task ") + action + " response for " + job + ":" + task), -1;
+    return *u == "true" ? 1 : 0;
+}
+
+// ---- bx_taskdb_ops ----
+int rest_request_work(void* user, const char* stream, bx_ready_task* out, char* eb, size_t cap) {
+    auto* c = (bx_rest_client*)user;
+    try {
+        Response r;
+        std::string path = "/worker/gpu/tasks/claim/" + enc_path(stream, false) + "?wait_timeout_secs=" + std::to_string(c->claim_wait);
+        std::string e = http_call(c, "POST", path, nullptr, nullptr, 0, c->claim_wait, &r);
+        if (!e.empty()) return put_err(eb, cap, std::string("failed to claim GPU work for stream ") + stream + ": " + e), -1;
+        if (r.status >= 400 || r.status < 200)
+            return put_err(eb, cap, std::string("GPU work claim failed for stream ") + stream + ": HTTP " + std::to_string(r.status) + " " + r.body.substr(0, 160)), -1;
+        JScan ws{r.body.data(), r.body.data() + r.body.size()};
+        ws.ws();
+        if ((size_t)(ws.end - ws.p) >= 4 && !strncmp(ws.p, "null", 4)) return 0;  // Json(None)
+        std::vector<std::pair<std::string, std::string>> m;
+        if (!json_members(r.body, &m)) return put_err(eb, cap, "failed to decode GPU work claim response"), -1;
+        const std::string *job = member(m, "job_id"), *task = member(m, "task_id"), *def = member(m, "task_def"), *mr = member(m, "max_retries");
+        std::string job_s, task_s;
+        if (!job || !task || !def || !mr || !json_string_value(*job, &job_s) || !json_string_value(*task, &task_s))
+            return put_err(eb, cap, "GPU work claim response lacks job_id / task_id / task_def / max_retries"), -1;
+        if (job_s.size() >= sizeof out->job_id || task_s.size() >= sizeof out->task_id || def->size() >= sizeof out->task_def)
+            return put_err(eb, cap, "claimed task " + job_s + ":" + task_s + " does not fit bx_ready_task"), -1;
+        memset(out, 0, sizeof *out);
+        memcpy(out->job_id, job_s.data(), job_s.size());
+        memcpy(out->task_id, task_s.data(), task_s.size());
+        memcpy(out->task_def, def->data(), def->size());  // the raw JSON text of task_def, e.g. {"Prove":{"index":3}}
+        out->max_retries = (int32_t)strtol(mr->c_str(), nullptr, 10);
+        return 1;
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, std::string("claim: ") + ex.what()), -1;
+    }
+}
+int rest_done(void* user, const char* job, const char* task, const char* output_json, char* eb, size_t cap) {
+    try {
+        std::string body = std::string("{\"output\":") + (output_json && *output_json ? output_json : "null") + "}";
+        return task_update((bx_rest_client*)user, job, task, "done", &body, eb, cap);
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+int rest_failed(void* user, const char* job, const char* task, const char* error, char* eb, size_t cap) {
+    try {
+        std::string body = "{\"error\":" + json_escape(error ? error : "") + "}";
+        return task_update((bx_rest_client*)user, job, task, "failed", &body, eb, cap);
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+int rest_retry(void* user, const char* job, const char* task, char* eb, size_t cap) {
+    try {
+        return task_update((bx_rest_client*)user, job, task, "retry", nullptr, eb, cap);
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+int rest_current_retries(void* user, const char* job, const char* task, int32_t* retries, char* eb, size_t cap) {
+    auto* c = (bx_rest_client*)user;
+    try {
+        Response r;
+        std::string e = http_call(c, "GET", task_url(job, task, "retries-running"), nullptr, nullptr, 0, 0, &r);
+        if (!e.empty()) return put_err(eb, cap, std::string("failed to fetch retries for task ") + job + ":" + task + ": " + e), -1;
+        if (r.status >= 400 || r.status < 200) return put_err(eb, cap, std::string("task retries fetch failed for ") + job + ":" + task + ": HTTP " + std::to_string(r.status)), -1;
+        std::vector<std::pair<std::string, std::string>> m;
+        const std::string* v = json_members(r.body, &m) ? member(m, "retries") : nullptr;
+        if (!v) return put_err(eb, cap, std::string("failed to decode retries-running response for ") + job + ":" + task), -1;
+        if (*v == "null") return 0;  // Option::None: no running row
+        *retries = (int32_t)strtol(v->c_str(), nullptr, 10);
+        return 1;
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+
+// ---- bx_hot_store_ops ----
+int rest_hot_get(void* user, const char* key, uint8_t** value, size_t* len, char* eb, size_t cap) {
+    auto* c = (bx_rest_client*)user;
+    try {
+        Response r;
+        std::string e = http_call(c, "GET", "/worker/hot/" + enc_path(key, true), nullptr, nullptr, 0, 0, &r);
+        if (!e.empty()) return put_err(eb, cap, std::string("failed to fetch hot-store key ") + key + ": " + e), -1;
+        if (r.status == 404) return 1;  // AppError::HotDataMissing
+        if (r.status >= 400 || r.status < 200) return put_err(eb, cap, std::string("hot-store fetch failed for key ") + key + ": HTTP " + std::to_string(r.status)), -1;
+        *len = r.body.size();
+        *value = (uint8_t*)malloc(*len ? *len : 1);
+        if (!*value) return put_err(eb, cap, "out of memory"), -1;
+        memcpy(*value, r.body.data(), *len);
+        return 0;
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+void rest_hot_free(void*, uint8_t* v) { free(v); }
+int rest_hot_set(void* user, const char* key, const uint8_t* value, size_t len, uint64_t ttl, char* eb, size_t cap) {
+    auto* c = (bx_rest_client*)user;
+    try {
+        Response r;
+        std::string path = "/worker/hot/" + enc_path(key, true);
+        if (ttl) path += "?ttl_secs=" + std::to_string(ttl);
+        std::string e = http_call(c, "PUT", path, "application/octet-stream", value, len, 0, &r);
+        if (!e.empty()) return put_err(eb, cap, std::string("failed to write hot-store key ") + key + ": " + e), -1;
+        if (r.status >= 400 || r.status < 200) return put_err(eb, cap, std::string("hot-store write failed for key ") + key + ": HTTP " + std::to_string(r.status)), -1;
+        return 0;
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+int rest_hot_unlink(void* user, const char* key, char* eb, size_t cap) {
+    auto* c = (bx_rest_client*)user;
+    try {
+        Response r;
+        std::string e = http_call(c, "DELETE", "/worker/hot/" + enc_path(key, true), nullptr, nullptr, 0, 0, &r);
+        if (!e.empty()) return put_err(eb, cap, std::string("failed to delete hot-store key ") + key + ": " + e), -1;
+        if (r.status >= 400 || r.status < 200) return put_err(eb, cap, std::string("hot-store delete failed for key ") + key + ": HTTP " + std::to_string(r.status)), -1;
+        return 0;
+    } catch (const std::exception& ex) {
+        return put_err(eb, cap, ex.what()), -1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bx_rest_client_create(const char* base_url, uint64_t claim_wait_secs, uint64_t io_timeout_secs, bx_rest_client** out) {
+    if (!base_url || !out) return "bx_rest_client_create: NULL argument";
+    try {
+        std::string u = base_url;
+        while (!u.empty() && u.back() == '/') u.pop_back();
+        if (u.empty()) return "bx_rest_client_create: API URL must not be empty";  // assets.rs:69-71
+        if (u.compare(0, 7, "http://") != 0) return fail("bx_rest_client_create: only http:// URLs are supported (TLS terminates in front of the API): " + u);
+        std::string rest = u.substr(7), hostport = rest, prefix;
+        size_t slash = rest.find('/');
+        if (slash != std::string::npos) {
+            hostport = rest.substr(0, slash);
+            prefix = rest.substr(slash);
+        }
+        if (hostport.empty()) return fail("bx_rest_client_create: failed to parse API URL: " + u);
+        auto* c = new bx_rest_client();
+        size_t colon = hostport.rfind(':');
+        if (colon != std::string::npos && hostport.find(']') == std::string::npos) {
+            c->host = hostport.substr(0, colon);
+            c->port = hostport.substr(colon + 1);
+        } else {
+            c->host = hostport;
+            c->port = "80";
+        }
+        c->prefix = prefix;
+        c->claim_wait = claim_wait_secs;
+        c->io_timeout = io_timeout_secs ? io_timeout_secs : 30;
+        if (c->host.empty() || c->port.empty() || c->port.find_first_not_of("0123456789") != std::string::npos) {
+            delete c;
+            return fail("bx_rest_client_create: failed to parse API URL: " + u);
+        }
+        *out = c;
+        return nullptr;
+    } catch (const std::exception& ex) {
+        return fail(std::string("bx_rest_client_create: ") + ex.what());
+    }
+}
+void bx_rest_client_destroy(bx_rest_client* c) { delete c; }
+bx_taskdb_ops bx_rest_taskdb_ops(bx_rest_client* c) {
+    return bx_taskdb_ops{c, rest_request_work, rest_done, rest_failed, rest_retry, rest_current_retries};
+}
+bx_hot_store_ops bx_rest_hot_store_ops(bx_rest_client* c) {
+    return bx_hot_store_ops{c, rest_hot_get, rest_hot_free, rest_hot_set, rest_hot_unlink};
+}
+uint64_t bx_rest_client_requests(const bx_rest_client* c) { return c ? c->requests.load() : 0; }
+
+}  // extern "C"

@@ -128,6 +128,96 @@ def test_agent_feed_loop_with_the_hip_prover():
         a.close()
 
 
+def test_one_native_agent_over_two_device_slots_steals_work_and_stays_bit_exact():
+    """bx_agent_config.n_devices on real hardware: one agent process, two "devices" (this box has one GPU, so both slots are
+    ordinal 0: two independent sets of lanes, contexts and provers), 2 lanes each, all four lanes claiming from the one task db.
+    BASELINE configs[2] (a batch work-stolen across the GPUs of a node) through the native queue; every seal must equal the
+    oracle's and every task must be done exactly once."""
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment, verify_seal
+
+    po2, widths, n = 12, (4, 12, 4), 16
+    a = ag.Agent(prover=None, devices=[0, 0], inflight=2, widths=widths, poll_time=0.005)
+    try:
+        for i in range(n):
+            a.store.set_key_with_expiry(f"job:B:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=po2)), 600)
+            a.taskdb.create_task("B", f"prove-{i}", {"Prove": {"index": i}})
+        assert a.poll_work(max_idle_polls=3) == n
+        stats = a.lane_stats()
+        assert [d for d, _ in stats] == [0, 0, 0, 0] and sum(k for _, k in stats) == n
+        assert sum(k for _, k in stats[:2]) > 0 and sum(k for _, k in stats[2:]) > 0, stats  # both device slots got work
+        assert a.taskdb.count("done") == n
+        for i in range(n):
+            rec = ag.deserialize_receipt(a.store.get(f"job:B:synthetic_receipts:prove-{i}"))
+            want, _ = ol.prove_segment(po2, *widths, Segment.synthetic(i, po2=po2).seed)
+            assert rec.index == i and np.array_equal(rec.seal, want), f"segment {i}"
+            verify_seal(rec.seal)
+    finally:
+        a.close()
+
+
+def test_hip_prover_as_a_rest_worker_of_a_bento_api():
+    """The native agent with the HIP prover as a worker of a next-gen Bento API (include/bx_rest.h): claims over
+    POST /worker/gpu/tasks/claim/prove, fetches segments over GET /worker/hot/..., proves on the GPU, verifies, PUTs the
+    receipts, DELETEs the segments and reports done — against the local stub of the API's worker routes."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rest_stub_server import StubServer
+
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment, verify_seal
+
+    job, po2, widths, n = "0b1e55ed-0000-4000-8000-0000000000aa", 12, (4, 12, 4), 6
+    srv = StubServer()
+    w = ag.RestWorker(srv.url, claim_wait_secs=0)
+    a = ag.Agent(prover=None, device=0, inflight=2, widths=widths, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    try:
+        for i in range(n):
+            srv.state.hot[f"job:{job}:segments:{i}"] = (ag.serialize_segment(Segment.synthetic(i, po2=po2)), None)
+            srv.state.create_task("prove", job, f"prove-{i}", {"Prove": {"index": i}}, max_retries=1)
+        assert a.poll_work(max_idle_polls=2) == n
+        assert [t["state"] for t in srv.state.tasks] == ["done"] * n
+        assert sorted(srv.state.hot) == sorted(f"job:{job}:synthetic_receipts:prove-{i}" for i in range(n))
+        for i in range(n):
+            rec = ag.deserialize_receipt(srv.state.hot[f"job:{job}:synthetic_receipts:prove-{i}"][0])
+            want, _ = ol.prove_segment(po2, *widths, Segment.synthetic(i, po2=po2).seed)
+            assert np.array_equal(rec.seal, want)
+            verify_seal(rec.seal)
+    finally:
+        a.close()
+        w.close()
+        srv.close()
+
+
+def test_agent_bounds_the_shapes_it_caches_and_reports_create_errors():
+    """Round-1 advisor finding: po2 came unvalidated from the blob, every distinct value allocated a buffer set per lane for
+    good, and a failed allocation surfaced as "no prover".  Sizes outside [po2_min, po2_max] now fail the task with the reason,
+    at most max_shapes buffer sets are cached per lane (least recently used evicted), and create errors are passed through."""
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment
+
+    a = ag.Agent(prover=None, device=0, inflight=1, widths=(2, 6, 2), poll_time=0.005, po2_range=(9, 12), max_shapes=2)
+    try:
+        order = [10, 11, 12, 10, 9, 13, 8]
+        for k, po2 in enumerate(order):
+            a.store.set_key_with_expiry(f"job:S:segments:{k}", ag.serialize_segment(Segment.synthetic(k, po2=po2)), 600)
+            a.taskdb.create_task("S", f"t{k}", {"Prove": {"index": k}})
+        assert a.poll_work(max_idle_polls=2) == 5
+        for k, po2 in enumerate(order):
+            row = a.taskdb.task("S", f"t{k}")
+            if 9 <= po2 <= 12:
+                assert row.state == "done", (po2, row.error)
+                rec = ag.deserialize_receipt(a.store.get(f"job:S:synthetic_receipts:t{k}"))
+                want, _ = ol.prove_segment(po2, 2, 6, 2, Segment.synthetic(k, po2=po2).seed)
+                assert np.array_equal(rec.seal, want)  # still exact after evictions and re-creations
+            else:
+                assert row.state == "failed" and "outside the sizes this agent accepts [9, 12]" in row.error, row.error
+    finally:
+        a.close()
+
+
 def test_plain_c_consumer_of_the_abi(tmp_path):
     """Build tests/c_abi_smoke.c with gcc, link it against the in-tree library and run it on the GPU."""
     import os

@@ -1,0 +1,158 @@
+"""CPU: the next-gen Bento worker protocol (include/bx_rest.h) against a local stub of the API's worker routes.
+
+The native agent (C++ feed loop) claims, proves through an injected prover, stores and reports over HTTP exactly as
+prover/crates/workflow does (assets.rs:193-420): same URLs, same JSON bodies, same status handling.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rest_stub_server import StubServer  # noqa: E402
+
+from boundless_amd import agent as ag  # noqa: E402
+from boundless_amd.hal import HalError  # noqa: E402
+from boundless_amd.prover import Segment, SegmentReceipt  # noqa: E402
+
+JOB = "0b1e55ed-0000-4000-8000-00000000c0de"
+
+
+class FakeProver:
+    def __init__(self, fail_times=0):
+        self.calls, self.fail_times = 0, fail_times
+
+    def prove_segment(self, seg):
+        self.calls += 1
+        if self.calls <= self.fail_times:
+            raise RuntimeError("hipErrorLaunchFailure (injected)")
+        return SegmentReceipt(seal=np.arange(10, dtype=np.uint32) + seg.index, index=seg.index, po2=seg.po2)
+
+
+@pytest.fixture()
+def server():
+    s = StubServer()
+    yield s
+    s.close()
+
+
+def test_claim_prove_store_done_over_http(server):
+    st = server.state
+    for i in range(6):
+        st.hot[f"job:{JOB}:segments:{i}"] = (ag.serialize_segment(Segment.synthetic(i, po2=12)), None)
+        st.create_task("prove", JOB, f"prove-{i}", {"Prove": {"index": i}}, max_retries=2)
+    st.create_task("join", JOB, "join-1", {"Join": {"idx": 1, "left": 2, "right": 3}})
+    w = ag.RestWorker(server.url, claim_wait_secs=0)
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, inflight=2, store=w.store, taskdb=w.taskdb, redis_ttl=3600)
+    try:
+        assert a.poll_work(max_idle_polls=2) == 6
+    finally:
+        a.close()
+    assert sorted(st.hot) == sorted(f"job:{JOB}:synthetic_receipts:prove-{i}" for i in range(6))  # receipts stored, segments deleted
+    for i in range(6):
+        blob, deadline = st.hot[f"job:{JOB}:synthetic_receipts:prove-{i}"]
+        rec = ag.deserialize_receipt(blob)
+        assert rec.index == i and np.array_equal(rec.seal, np.arange(10, dtype=np.uint32) + i)
+        assert deadline is not None  # PUT ...?ttl_secs=3600 (hot_set_bytes with a TTL, assets.rs:386-399)
+    assert [t["state"] for t in st.tasks] == ["done"] * 6 + ["ready"]  # the join task is another stream's
+    assert all(t["output"] is None for t in st.tasks[:6])  # {"output": null}: the prove task returns ()
+    paths = [p for _, p in st.log]
+    assert ("POST", "/worker/gpu/tasks/claim/prove") in st.log
+    assert ("POST", f"/worker/gpu/tasks/{JOB}/prove-3/done") in st.log
+    assert ("GET", f"/worker/hot/job:{JOB}:segments:3") in st.log and ("DELETE", f"/worker/hot/job:{JOB}:segments:3") in st.log
+    assert ("PUT", f"/worker/hot/job:{JOB}:synthetic_receipts:prove-3") in st.log
+    assert w.requests == len(paths)
+    w.close()
+
+
+def test_retry_failed_and_missing_blob_semantics_over_http(server):
+    st = server.state
+    st.hot[f"job:{JOB}:segments:0"] = (ag.serialize_segment(Segment.synthetic(0, po2=10)), None)
+    st.create_task("prove", JOB, "flaky", {"Prove": {"index": 0}}, max_retries=3)
+    st.create_task("prove", JOB, "missing", {"Prove": {"index": 7}}, max_retries=1)
+    st.create_task("prove", JOB, "nonsense", {"Nope": {}}, max_retries=0)
+    w = ag.RestWorker(server.url)
+    p = FakeProver(fail_times=2)
+    a = ag.Agent(prover=p, verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    try:
+        assert a.poll_work(max_idle_polls=2) == 1
+    finally:
+        a.close()
+    by = {t["task_id"]: t for t in st.tasks}
+    assert (by["flaky"]["state"], by["flaky"]["retries"]) == ("done", 2)  # retries-running -> retry -> claimed again (lib.rs:381-436)
+    assert by["missing"]["state"] == "failed" and by["missing"]["retries"] == 1
+    # 404 HotDataMissing arrives as the reference's nil-key error chain
+    assert by["missing"]["error"].startswith("retry max hit: [BENTO-WF-115] Prove failed: segment data not found for segment key: "
+                                             f"job:{JOB}:segments:7: Key not found (nil response)")
+    assert by["nonsense"]["state"] == "failed" and by["nonsense"]["error"] == f"Invalid task_def: {JOB}:nonsense"
+    assert ("GET", f"/worker/gpu/tasks/{JOB}/flaky/retries-running") in st.log and ("POST", f"/worker/gpu/tasks/{JOB}/flaky/retry") in st.log
+    w.close()
+
+
+def test_error_text_is_json_escaped_and_keys_are_path_encoded(server):
+    st = server.state
+    odd_task = 'we ird"task\\1'
+    st.hot[f"job:{JOB}:segments:0"] = (ag.serialize_segment(Segment.synthetic(0, po2=10)), None)
+    st.create_task("prove", JOB, odd_task, {"Prove": {"index": 0}}, max_retries=0)
+
+    class Noisy:
+        def prove_segment(self, seg):
+            raise RuntimeError('line1\n"quoted" \\ tab\t end')
+
+    w = ag.RestWorker(server.url)
+    a = ag.Agent(prover=Noisy(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    try:
+        assert a.poll_work(max_idle_polls=1) == 0
+    finally:
+        a.close()
+    t = st.tasks[0]
+    assert t["state"] == "failed" and t["error"] == '[BENTO-WF-115] Prove failed: line1\n"quoted" \\ tab\t end'
+    w.close()
+
+
+def test_transport_and_server_errors_end_the_loop_like_the_reference(server):
+    """A failing claim is fatal to poll_work (the reference `?`-returns with BENTO-WF-105/107); the agent object survives."""
+    w = ag.RestWorker(server.url)
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    server.state.fail_next = 1
+    with pytest.raises(HalError, match=r"\[BENTO-WF-107\] Failed to request_work: GPU work claim failed for stream prove: HTTP 500"):
+        a.poll_work(max_idle_polls=1)
+    assert a.poll_work(max_idle_polls=1) == 0  # the next poll works again
+    a.close()
+    w.close()
+    dead = ag.RestWorker("http://127.0.0.1:1")  # nothing listens there
+    b = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, store=dead.store, taskdb=dead.taskdb)
+    with pytest.raises(HalError, match="failed to claim GPU work for stream prove: connect 127.0.0.1:1"):
+        b.poll_work(max_idle_polls=1)
+    b.close()
+    dead.close()
+    for bad in ("", "https://x", "http://", "http://host:port"):
+        with pytest.raises(HalError):
+            ag.RestWorker(bad)
+
+
+def test_long_poll_claim_and_invalid_stream(server):
+    import threading
+    import time
+
+    st = server.state
+    w = ag.RestWorker(server.url, claim_wait_secs=2)
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    st.hot[f"job:{JOB}:segments:0"] = (ag.serialize_segment(Segment.synthetic(0, po2=10)), None)
+
+    def later():
+        time.sleep(0.3)
+        st.create_task("prove", JOB, "late", {"Prove": {"index": 0}})
+
+    threading.Thread(target=later).start()
+    t0 = time.time()
+    assert a.poll_work(max_idle_polls=1) == 1  # the claim blocks server-side (request_work_wait) until the task appears
+    assert 0.25 < time.time() - t0 < 6
+    a.close()
+    bad = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb, task_stream="exec")
+    with pytest.raises(HalError, match="HTTP 400"):  # AppError::InvalidGpuWorkerStream
+        bad.poll_work(max_idle_polls=1)
+    bad.close()
+    w.close()
