@@ -36,8 +36,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = "r02"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GOPS = 39321.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz non-packed VALU lane-ops (measured ~37k, profiles/r01_microbench_valu.jsonl)
+
+
+def _profile(name):
+    """profiles/<PROFILE_ROUND>_<name>, or round 1's file while this round's has not been collected yet"""
+    for rnd in (PROFILE_ROUND, "r01"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(name)
+
+
+def _valu_per_wave():
+    """VALU instructions per wave, per kernel name: this round's job-level PMC pass, else round 1's opbench pass"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_job_valu_insts.json")))["valu_insts_per_wave"]
+    except Exception:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
+        return {name: v["valu_insts_per_wave"] for name, v in k.items() if "valu_insts_per_wave" in v}
 
 
 def cpu_baseline(po2_sample, widths, po2_full):
@@ -84,10 +103,10 @@ def cpu_baseline(po2_sample, widths, po2_full):
 
 
 def job_valu_view(segments_per_s_per_gpu):
-    """Whole-job VALU issue rate: wave-level VALU instructions per segment (PMC, profiles/r01_job_valu_insts.json, all
+    """Whole-job VALU issue rate: wave-level VALU instructions per segment (PMC, profiles/r02_job_valu_insts.json, all
     kernels of the default workload) x the measured segment rate of one GPU, against the multiply-class issue peak."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r01_job_valu_insts.json")))
+        j = json.load(open(_profile("job_valu_insts.json")))
         rate = j["per_segment"] * segments_per_s_per_gpu
         return {"valu_wave_insts_per_segment": j["per_segment"], "wave_insts_per_s_per_gpu": rate,
                 "issue_peak_mul": 1024 * 2.4e9 / 4, "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3),
@@ -266,7 +285,7 @@ def main():
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/pmc_traffic.py); None when the file is absent
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")))["kernels"]
+            pmc = json.load(open(_profile("bench_pmc_traffic.json")))["kernels"]
             sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k or "ntt_passA_fwd12_multi_kernel" in k]
             if sel:
                 launches = max(v["launches"] for v in sel)
@@ -281,7 +300,7 @@ def main():
                     "achieved_bytes_per_launch": (e.get("alg_GBps", 0) or 0) * 1e9 * (e.get("avg_ms", 0) or 0) * 1e-3,
                     "measured": measured,
                     "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream; traffic = "
-                            "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r01_bench_pmc_traffic.json; "
+                            "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r02_bench_pmc_traffic.json; "
                             "the path is VALU-issue-bound (DESIGN.md section 4), see roofline_dominant"}
 
         # With several segments in flight the per-launch durations of the timed region include time-slicing between the
@@ -292,9 +311,9 @@ def main():
             # VALU-issue view of the same launch: wave-instructions per output element of the two LDE kernels from the
             # committed PMC counts (pass A multi-column: 8192 elements per wave, pass B: 1024 elements per wave)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
-                a = [v["valu_insts_per_wave"] for k, v in pmc.items() if "ntt_passA_fwd12_multi_kernel" in k][0] / 8192.0
-                b = [v["valu_insts_per_wave"] for k, v in pmc.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0] / 1024.0
+                pmc = _valu_per_wave()
+                a = [v for k, v in pmc.items() if "ntt_passA_fwd12_multi_kernel" in k][0] / 8192.0
+                b = [v for k, v in pmc.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0] / 1024.0
                 out_elems = r["achieved_bytes_per_launch"] / 4.0 / 1.25
                 rate = out_elems * (a + b) / (r["avg_ms_per_launch"] * 1e-3)
                 r["valu_view"] = {"wave_insts_per_output_element": round(a + b, 4), "wave_insts_per_s": rate,
@@ -316,8 +335,8 @@ def main():
                     "note": "Poseidon2 is VALU-issue-bound (no HBM or MFMA roofline applies); see DESIGN.md section 4"}
         try:
             src_k = iso_k if iso_k else kernels
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
-            per_perm = [v["valu_insts_per_wave"] for k, v in pmc.items() if "hash_fold_kernel" in k][0]
+            pmc = _valu_per_wave()
+            per_perm = [v for k, v in pmc.items() if "hash_fold_kernel" in k][0]
             rows4 = 4 << args.po2
             perms = rows4 * sum((w + 15) // 16 for w in list(widths) + [16])
             hr = src_k.get("hash_rows", {})
