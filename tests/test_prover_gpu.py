@@ -35,6 +35,27 @@ def test_seal_bit_exact_vs_oracle(po2, widths, seed):
         srv.close()
 
 
+@pytest.mark.parametrize("po2,widths,knobs,seed", [
+    (21, (4, 16, 8), (0, 0), 21),      # compose.yml:67 runs segment_po2 = 21: 2^23-point LDEs
+    (14, (16, 64, 16), (16, 3), 3),    # another compile-time circuit shape
+    (13, (5, 33, 9), (5, 2), 8),       # knobs without a specialisation: the run-time path of cons_sum
+    (12, (3, 10, 4), (64, 5), 9),      # the highest constraint degree the check polynomial admits
+    (11, (2, 7, 12), (1, 1), 4),       # degenerate: every derived cell is one pool entry; three accumulators, one pair
+])
+def test_seal_bit_exact_vs_oracle_other_sizes_and_circuit_knobs(po2, widths, knobs, seed):
+    from boundless_amd.prover import HipProverServer, Segment
+
+    srv = HipProverServer(0, po2=po2, widths=widths, terms=knobs[0], degree=knobs[1])
+    try:
+        receipt = srv.prove_segment(Segment(index=0, po2=po2, seed=seed))
+    finally:
+        srv.close()
+    seal, roots = ol.prove_segment(po2, *widths, seed, terms=knobs[0], degree=knobs[1])
+    assert np.array_equal(receipt.roots, roots), "Merkle roots differ"
+    assert np.array_equal(receipt.seal, seal)
+    receipt.verify_integrity()
+
+
 def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
     """`deep_bitrev` = 0 runs upstream's order (bit-reverse every coefficient column, evaluate, mix); the default keeps the
     trace coefficients bit-reversed and reverses only the two combination polynomials.  Same seal either way."""
