@@ -14,6 +14,7 @@
 #include "circuit.hpp"
 #include "ctx.hpp"
 #include "circuit_dev.hpp"
+#include "lazy_ext.hpp"
 
 namespace bx {
 
@@ -127,12 +128,14 @@ struct ZInv {
 template <int TT, int GG>
 __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ check, const uint32_t* __restrict__ ecode,
                                                          const uint32_t* __restrict__ edata, const uint32_t* __restrict__ eacc, Circuit cc,
-                                                         const uint32_t* __restrict__ mixpows, const uint32_t* __restrict__ betas, ZInv zinv) {
+                                                         const uint32_t* __restrict__ mixpows, const uint32_t* __restrict__ mixpows_c,
+                                                         const uint32_t* __restrict__ betas, ZInv zinv) {
     const uint32_t dom = 4u << cc.po2;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= dom) return;
     const uint32_t ib = (i + dom - 4u) & (dom - 1u);  // one row back: x * w_N^-1 = w_4N^(row - 4)
-    Fp4 tot = f4_zero();
+    LazyExtAcc mixacc;  // sum_j poly_mix^j * C_j over the derived-column constraints (ext weight x base value)
+    mixacc.reset();
     uint32_t ring[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -148,10 +151,12 @@ __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ 
         pool[6] = ck < 0 ? MONT_ONE : ecode[(size_t)ck * dom + i];
         const uint32_t d = edata[(size_t)(cc.F + j) * dom + i];
         const uint32_t cons = fp_sub(d, cons_sum<TT, GG>(pool, cc.T, cc.G));
-        const uint4 m = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)j);  // wave-uniform
-        tot = f4_add(tot, f4_scale(Fp4{{m.x, m.y, m.z, m.w}}, cons));
+        const uint4 m = *reinterpret_cast<const uint4*>(mixpows_c + 4 * (size_t)j);  // wave-uniform, centred
+        const i32 w[4] = {(i32)m.x, (i32)m.y, (i32)m.z, (i32)m.w};
+        mixacc.add(w, cons);
         ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = d;
     }
+    Fp4 tot = mixacc.finish();
     const uint32_t first = ecode[i];
     for (uint32_t e = 0; e < cc.E; ++e) {
         Fp4 a, ab;
@@ -267,20 +272,41 @@ const char* circuit_accumulate(bx_ctx* c, const Circuit& cc, bx_buf accum, bx_bu
     return nullptr;
 }
 
+// mixpows[i] = poly_mix^i for i < n (canonical), followed by the same table centred (the weights of eval_check's LazyExtAcc)
+__global__ void mix_table_kernel(uint32_t* __restrict__ out, Fp4 base, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fp4 r = f4_pow(base, i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out[4 * i + k] = r.c[k];
+        out[4 * (n + i) + k] = (uint32_t)fp_centre_w(r.c[k]);
+    }
+}
+const char* circuit_mix_table(bx_ctx* c, const Circuit& cc, bx_buf mixpows, const uint32_t poly_mix[4]) {
+    const uint32_t n = (uint32_t)cc.constraints();
+    BX_REQUIRE(c, mixpows.len >= 8 * (size_t)n, "circuit_mix_table: table too small");
+    if (!n) return nullptr;
+    hipLaunchKernelGGL(mix_table_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)mixpows.dptr,
+                       Fp4{{poly_mix[0], poly_mix[1], poly_mix[2], poly_mix[3]}}, n);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
 // eval_check over the committed 4N evaluations; `check` receives the four ext planes of check(x) over the domain
 const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, bx_buf mixpows, bx_buf betas_dev,
                                const uint32_t zinv[4]) {
     const size_t dom = (size_t)4 << cc.po2;
     BX_REQUIRE(c, check.len == 4 * dom && ecode.len == dom * cc.wc && edata.len == dom * cc.wd && eacc.len == dom * cc.wa,
                "circuit_eval_check: buffer size mismatch");
-    BX_REQUIRE(c, mixpows.len >= 4 * cc.constraints(), "circuit_eval_check: mix power table too small");
+    BX_REQUIRE(c, mixpows.len >= 8 * cc.constraints(), "circuit_eval_check: mix power table too small");
     ZInv z;
     for (int m = 0; m < 4; ++m) z.v[m] = zinv[m];
     // every committed evaluation is read once (plus the one-row-back taps), the check planes are written once
     OpScope op(c, "eval_check", 4.0 * (double)dom * (cc.wc + cc.wd + cc.J / 4.0 + 2.0 * cc.wa + 4.0));
     BX_CIRCUIT_DISPATCH(eval_check_kernel, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)check.dptr,
                         (const uint32_t*)ecode.dptr, (const uint32_t*)edata.dptr, (const uint32_t*)eacc.dptr, cc, (const uint32_t*)mixpows.dptr,
-                        (const uint32_t*)betas_dev.dptr, z);
+                        (const uint32_t*)mixpows.dptr + 4 * cc.constraints(), (const uint32_t*)betas_dev.dptr, z);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }

@@ -5,10 +5,19 @@
 // bento/crates/workflow/src/tasks/prove.rs:41-49 through Prover::finalize / fri_prove.
 // All of these stream each input word once; they are HBM-bound except batch_evaluate_any and
 // poly_divide, whose Fp4 products make them VALU-bound.
+#define BX_PLAIN_MAD 1  // the signed multiply-adds of lazy_ext.hpp are left to the compiler here (no loop-carried cell state)
 #include "ctx.hpp"
+#include "lazy_ext.hpp"
 
 namespace bx {
 
+struct W4 {  // a centred Fp4 weight
+    i32 c[4];
+};
+__device__ __forceinline__ W4 ldw4(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return W4{{(i32)v.x, (i32)v.y, (i32)v.z, (i32)v.w}};
+}
 __device__ __forceinline__ Fp4 ld4(const uint32_t* p) {
     uint4 v = *reinterpret_cast<const uint4*>(p);
     return Fp4{{v.x, v.y, v.z, v.w}};
@@ -40,7 +49,11 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(uint32_t* __restrict__ ou
 __global__ void mix_prep_kernel(const uint32_t* __restrict__ combos, uint32_t input_size, uint32_t n_combos,
                                 uint32_t* __restrict__ order, uint32_t* __restrict__ starts, uint32_t* __restrict__ pows,
                                 Fp4 mix_start, Fp4 mix) {
-    for (uint32_t i = threadIdx.x; i < input_size; i += blockDim.x) st4(pows + 4 * (size_t)i, f4_mul(mix_start, f4_pow(mix, i)));
+    for (uint32_t i = threadIdx.x; i < input_size; i += blockDim.x) {  // stored centred: the weights of a LazyExtAcc
+        const Fp4 w = f4_mul(mix_start, f4_pow(mix, i));
+        st4(pows + 4 * (size_t)i, Fp4{{(uint32_t)fp_centre_w(w.c[0]), (uint32_t)fp_centre_w(w.c[1]), (uint32_t)fp_centre_w(w.c[2]),
+                                       (uint32_t)fp_centre_w(w.c[3])}});
+    }
     if (threadIdx.x == 0) {
         uint32_t pos = 0;
         for (uint32_t c = 0; c < n_combos; ++c) {
@@ -60,13 +73,46 @@ __global__ __launch_bounds__(256) void mix_poly_kernel(uint32_t* __restrict__ ou
     uint32_t lo = starts[combo], hi = starts[combo + 1];
     if (lo == hi) return;
     uint32_t* o = out + 4 * ((size_t)combo * count + idx);
-    Fp4 acc = ld4(o);
+    LazyExtAcc acc;
+    acc.reset();
     for (uint32_t k = lo; k < hi; ++k) {
-        uint32_t i = order[k];
-        Fp4 w = ld4(pows + 4 * (size_t)i);  // wave-uniform
-        acc = f4_add(acc, f4_scale(w, in[(size_t)i * count + idx]));
+        const uint32_t i = order[k];
+        const W4 w = ldw4(pows + 4 * (size_t)i);  // wave-uniform, centred by mix_prep_kernel
+        acc.add(w.c, in[(size_t)i * count + idx]);
     }
-    st4(o, acc);
+    st4(o, f4_add(ld4(o), acc.finish()));
+}
+// Four consecutive coefficients per thread (one 16-byte load per polynomial, two polynomials in flight): the one-word
+// form above keeps a single 4-byte load per lane in flight and is bound by memory latency (3.0 TB/s on 256 polynomials).
+__global__ __launch_bounds__(256) void mix_poly_x4_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+                                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ starts,
+                                                          const uint32_t* __restrict__ pows, size_t count) {
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (idx >= count) return;
+    const uint32_t combo = blockIdx.y;
+    const uint32_t lo = starts[combo], hi = starts[combo + 1];
+    if (lo == hi) return;
+    LazyExtAcc acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q].reset();
+    uint32_t k = lo;
+    for (; k + 2 <= hi; k += 2) {
+        const uint32_t i0 = order[k], i1 = order[k + 1];
+        const uint4 v0 = *reinterpret_cast<const uint4*>(in + (size_t)i0 * count + idx);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(in + (size_t)i1 * count + idx);
+        const W4 w0 = ldw4(pows + 4 * (size_t)i0), w1 = ldw4(pows + 4 * (size_t)i1);  // wave-uniform
+        acc[0].add(w0.c, v0.x); acc[1].add(w0.c, v0.y); acc[2].add(w0.c, v0.z); acc[3].add(w0.c, v0.w);
+        acc[0].add(w1.c, v1.x); acc[1].add(w1.c, v1.y); acc[2].add(w1.c, v1.z); acc[3].add(w1.c, v1.w);
+    }
+    if (k < hi) {
+        const uint32_t i0 = order[k];
+        const uint4 v0 = *reinterpret_cast<const uint4*>(in + (size_t)i0 * count + idx);
+        const W4 w0 = ldw4(pows + 4 * (size_t)i0);
+        acc[0].add(w0.c, v0.x); acc[1].add(w0.c, v0.y); acc[2].add(w0.c, v0.z); acc[3].add(w0.c, v0.w);
+    }
+    uint32_t* o = out + 4 * ((size_t)combo * count + idx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st4(o + 4 * q, f4_add(ld4(o + 4 * q), acc[q].finish()));
 }
 // ---- batch_evaluate_any ----
 // grid = (segments, evals).  A workgroup evaluates SEG = 256*K consecutive coefficients of polynomial which[e] at x:
@@ -120,21 +166,28 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         }
         __syncthreads();
     }
-    Fp4 acc = f4_zero();
+    // the (x^256)^i table becomes the centred weights of a LazyExtAcc: 10 instead of 32 instructions per coefficient
+    if (tid < EV_K) {
+        const Fp4 w = ld4(ypow + 4 * tid);
+        st4(ypow + 4 * tid, Fp4{{(uint32_t)fp_centre_w(w.c[0]), (uint32_t)fp_centre_w(w.c[1]), (uint32_t)fp_centre_w(w.c[2]),
+                                 (uint32_t)fp_centre_w(w.c[3])}});
+    }
+    __syncthreads();
+    LazyExtAcc lz;
+    lz.reset();
     if (brev_log) {
-#pragma unroll 8
-        for (int i = 0; i < EV_K; ++i)
-            acc = f4_add(acc, f4_scale(ld4(ypow + 4 * (__brev((uint32_t)i) >> 25)), c[(size_t)tid + (size_t)EV_T * i]));
+#pragma unroll 16
+        for (int i = 0; i < EV_K; ++i) lz.add(ldw4(ypow + 4 * (__brev((uint32_t)i) >> 25)).c, c[(size_t)tid + (size_t)EV_T * i]);
     } else if (remaining >= seg_elems) {
-#pragma unroll 8
-        for (int i = 0; i < EV_K; ++i) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[(size_t)tid + (size_t)EV_T * i]));
+#pragma unroll 16
+        for (int i = 0; i < EV_K; ++i) lz.add(ldw4(ypow + 4 * i).c, c[(size_t)tid + (size_t)EV_T * i]);
     } else {
         for (int i = 0; i < EV_K; ++i) {
             size_t j = (size_t)tid + (size_t)EV_T * i;
-            if (j < remaining) acc = f4_add(acc, f4_scale(ld4(ypow + 4 * i), c[j]));
+            if (j < remaining) lz.add(ldw4(ypow + 4 * i).c, c[j]);
         }
     }
-    acc = f4_mul(acc, ld4(xpow + 4 * (brev_log ? (__brev(tid) >> 24) : tid)));
+    Fp4 acc = f4_mul(lz.finish(), ld4(xpow + 4 * (brev_log ? (__brev(tid) >> 24) : tid)));
     __syncthreads();
     st4(xpow + 4 * tid, acc);
     __syncthreads();
@@ -369,8 +422,12 @@ extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t 
     hipLaunchKernelGGL(mix_prep_kernel, dim3(1), dim3(256), 0, c->stream, (const uint32_t*)combos.dptr, (uint32_t)input_size,
                        (uint32_t)n_combos, s + order_off, s + starts_off, s + pows_off, host4(mix_start), host4(mix));
     BX_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(mix_poly_kernel, dim3((unsigned)((count + 255) / 256), (unsigned)n_combos), dim3(256), 0, c->stream,
-                       (uint32_t*)out.dptr, (const uint32_t*)in.dptr, s + order_off, s + starts_off, s + pows_off, count);
+    if (count % 4 == 0 && ((uintptr_t)in.dptr & 15u) == 0)
+        hipLaunchKernelGGL(mix_poly_x4_kernel, dim3((unsigned)((count / 4 + 255) / 256), (unsigned)n_combos), dim3(256), 0, c->stream,
+                           (uint32_t*)out.dptr, (const uint32_t*)in.dptr, s + order_off, s + starts_off, s + pows_off, count);
+    else
+        hipLaunchKernelGGL(mix_poly_kernel, dim3((unsigned)((count + 255) / 256), (unsigned)n_combos), dim3(256), 0, c->stream,
+                           (uint32_t*)out.dptr, (const uint32_t*)in.dptr, s + order_off, s + starts_off, s + pows_off, count);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }

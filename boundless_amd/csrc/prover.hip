@@ -18,12 +18,6 @@ namespace bx {
 
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
 
-__global__ void ext_pows_kernel(uint32_t* __restrict__ out, Fp4 base, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp4 r = f4_pow(base, i);
-    out[4 * i + 0] = r.c[0]; out[4 * i + 1] = r.c[1]; out[4 * i + 2] = r.c[2]; out[4 * i + 3] = r.c[3];
-}
 // beta_e = beta^(floor(e/2)+1): the two accumulators of a pair share their challenge
 __global__ void beta_table_kernel(uint32_t* __restrict__ out, Fp4 beta, uint32_t n) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,7 +240,7 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
     }
     {
         const Circuit& cc = p->cc;
-        BX_TRY(p->mixpows.alloc(c, 4 * (cc.constraints() + 1)));
+        BX_TRY(p->mixpows.alloc(c, 8 * (cc.constraints() + 1)));  // canonical table + centred copy
         BX_TRY(p->perm_offsets.alloc(c, N * (cc.pairs ? cc.pairs : 1)));
         BX_TRY(p->perm_index.alloc(c, N + 1));
         BX_TRY(p->acc_src.alloc(c, N * (cc.E ? cc.E : 1)));
@@ -356,11 +350,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     Group& CK = p->groups[3];
     {
         Fp4 poly_mix = T.random_ext();
-        const uint32_t n_cons = (uint32_t)cc.constraints();
-        if (n_cons) {
-            hipLaunchKernelGGL(ext_pows_kernel, dim3((n_cons + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->mixpows.b.dptr, poly_mix, n_cons);
-            if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: mix power launch failed");
-        }
+        PV(circuit_mix_table(c, cc, p->mixpows.b, poly_mix.c));
         // 1 / ((3x)^N - 1) takes four values on the domain x = w_4N^row: (3x)^N = 3^N w_4^(row mod 4)
         uint32_t zinv[4];
         {

@@ -10,6 +10,7 @@
 #include "fp.hpp"
 #include "poseidon2_arith.hpp"
 #include "circuit_dev.hpp"
+#include "lazy_ext.hpp"
 #include "poseidon2_params.hpp"
 #include "transcript.hpp"
 
@@ -54,7 +55,37 @@ static int check_cons_sum() {
     return 0;
 }
 
+// LazyExtAcc (mix_poly_coeffs, batch_evaluate_any, eval_check's mixing): sum_k w_k * x_k against f4_scale + f4_add, for term
+// counts around every fold boundary, worst-case magnitudes (weights +-P/2, x = P - 1) and random operands
+static int check_lazy_ext_acc() {
+    const int counts[] = {0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 100, 336, 1000};
+    for (int mode = 0; mode < 3; ++mode)
+        for (int n : counts) {
+            LazyExtAcc acc;
+            acc.reset();
+            Fp4 want = f4_zero();
+            for (int k = 0; k < n; ++k) {
+                Fp4 w;
+                uint32_t x;
+                for (int c = 0; c < 4; ++c)
+                    w.c[c] = mode == 0 ? (uint32_t)(rnd64() % P) : ((rnd64() & 1) ? P / 2 : P / 2 + 1);  // centred: +P/2 or -P/2
+                x = mode == 0 ? (uint32_t)(rnd64() % P) : (mode == 1 ? P - 1 : (uint32_t)(rnd64() % 3) * (P / 2));
+                const i32 wc[4] = {fp_centre_w(w.c[0]), fp_centre_w(w.c[1]), fp_centre_w(w.c[2]), fp_centre_w(w.c[3])};
+                acc.add(wc, x);
+                want = f4_add(want, f4_scale(w, x));
+            }
+            const Fp4 got = acc.finish();
+            for (int c = 0; c < 4; ++c)
+                if (got.c[c] != want.c[c] || got.c[c] >= P) {
+                    fprintf(stderr, "LazyExtAcc mismatch: mode %d, %d terms, component %d\n", mode, n, c);
+                    return 1;
+                }
+        }
+    return 0;
+}
+
 int main() {
+    if (check_lazy_ext_acc()) return 1;
     if (check_cons_sum<64, 4>() || check_cons_sum<48, 3>() || check_cons_sum<16, 3>() || check_cons_sum<32, 3>() || check_cons_sum<8, 2>() || check_cons_sum<5, 1>() ||
         check_cons_sum<7, 4>() || check_cons_sum<64, 5>() || check_cons_sum<1, 1>() || check_cons_sum<25, 2>())
         return 1;

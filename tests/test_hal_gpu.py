@@ -340,7 +340,7 @@ def test_fri_fold_golden(hal, golden_dir):
     assert got == g["out_natural"]
 
 
-@pytest.mark.parametrize("count,npoly,ncombo", [(64, 5, 2), (1000, 33, 4), (1 << 14, 16, 3)])
+@pytest.mark.parametrize("count,npoly,ncombo", [(64, 5, 2), (1000, 33, 4), (1 << 14, 16, 3), (1001, 9, 3), (6, 4, 2), (4, 1, 1), (1 << 12, 35, 3)])
 def test_mix_poly_coeffs_vs_oracle(hal, oracle, count, npoly, ncombo):
     rng = np.random.default_rng(count)
     inp = rnd(count + 1, npoly * count)
