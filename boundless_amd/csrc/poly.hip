@@ -238,7 +238,11 @@ __global__ void gather_sample_kernel(uint32_t* __restrict__ dst, const uint32_t*
 // ---- poly_divide: q_{i-1} = p_i + z q_i (top down), in place; remainder = p_0 + z q_0 ----
 // Three phases over chunks of DIV_L coefficients: (1) each chunk's carry-out assuming zero carry-in,
 // (2) sequential composition of the chunk maps carry -> local + z^L * carry (one workgroup), (3) replay.
-constexpr int DIV_L = 64;
+// The phases nest: the chunk values are themselves an array to be divided by (x - z^L) — "the carry entering chunk ch" is
+// that division's quotient coefficient — so arrays longer than DIV_DIRECT recurse with chunks of DIV_L and the one-workgroup
+// kernel only ever sees <= DIV_DIRECT entries (2^20 -> 2^15 -> 2^10: five launches, 123 -> 40 us per 2^20 coefficients).
+constexpr int DIV_L = 32;
+constexpr size_t DIV_DIRECT = 2048;
 __global__ void div_local_kernel(const uint32_t* __restrict__ poly, size_t size, Fp4 z, uint32_t* __restrict__ local,
                                  size_t chunks) {
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,21 +303,23 @@ __global__ void div_apply_kernel(uint32_t* __restrict__ poly, size_t size, Fp4 z
 
 // ---- prefix_products: inclusive running product of ext elements, same three-phase shape as poly_divide ----
 constexpr int PP_L = 64;
+constexpr size_t PP_DIRECT = 2048;
 // blockIdx.y = sequence of a batch (each with its own n elements of io and `chunks` aggregates)
-__global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, uint32_t* __restrict__ agg, size_t chunks) {
+__global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, size_t seq_stride, uint32_t* __restrict__ agg, size_t chunks,
+                                size_t agg_stride) {
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= chunks) return;
-    io += 4 * n * blockIdx.y;
-    agg += 4 * chunks * blockIdx.y;
+    io += 4 * seq_stride * blockIdx.y;
+    agg += 4 * agg_stride * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = f4_one();
     for (size_t i = lo; i < hi; ++i) p = f4_mul(p, ld4(io + 4 * i));
     st4(agg + 4 * ch, p);
 }
 // agg[ch] <- product of all chunks before ch (exclusive scan), one workgroup, log-step scan across threads
-__global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks) {
+__global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks, size_t agg_stride) {
     extern __shared__ uint32_t sh[];
-    agg += 4 * chunks * blockIdx.x;
+    agg += 4 * agg_stride * blockIdx.x;
     const uint32_t nt = blockDim.x, tid = threadIdx.x;
     size_t per = (chunks + nt - 1) / nt;
     size_t lo = (size_t)tid * per < chunks ? (size_t)tid * per : chunks;
@@ -334,6 +340,21 @@ __global__ void pp_scan_kernel(uint32_t* __restrict__ agg, size_t chunks) {
         Fp4 a = ld4(agg + 4 * ch);
         st4(agg + 4 * ch, carry);
         carry = f4_mul(carry, a);
+    }
+}
+// exclusive form for the inner levels: io[i] <- carry * prod_{lo <= k < i} io[k]
+__global__ void pp_apply_excl_kernel(uint32_t* __restrict__ io, size_t n, size_t seq_stride, const uint32_t* __restrict__ carry_in,
+                                     size_t chunks, size_t carry_stride) {
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= chunks) return;
+    io += 4 * seq_stride * blockIdx.y;
+    carry_in += 4 * carry_stride * blockIdx.y;
+    size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
+    Fp4 p = ld4(carry_in + 4 * ch);
+    for (size_t i = lo; i < hi; ++i) {
+        const Fp4 a = ld4(io + 4 * i);
+        st4(io + 4 * i, p);
+        p = f4_mul(p, a);
     }
 }
 __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint32_t* __restrict__ carry_in, size_t chunks) {
@@ -517,6 +538,34 @@ extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_
     return nullptr;
 }
 
+// in-place division of the AoS ext array `arr` (n entries) by (x - z); `scratch` has room for every level's chunk values
+static const char* divide_rec(bx_ctx* c, uint32_t* arr, size_t n, Fp4 z, uint32_t* scratch, uint32_t* rem) {
+    if (n <= DIV_DIRECT) {
+        // one workgroup: thread t owns a run of entries; the "chunk" multiplier of the kernel is z itself here
+        unsigned nt = n >= 1024 ? 1024 : 64;
+        hipLaunchKernelGGL(div_scan_kernel, dim3(1), dim3(nt), nt * 32, c->stream, arr, n, z, rem);
+        BX_LAUNCH_CHECK(c);
+        return nullptr;
+    }
+    const size_t chunks = (n + DIV_L - 1) / DIV_L;
+    hipLaunchKernelGGL(div_local_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)arr, n, z, scratch,
+                       chunks);
+    BX_LAUNCH_CHECK(c);
+    BX_TRY(divide_rec(c, scratch, chunks, f4_pow(z, DIV_L), scratch + 4 * chunks, rem));  // chunk values -> carries entering the chunks
+    hipLaunchKernelGGL(div_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, arr, n, z, (const uint32_t*)scratch,
+                       chunks);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+static size_t scan_scratch_words(size_t n, size_t L, size_t direct, size_t count) {
+    size_t words = 8;
+    while (n > direct) {
+        n = (n + L - 1) / L;
+        words += 4 * n * count;
+    }
+    return words;
+}
+
 extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4], bx_buf rem_out) {
     if (!c) return "bx_poly_divide: null ctx";
     BX_REQUIRE(c, poly.len % 4 == 0 && rem_out.len >= 4, "poly_divide: poly must be AoS ext, remainder buffer >= 4 words");
@@ -524,18 +573,25 @@ extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4
     size_t size = poly.len / 4;
     if (!size) return nullptr;
     OpScope op(c, "poly_divide", 8.0 * (double)poly.len);
-    size_t chunks = (size + DIV_L - 1) / DIV_L;
-    BX_TRY(ensure_scratch(c, 4 * chunks + 8));
-    Fp4 zz = host4(z);
-    Fp4 zL = f4_pow(zz, DIV_L);
-    hipLaunchKernelGGL(div_local_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream,
-                       (const uint32_t*)poly.dptr, size, zz, c->d_scratch, chunks);
+    BX_TRY(ensure_scratch(c, scan_scratch_words(size, DIV_L, DIV_DIRECT, 1)));
+    return divide_rec(c, (uint32_t*)poly.dptr, size, host4(z), c->d_scratch, (uint32_t*)rem_out.dptr);
+}
+
+// exclusive running products, in place, of `count` sequences of n entries (sequence k at arr + 4 * k * stride)
+static const char* excl_scan_rec(bx_ctx* c, uint32_t* arr, size_t n, size_t stride, size_t count, uint32_t* scratch) {
+    if (n <= PP_DIRECT) {
+        unsigned nt = n >= 1024 ? 1024 : 64;
+        hipLaunchKernelGGL(pp_scan_kernel, dim3((unsigned)count), dim3(nt), nt * 16, c->stream, arr, n, stride);
+        BX_LAUNCH_CHECK(c);
+        return nullptr;
+    }
+    const size_t chunks = (n + PP_L - 1) / PP_L;
+    hipLaunchKernelGGL(pp_local_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream, (const uint32_t*)arr, n,
+                       stride, scratch, chunks, chunks);
     BX_LAUNCH_CHECK(c);
-    unsigned nt = chunks >= 1024 ? 1024 : (chunks >= 64 ? 64 : 64);
-    hipLaunchKernelGGL(div_scan_kernel, dim3(1), dim3(nt), nt * 32, c->stream, c->d_scratch, chunks, zL, (uint32_t*)rem_out.dptr);
-    BX_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(div_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)poly.dptr,
-                       size, zz, c->d_scratch, chunks);
+    BX_TRY(excl_scan_rec(c, scratch, chunks, chunks, count, scratch + 4 * chunks * count));
+    hipLaunchKernelGGL(pp_apply_excl_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream, arr, n, stride,
+                       (const uint32_t*)scratch, chunks, chunks);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
@@ -549,14 +605,13 @@ extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t cou
     size_t n = io.len / 4 / count;
     if (n < 2) return nullptr;
     OpScope op(c, "prefix_products", 8.0 * (double)io.len);
+    // chunk products -> exclusive scan of them (recursively, PP_L per level) -> inclusive replay of every chunk with its carry
     size_t chunks = (n + PP_L - 1) / PP_L;
-    BX_TRY(ensure_scratch(c, 4 * chunks * count + 8));
+    BX_TRY(ensure_scratch(c, 4 * chunks * count + scan_scratch_words(chunks, PP_L, PP_DIRECT, count)));
     hipLaunchKernelGGL(pp_local_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream,
-                       (const uint32_t*)io.dptr, n, c->d_scratch, chunks);
+                       (const uint32_t*)io.dptr, n, n, c->d_scratch, chunks, chunks);
     BX_LAUNCH_CHECK(c);
-    unsigned nt = chunks >= 1024 ? 1024 : 64;
-    hipLaunchKernelGGL(pp_scan_kernel, dim3((unsigned)count), dim3(nt), nt * 16, c->stream, c->d_scratch, chunks);
-    BX_LAUNCH_CHECK(c);
+    BX_TRY(excl_scan_rec(c, c->d_scratch, chunks, chunks, count, c->d_scratch + 4 * chunks * count));
     hipLaunchKernelGGL(pp_apply_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)count), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n,
                        c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);

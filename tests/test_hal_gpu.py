@@ -420,7 +420,7 @@ def test_batch_bit_reverse_ext(hal, n, count):
     assert np.array_equal(buf.view(), data)
 
 
-@pytest.mark.parametrize("size", [1, 5, 64, 100, 4096, 1 << 16, 1 << 20])
+@pytest.mark.parametrize("size", [1, 5, 64, 100, 2047, 2048, 2049, 4096, 65535, 1 << 16, (1 << 16) + 33, 1 << 20, (1 << 21) + 7])
 def test_poly_divide_vs_oracle(hal, oracle, size):
     poly = rnd(size, 4 * size)
     z = rnd(17, 4)
@@ -469,7 +469,7 @@ def test_eltwise_and_gather(hal, oracle):
         hal.gather_sample(g, hal.copy_from(a), 5, 17, 1000)  # out of range
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4096, 1 << 16, (1 << 18) + 3])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 1000, 2048, 2049, 4096, 65537, 1 << 16, (1 << 18) + 3, 1 << 20, (1 << 21) + 5])
 def test_prefix_products_vs_oracle(hal, oracle, n):
     x = rnd(n, 4 * n)
     buf = hal.copy_from(x)
@@ -515,7 +515,7 @@ def test_scatter_vs_oracle(hal, oracle):
     assert np.array_equal(dst2.view(), ref2)
 
 
-@pytest.mark.parametrize("n,count", [(2, 3), (64, 2), (1000, 5), (4096, 16), ((1 << 16) + 1, 3)])
+@pytest.mark.parametrize("n,count", [(2, 3), (64, 2), (1000, 5), (2049, 4), (4096, 16), ((1 << 16) + 1, 3), (65537, 2), (1 << 20, 3)])
 def test_batch_prefix_products_vs_oracle(hal, oracle, n, count):
     """`count` independent sequences back to back (the accumulate step's shape): each equals the single-sequence result."""
     x = rnd(n + count, 4 * n * count)
