@@ -5,12 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one synthetic 2^20-cycle segment per rank (BASELINE.json configs[1]:
-"single 2^20-cycle segment on 1xMI355X via new HIP HAL (NTT+Poseidon2+FRI)"): witness fill -> 3 trace-group commits
-(iNTT, zk_shift, 4x LDE, Poseidon2 Merkle) -> check-polynomial commit -> DEEP taps/mix/divide -> FRI (3 rounds) ->
-50 queries -> seal, all through include/bx_prover.h.  Segments are independent, so ranks shard them with no
-data-path collective ("scaling": "weak"); torch.distributed (RCCL) only provides the barriers and the max-over-ranks.
-Inputs are generated on the device (no host buffers cross PCIe in the timed region except the seal and the
+A "step" = one pass of the hot path over one synthetic 2^20-cycle segment per lane and rank (BASELINE.json configs[1]:
+"single 2^20-cycle segment on 1xMI355X via new HIP HAL (NTT+Poseidon2+FRI)"): witness generation (free cells, scatter-placed
+permuted copies, derived columns) -> code/data commits (iNTT, zk_shift, 4x LDE, Poseidon2 Merkle) -> accumulate
+(prefix_products) -> accum commit -> eval_check over the 4N domain -> check commit -> DEEP taps/mix/divide -> FRI (3 rounds) ->
+50 queries -> seal, all through include/bx_prover.h.  The circuit is the SYNTHETIC AIR of include/bx_prover.h (not rv32im: the
+generated circuit is not in the reference tree), so `value` is the rate of complete STARK proofs of that circuit and is not
+comparable to upstream's effective kHz; `config.circuit` says what is and is not included.  Segments are independent, so ranks
+shard them with no data-path collective ("scaling": "weak"); torch.distributed (RCCL) only provides the barriers and the
+max-over-ranks.  Inputs are generated on the device (no host buffers cross PCIe in the timed region except the seal and the
 Fiat-Shamir digests, exactly as in the reference's prover).
 
 By default three segments are in flight per GPU (one prover, stream and host thread each): the others fill the
@@ -24,7 +27,7 @@ The JSON line also carries
                 in-region durations; `roofline_in_region` is the concurrent figure;
   kernels       the same for every HAL entry point in the timed region;
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
-                box's host cores on a bounded sample.
+                box's host cores: one proof of the metric's own size (2^20, ~40 s), thread count chosen on a small probe.
 """
 import argparse
 import json
@@ -363,6 +366,10 @@ def main():
         circ_ms = sum(src_c[k]["ms_per_step"] for k in circ_ops if k in src_c)
         all_ms = sum(v["ms_per_step"] for v in src_c.values())
         circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: no image id / claim / ZK blinding; lift is not included",
+                        "included": ["witness generation (synthetic)", "accumulate (prefix_products)", "eval_check (synthetic constraints / vanishing polynomial)",
+                                     "3 trace commits + check commit", "DEEP", "FRI", "50 queries"],
+                        "excluded": ["rv32im preflight/witgen/eval_check (generated code, not in the reference tree)", "lift (recursion circuit)",
+                                     "ZK blinding rows", "CPU verification of the seal (reported in agent_mode)"],
                         "terms": int(receipt.seal[4]), "degree": int(receipt.seal[5]),
                         "stages_ms_per_segment": {k: src_c[k]["ms_per_step"] for k in circ_ops if k in src_c},
                         "share_of_gpu_time": round(circ_ms / all_ms, 3) if all_ms else None}
