@@ -66,22 +66,34 @@ __global__ __launch_bounds__(256) void witness_derive_kernel(uint32_t* __restric
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const uint32_t rb = (r + n - 1) & (n - 1);
-    uint32_t ring[4];
+    // rings: the eight previous derived columns (csel(0..7) before the first), free columns j, j+1, j+2, code csel(j..j+3)
+    const auto code_at = [&](unsigned i) -> uint32_t {
+        const int col = cc.csel_col(i);
+        return col < 0 ? MONT_ONE : code[(size_t)col * n + r];
+    };
+    uint32_t ring[8], u[3], k[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int col = cc.csel_col((unsigned)q);
-        ring[q] = col < 0 ? MONT_ONE : code[(size_t)col * n + r];
-    }
+    for (int q = 0; q < 8; ++q) ring[q] = code_at((unsigned)q);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) u[q] = data[(size_t)((uint32_t)q % cc.F) * n + r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = code_at((unsigned)q);
     for (uint32_t j = 0; j < cc.J; ++j) {
         uint32_t pool[Circuit::POOL];
-        pool[0] = data[(size_t)j * n + r];
-        pool[1] = (j & 3u) == 0 ? data[(size_t)j * n + rb] : pool[0];
-        pool[2] = ring[0]; pool[3] = ring[1]; pool[4] = ring[2]; pool[5] = ring[3];
-        const int ck = cc.csel_col(j);
-        pool[6] = ck < 0 ? MONT_ONE : code[(size_t)ck * n + r];
+        pool[0] = u[0];
+        pool[1] = (j & 3u) == 0 ? data[(size_t)j * n + rb] : u[0];
+        pool[2] = u[1]; pool[3] = u[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pool[4 + q] = ring[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pool[12 + q] = k[q];
         const uint32_t d = cons_sum<TT, GG>(pool, cc.T, cc.G);
         data[(size_t)(cc.F + j) * n + r] = d;
-        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = d;
+#pragma unroll
+        for (int q = 7; q > 0; --q) ring[q] = ring[q - 1];
+        ring[0] = d;
+        u[0] = u[1]; u[1] = u[2]; u[2] = data[(size_t)((j + 3) % cc.F) * n + r];
+        k[0] = k[1]; k[1] = k[2]; k[2] = k[3]; k[3] = code_at(j + 4);
     }
 }
 
@@ -136,25 +148,36 @@ __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ 
     const uint32_t ib = (i + dom - 4u) & (dom - 1u);  // one row back: x * w_N^-1 = w_4N^(row - 4)
     LazyExtAcc mixacc;  // sum_j poly_mix^j * C_j over the derived-column constraints (ext weight x base value)
     mixacc.reset();
-    uint32_t ring[4];
+    const auto code_at = [&](unsigned q) -> uint32_t {
+        const int col = cc.csel_col(q);
+        return col < 0 ? MONT_ONE : ecode[(size_t)col * dom + i];
+    };
+    uint32_t ring[8], u[3], k[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int col = cc.csel_col((unsigned)q);
-        ring[q] = col < 0 ? MONT_ONE : ecode[(size_t)col * dom + i];
-    }
+    for (int q = 0; q < 8; ++q) ring[q] = code_at((unsigned)q);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) u[q] = edata[(size_t)((uint32_t)q % cc.F) * dom + i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = code_at((unsigned)q);
     for (uint32_t j = 0; j < cc.J; ++j) {
         uint32_t pool[Circuit::POOL];
-        pool[0] = edata[(size_t)j * dom + i];
-        pool[1] = (j & 3u) == 0 ? edata[(size_t)j * dom + ib] : pool[0];
-        pool[2] = ring[0]; pool[3] = ring[1]; pool[4] = ring[2]; pool[5] = ring[3];
-        const int ck = cc.csel_col(j);
-        pool[6] = ck < 0 ? MONT_ONE : ecode[(size_t)ck * dom + i];
+        pool[0] = u[0];
+        pool[1] = (j & 3u) == 0 ? edata[(size_t)j * dom + ib] : u[0];
+        pool[2] = u[1]; pool[3] = u[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pool[4 + q] = ring[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pool[12 + q] = k[q];
         const uint32_t d = edata[(size_t)(cc.F + j) * dom + i];
         const uint32_t cons = fp_sub(d, cons_sum<TT, GG>(pool, cc.T, cc.G));
         const uint4 m = *reinterpret_cast<const uint4*>(mixpows_c + 4 * (size_t)j);  // wave-uniform, centred
         const i32 w[4] = {(i32)m.x, (i32)m.y, (i32)m.z, (i32)m.w};
         mixacc.add(w, cons);
-        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = d;
+#pragma unroll
+        for (int q = 7; q > 0; --q) ring[q] = ring[q - 1];
+        ring[0] = d;
+        u[0] = u[1]; u[1] = u[2]; u[2] = edata[(size_t)((j + 3) % cc.F) * dom + i];
+        k[0] = k[1]; k[1] = k[2]; k[2] = k[3]; k[3] = code_at(j + 4);
     }
     Fp4 tot = mixacc.finish();
     const uint32_t first = ecode[i];

@@ -17,7 +17,14 @@
 namespace bx {
 
 struct Circuit {
-    static constexpr unsigned POOL = 7;  // u, u one row back, the four previous derived columns, a code column
+    // pool of a derived column: [0] free column j, [1] the same one row back (when it has that tap), [2] [3] free columns
+    // j+1, j+2 (mod F), [4..11] the eight previous derived columns, [12..15] code columns csel(j..j+3)
+    static constexpr unsigned POOL = 16;
+    struct Src {
+        int group;      // 0 code, 1 data, -1 = the constant one
+        uint32_t col;
+        int back;       // 0 = this row, 1 = one row back
+    };
     uint32_t po2, wc, wd, wa, T, G;
     uint32_t F, J, E, pairs;
     Circuit() = default;
@@ -32,7 +39,21 @@ struct Circuit {
         if (wc < 2) pairs = 0;  // the closing constraint needs the `last` selector (code column 1)
     }
     size_t constraints() const { return (size_t)J + E + pairs; }
-    BX_CIRC_HD static constexpr unsigned pool_idx(unsigned t, unsigned f) { return (3 * t + t / 7 + f * (2 * (t % 3) + 1)) % POOL; }
+    BX_CIRC_HD static constexpr unsigned pool_idx(unsigned t, unsigned f) { return (7 * t + 3 * f + (t >> 2) * f + (t >> 4)) & 15u; }
+    // where pool entry `slot` of derived column j comes from
+    BX_CIRC_HD Src pool_src(uint32_t j, unsigned slot) const {
+        if (slot == 0) return Src{1, j, 0};
+        if (slot == 1) return Src{1, j, (j & 3u) == 0 ? 1 : 0};
+        if (slot <= 3) return Src{1, (j + slot - 1) % F, 0};
+        if (slot <= 11) {
+            const uint32_t s = slot - 3;  // 1..8
+            if (j >= s) return Src{1, F + j - s, 0};
+            const int c = csel_col(s - j - 1);
+            return c < 0 ? Src{-1, 0, 0} : Src{0, (uint32_t)c, 0};
+        }
+        const int c = csel_col(j + slot - 12);
+        return c < 0 ? Src{-1, 0, 0} : Src{0, (uint32_t)c, 0};
+    }
     // code column behind csel(i), or -1 for the constant one (fewer than three code columns)
     BX_CIRC_HD int csel_col(unsigned i) const { return wc >= 3 ? (int)(2 + i % (wc - 2)) : -1; }
     // data column accumulator e runs over

@@ -215,6 +215,10 @@ __global__ void eltwise_add_kernel(uint32_t* __restrict__ out, const uint32_t* a
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fp_add(a[i], b[i]);
 }
+__global__ void eltwise_mul_factor_kernel(uint32_t* __restrict__ io, uint32_t factor, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) io[i] = fp_mul(io[i], factor);
+}
 __global__ void eltwise_zeroize_kernel(uint32_t* __restrict__ io, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -496,6 +500,16 @@ extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_b
     OpScope op(c, "eltwise_add_elem", 12.0 * (double)out.len);
     hipLaunchKernelGGL(eltwise_add_kernel, dim3(grid1d(out.len)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
                        (const uint32_t*)a.dptr, (const uint32_t*)b.dptr, out.len);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t factor_mont) {
+    if (!c) return "bx_eltwise_mul_factor: null ctx";
+    BX_REQUIRE(c, factor_mont < P, "eltwise_mul_factor: factor is not a canonical Montgomery word");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!io.len) return nullptr;
+    OpScope op(c, "eltwise_mul_factor", 8.0 * (double)io.len);
+    hipLaunchKernelGGL(eltwise_mul_factor_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, factor_mont, io.len);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }

@@ -183,17 +183,13 @@ void verify(const uint32_t* seal, size_t words) {
             }
             return f4_add(ld(w), f4_mul(ld(w + 4), back ? Zb : Z));  // u(x) = c0 + c1 x
         };
-        auto csel = [&](unsigned i) -> Fp4 {
-            int col = cc.csel_col(i);
-            return col < 0 ? f4_one() : at(0, (uint32_t)col, 0);
-        };
         Fp4 rhs = f4_zero(), cur = f4_one();
         for (uint32_t j = 0; j < cc.J; ++j) {
             Fp4 pool[Circuit::POOL];
-            pool[0] = at(1, j, 0);
-            pool[1] = j % 4 == 0 ? at(1, j, 1) : pool[0];
-            for (uint32_t s = 1; s <= 4; ++s) pool[1 + s] = j >= s ? at(1, cc.F + j - s, 0) : csel(s - j - 1);
-            pool[6] = csel(j);
+            for (unsigned slot = 0; slot < Circuit::POOL; ++slot) {
+                const Circuit::Src src = cc.pool_src(j, slot);
+                pool[slot] = src.group < 0 ? f4_one() : at(src.group, src.col, src.back);
+            }
             Fp4 sum = f4_zero();
             for (uint32_t t = 0; t < cc.T; ++t) {
                 Fp4 prod = pool[Circuit::pool_idx(t, 0)];

@@ -89,6 +89,7 @@ def load_library():
         "bx_eltwise_sum_extelem": [ctx, BxBuf, BxBuf],
         "bx_gather_sample": [ctx, BxBuf, BxBuf, sz, sz, sz],
         "bx_poly_divide": [ctx, BxBuf, u32p, BxBuf],
+        "bx_eltwise_mul_factor": [ctx, BxBuf, C.c_uint32],
         "bx_prefix_products": [ctx, BxBuf],
         "bx_batch_prefix_products": [ctx, BxBuf, sz],
         "bx_scatter": [ctx, BxBuf, BxBuf, BxBuf, BxBuf],
@@ -287,6 +288,9 @@ class HipHal:
 
     def eltwise_sum_extelem(self, output, inp):
         self._check(self.lib.bx_eltwise_sum_extelem(self.ctx, output.raw, inp.raw))
+
+    def eltwise_mul_factor(self, io, factor_mont):
+        self._check(self.lib.bx_eltwise_mul_factor(self.ctx, io.raw, int(factor_mont)))
 
     def gather_sample(self, dst, src, idx, size, stride):
         self._check(self.lib.bx_gather_sample(self.ctx, dst.raw, src.raw, idx, size, stride))

@@ -128,6 +128,8 @@ const char* bx_eltwise_add_elem(bx_ctx* ctx, bx_buf out, bx_buf a, bx_buf b);
 const char* bx_eltwise_copy_elem(bx_ctx* ctx, bx_buf out, bx_buf in);
 const char* bx_eltwise_zeroize_elem(bx_ctx* ctx, bx_buf io);
 const char* bx_eltwise_sum_extelem(bx_ctx* ctx, bx_buf out, bx_buf in_ext);
+/* the CUDA HAL's eltwise_mul_factor_fp kernel (risc0-sys): io[i] *= factor, factor a Montgomery word */
+const char* bx_eltwise_mul_factor(bx_ctx* ctx, bx_buf io, uint32_t factor_mont);
 /* Hal::gather_sample(dst, src, idx, size, stride): dst[i] = src[idx + i*stride] */
 const char* bx_gather_sample(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride);
 /* Hal::prefix_products(io): io[i] = io[i] * io[i-1] over AoS ext elements (inclusive running product; the circuit's

@@ -96,7 +96,7 @@ static uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
 /* ---- the synthetic circuit (include/bx_prover.h, "The synthetic circuit") ---- */
 #define DEFAULT_TERMS 64
 #define DEFAULT_DEGREE 4
-#define POOL 7
+#define POOL 16
 typedef struct {
     uint32_t po2, wc, wd, wa, T, G;
     size_t n;
@@ -115,7 +115,7 @@ static void circ_init(circ_t* c, uint32_t po2, uint32_t wc, uint32_t wd, uint32_
     if (wc < 2) c->pairs = 0; /* the closing constraint needs the `last` selector */
 }
 /* which pool entry is factor f of term t */
-static unsigned pool_idx(unsigned t, unsigned f) { return (3 * t + t / 7 + f * (2 * (t % 3) + 1)) % POOL; }
+static unsigned pool_idx(unsigned t, unsigned f) { return (7 * t + 3 * f + (t >> 2) * f + (t >> 4)) & 15u; }
 /* code column standing behind csel(i); -1 = the constant one */
 static int csel_col(const circ_t* c, unsigned i) { return c->wc >= 3 ? (int)(2 + i % (c->wc - 2)) : -1; }
 /* data column an accumulator runs over */
@@ -270,18 +270,24 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                 uint32_t* out = w + (size_t)(cc.F + j) * n;
                 _Pragma("omp parallel for schedule(static) num_threads(bxo_get_threads())")
                 for (size_t r = 0; r < n; r++) {
+                    /* pool: free column j, the same one row back, free columns j+1 and j+2, the eight previous derived
+                     * columns (control columns before the first), control columns csel(j..j+3) */
                     uint32_t pool[POOL];
                     pool[0] = w[(size_t)j * n + r];
                     pool[1] = j % 4 == 0 ? w[(size_t)j * n + (r + n - 1) % n] : pool[0];
-                    for (uint32_t s_ = 1; s_ <= 4; s_++) {
-                        if (j >= s_) pool[1 + s_] = w[(size_t)(cc.F + j - s_) * n + r];
+                    pool[2] = w[(size_t)((j + 1) % cc.F) * n + r];
+                    pool[3] = w[(size_t)((j + 2) % cc.F) * n + r];
+                    for (uint32_t s_ = 1; s_ <= 8; s_++) {
+                        if (j >= s_) pool[3 + s_] = w[(size_t)(cc.F + j - s_) * n + r];
                         else {
                             int cs = csel_col(&cc, s_ - j - 1);
-                            pool[1 + s_] = cs < 0 ? bxo_fp_encode(1) : code_w[(size_t)cs * n + r];
+                            pool[3 + s_] = cs < 0 ? bxo_fp_encode(1) : code_w[(size_t)cs * n + r];
                         }
                     }
-                    int ck = csel_col(&cc, j);
-                    pool[6] = ck < 0 ? bxo_fp_encode(1) : code_w[(size_t)ck * n + r];
+                    for (uint32_t q = 0; q < 4; q++) {
+                        int ck = csel_col(&cc, j + q);
+                        pool[12 + q] = ck < 0 ? bxo_fp_encode(1) : code_w[(size_t)ck * n + r];
+                    }
                     uint32_t sum = 0;
                     for (uint32_t t = 0; t < cc.T; t++) {
                         uint32_t prod = pool[pool_idx(t, 0)];
@@ -366,15 +372,19 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                 uint32_t pool[POOL];
                 pool[0] = edata[(size_t)j * dom + i];
                 pool[1] = j % 4 == 0 ? edata[(size_t)j * dom + ib] : pool[0];
-                for (uint32_t s_ = 1; s_ <= 4; s_++) {
-                    if (j >= s_) pool[1 + s_] = edata[(size_t)(cc.F + j - s_) * dom + i];
+                pool[2] = edata[(size_t)((j + 1) % cc.F) * dom + i];
+                pool[3] = edata[(size_t)((j + 2) % cc.F) * dom + i];
+                for (uint32_t s_ = 1; s_ <= 8; s_++) {
+                    if (j >= s_) pool[3 + s_] = edata[(size_t)(cc.F + j - s_) * dom + i];
                     else {
                         int cs = csel_col(&cc, s_ - j - 1);
-                        pool[1 + s_] = cs < 0 ? one : ecode[(size_t)cs * dom + i];
+                        pool[3 + s_] = cs < 0 ? one : ecode[(size_t)cs * dom + i];
                     }
                 }
-                int ck = csel_col(&cc, j);
-                pool[6] = ck < 0 ? one : ecode[(size_t)ck * dom + i];
+                for (uint32_t q = 0; q < 4; q++) {
+                    int ck = csel_col(&cc, j + q);
+                    pool[12 + q] = ck < 0 ? one : ecode[(size_t)ck * dom + i];
+                }
                 uint32_t sum = 0;
                 for (uint32_t t = 0; t < cc.T; t++) {
                     uint32_t prod = pool[pool_idx(t, 0)];

@@ -469,6 +469,24 @@ def test_eltwise_and_gather(hal, oracle):
         hal.gather_sample(g, hal.copy_from(a), 5, 17, 1000)  # out of range
 
 
+def test_eltwise_mul_factor(hal, oracle):
+    n = 100003
+    x = rnd(5, n)
+    f = int(rnd(6, 1)[0])
+    buf = hal.copy_from(x)
+    hal.eltwise_mul_factor(buf, f)
+    want = np.array([oracle.bxo_fp_mul(int(v), f) for v in x[:2000]], dtype=np.uint32)
+    got = buf.view()
+    assert np.array_equal(got[:2000], want)
+    # whole array through the field definition (Montgomery product = a * b * 2^-32 mod P)
+    rinv = pow(1 << 32, -1, P)
+    assert np.array_equal(got, ((x.astype(object) * f * rinv) % P).astype(np.uint32))
+    from boundless_amd.hal import HalError
+
+    with pytest.raises(HalError):
+        hal.eltwise_mul_factor(buf, P)
+
+
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 1000, 2048, 2049, 4096, 65537, 1 << 16, (1 << 18) + 3, 1 << 20, (1 << 21) + 5])
 def test_prefix_products_vs_oracle(hal, oracle, n):
     x = rnd(n, 4 * n)
