@@ -148,6 +148,11 @@ extern "C" const char* bx_device_name(bx_ctx* c, char* out, size_t cap) {
     return nullptr;
 }
 
+// Hal::get_hash_suite / Hal::has_unified_memory: the one suite this HAL implements is the reference's default `poseidon2`
+// (ProverOpts::default(), bento/crates/workflow/src/lib.rs:246-249); MI355X HBM is not host-coherent unified memory.
+extern "C" const char* bx_hash_suite_name(void) { return "poseidon2"; }
+extern "C" int bx_has_unified_memory(bx_ctx*) { return 0; }
+
 extern "C" const char* bx_set_stream(bx_ctx* c, void* s) {
     if (!c) return "bx_set_stream: null ctx";
     BX_HIP(c, hipStreamSynchronize(c->stream));

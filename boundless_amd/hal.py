@@ -321,10 +321,12 @@ class HipHal:
         return rc, d
 
     def get_hash_suite(self):
-        return "poseidon2"
+        self.lib.bx_hash_suite_name.restype = C.c_char_p
+        return self.lib.bx_hash_suite_name().decode()
 
     def has_unified_memory(self):
-        return False
+        self.lib.bx_has_unified_memory.argtypes, self.lib.bx_has_unified_memory.restype = [C.c_void_p], C.c_int
+        return bool(self.lib.bx_has_unified_memory(self.ctx))
 
     # ---- measurement ----
     def timer_start(self):

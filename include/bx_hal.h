@@ -67,6 +67,9 @@ const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
 const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */
 const char* bx_d2d(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t words);
 const char* bx_sync(bx_ctx* ctx);
+/* Hal::get_hash_suite (its name: "poseidon2", the reference's default hashfn) and Hal::has_unified_memory (0). */
+const char* bx_hash_suite_name(void);
+int bx_has_unified_memory(bx_ctx* ctx);
 
 /* ---- Hal NTT family ---- */
 /* Hal::batch_interpolate_ntt(io, count): `count` polys of size io.len/count, natural-order evaluations ->

@@ -155,7 +155,7 @@ def _run_bench_two_ranks_on_one_gpu(extra, dump, timeout=900):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
-           "--steal", "--no-cpu-baseline", "--no-agent-mode", "--dump", dump] + extra
+           "--no-cpu-baseline", "--no-agent-mode", "--dump", dump] + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -169,11 +169,31 @@ def test_work_stolen_batch_over_two_ranks_is_bit_exact(tmp_path):
     from boundless_amd.prover import Segment
 
     po2, batch = 12, 8
-    out, dumps = _run_bench_two_ranks_on_one_gpu(["--batch", str(batch), "--po2", str(po2), "--widths", "4,12,4", "--warmup", "1",
+    out, dumps = _run_bench_two_ranks_on_one_gpu(["--steal", "--batch", str(batch), "--po2", str(po2), "--widths", "4,12,4", "--warmup", "1",
                                                   "--steps", "1", "--inflight", "2"], str(tmp_path))
     assert out["n_gpus"] == 2 and out["config"]["segments_proved"] == batch
     a, b = dumps[0]["indices"].tolist(), dumps[1]["indices"].tolist()
     assert sorted(a + b) == list(range(batch)) and not set(a) & set(b), (a, b)
+    for k in (0, 1):
+        for i in dumps[k]["indices"].tolist():
+            want, _ = ol.prove_segment(po2, 4, 12, 4, Segment.synthetic(i, po2=po2).seed)
+            assert np.array_equal(dumps[k][f"seal_{i}"], want), f"segment {i} proved by rank {k}"
+
+
+def test_default_multi_rank_bench_path_static_split_is_bit_exact(tmp_path):
+    """The command the driver's scaling run uses (`bench.py --gpus N --steps K --warmup W` under torch.distributed.run), here with
+    two ranks on the one GPU: rank r proves segments r, r + 2, ... (fixed work per rank = weak scaling), the JSON line counts
+    the segments of both ranks, and every seal equals the oracle's."""
+    from boundless_amd.prover import Segment
+
+    po2, steps, lanes = 12, 2, 2
+    out, dumps = _run_bench_two_ranks_on_one_gpu(["--po2", str(po2), "--widths", "4,12,4", "--warmup", "1", "--steps", str(steps),
+                                                  "--inflight", str(lanes)], str(tmp_path))
+    total = 2 * steps * lanes
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["segments_proved"] == total
+    assert out["steps"] == steps and abs(out["value"] - total / (out["ms_per_step"] * steps / 1e3)) / out["value"] < 1e-6
+    a, b = dumps[0]["indices"].tolist(), dumps[1]["indices"].tolist()
+    assert a == list(range(0, total, 2)) and b == list(range(1, total, 2))
     for k in (0, 1):
         for i in dumps[k]["indices"].tolist():
             want, _ = ol.prove_segment(po2, 4, 12, 4, Segment.synthetic(i, po2=po2).seed)
