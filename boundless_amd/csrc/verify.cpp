@@ -3,7 +3,7 @@
 // Counterpart of `SegmentReceipt::verify_integrity_with_context` (bento/crates/workflow/src/tasks/prove.rs:53-55) for the
 // circuit-independent pipeline of bx_prove_segment.  Structure follows risc0_zkp::verify::{verify, fri::fri_verify,
 // merkle::MerkleTreeVerifier} (risc0-zkp 3.0.3, reference Cargo.lock:9155): replay the transcript, check the constraint
-// identity at the random point Z (here: the stand-in check polynomial, see bx_prover.h), then for each query verify the
+// identity at the random point Z (here: of the synthetic circuit specified in bx_prover.h), then for each query verify the
 // Merkle openings, recompute the DEEP quotient from the opened trace rows and follow the FRI folds to the final polynomial.
 // Pure CPU code (the reference verifies on the CPU as well); it shares only fp.hpp/transcript.hpp with the prover.
 #include <stdio.h>

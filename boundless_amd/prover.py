@@ -82,7 +82,7 @@ def verify_seal(seal_words):
 
 
 class HipProverServer:
-    """`impl ProverServer` for one GPU.  `widths` = (code, data, accum) trace-group widths of the circuit stand-in."""
+    """`impl ProverServer` for one GPU.  `widths` = (code, data, accum) trace-group widths of the synthetic circuit (include/bx_prover.h)."""
 
     DEFAULT_WIDTHS = (16, 256, 64)  # SURVEY.md §8d synthetic segment
 

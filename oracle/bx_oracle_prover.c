@@ -81,7 +81,7 @@ static e4 e4scale(e4 a, uint32_t s) { e4 r; for (int k = 0; k < 4; k++) r.c[k] =
 static e4 e4one(void) { e4 r = {{bxo_fp_encode(1), 0, 0, 0}}; return r; }
 
 
-/* ---- synthetic witness (stand-in for witgen; same definition as include/bx_prover.h) ---- */
+/* ---- pseudo-random words of the synthetic witness (definition: include/bx_prover.h, "seeds") ---- */
 static uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + GOLDEN;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
