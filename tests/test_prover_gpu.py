@@ -41,6 +41,10 @@ def test_seal_bit_exact_vs_oracle(po2, widths, seed):
     (13, (5, 33, 9), (5, 2), 8),       # knobs without a specialisation: the run-time path of cons_sum
     (12, (3, 10, 4), (64, 5), 9),      # the highest constraint degree the check polynomial admits
     (11, (2, 7, 12), (1, 1), 4),       # degenerate: every derived cell is one pool entry; three accumulators, one pair
+    (10, (2, 2, 4), (0, 0), 5),        # one free and one derived data column: the pool wraps around the free columns
+    (9, (3, 3, 8), (7, 3), 6),         # more accumulators than free columns allow pairs for
+    (10, (40, 6, 16), (0, 0), 7),      # wide code group, narrow data group
+    (22, (2, 6, 4), (0, 0), 22),       # the largest segment the prover accepts: 2^24-point LDEs
 ])
 def test_seal_bit_exact_vs_oracle_other_sizes_and_circuit_knobs(po2, widths, knobs, seed):
     from boundless_amd.prover import HipProverServer, Segment

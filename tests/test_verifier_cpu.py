@@ -12,7 +12,8 @@ from oracle import oracle_lib as ol
 
 
 @pytest.mark.parametrize("po2,widths,seed", [(9, (1, 1, 1), 3), (10, (4, 8, 4), 1234), (12, (3, 17, 5), 99), (13, (2, 9, 6), 5),
-                                             (11, (16, 40, 12), 8), (10, (2, 16, 8), 2), (10, (1, 16, 8), 2)])
+                                             (11, (16, 40, 12), 8), (10, (2, 16, 8), 2), (10, (1, 16, 8), 2), (10, (2, 2, 4), 5),
+                                             (9, (3, 3, 8), 6), (10, (40, 6, 16), 7)])
 def test_honest_seal_is_accepted(po2, widths, seed):
     seal, _ = ol.prove_segment(po2, *widths, seed)
     verify_seal(seal)
