@@ -239,6 +239,10 @@ __global__ void gather_sample_kernel(uint32_t* __restrict__ dst, const uint32_t*
     if (i < size) dst[i] = src[idx + i * stride];
 }
 
+// The chunk walks below are chains of dependent Fp4 products; their loads are independent, so they are issued eight at a
+// time (SCAN_B elements = 128 bytes per lane in flight) instead of one per product.
+constexpr int SCAN_B = 8;
+
 // ---- poly_divide: q_{i-1} = p_i + z q_i (top down), in place; remainder = p_0 + z q_0 ----
 // Three phases over chunks of DIV_L coefficients: (1) each chunk's carry-out assuming zero carry-in,
 // (2) sequential composition of the chunk maps carry -> local + z^L * carry (one workgroup), (3) replay.
@@ -253,7 +257,17 @@ __global__ void div_local_kernel(const uint32_t* __restrict__ poly, size_t size,
     if (ch >= chunks) return;
     size_t lo = ch * DIV_L, hi = lo + DIV_L < size ? lo + DIV_L : size;
     Fp4 cur = f4_zero();
-    for (size_t i = hi; i-- > lo;) cur = f4_add(f4_mul(z, cur), ld4(poly + 4 * i));
+    for (size_t top = hi; top > lo;) {
+        const size_t nb = top - lo < (size_t)SCAN_B ? top - lo : (size_t)SCAN_B;
+        Fp4 v[SCAN_B];
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) v[k] = ld4(poly + 4 * (top - 1 - k));
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) cur = f4_add(f4_mul(z, cur), v[k]);
+        top -= nb;
+    }
     st4(local + 4 * ch, cur);
 }
 // carry_in[ch] = value of `cur` entering chunk ch from above.  One workgroup: thread t owns a contiguous run of chunks
@@ -298,10 +312,19 @@ __global__ void div_apply_kernel(uint32_t* __restrict__ poly, size_t size, Fp4 z
     if (ch >= chunks) return;
     size_t lo = ch * DIV_L, hi = lo + DIV_L < size ? lo + DIV_L : size;
     Fp4 cur = ld4(carry_in + 4 * ch);
-    for (size_t i = hi; i-- > lo;) {
-        Fp4 next = f4_add(f4_mul(z, cur), ld4(poly + 4 * i));
-        st4(poly + 4 * i, cur);
-        cur = next;
+    for (size_t top = hi; top > lo;) {
+        const size_t nb = top - lo < (size_t)SCAN_B ? top - lo : (size_t)SCAN_B;
+        Fp4 v[SCAN_B];
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) v[k] = ld4(poly + 4 * (top - 1 - k));
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) {
+                st4(poly + 4 * (top - 1 - k), cur);
+                cur = f4_add(f4_mul(z, cur), v[k]);
+            }
+        top -= nb;
     }
 }
 
@@ -317,7 +340,16 @@ __global__ void pp_local_kernel(const uint32_t* __restrict__ io, size_t n, size_
     agg += 4 * agg_stride * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = f4_one();
-    for (size_t i = lo; i < hi; ++i) p = f4_mul(p, ld4(io + 4 * i));
+    for (size_t b = lo; b < hi; b += SCAN_B) {
+        const size_t nb = hi - b < (size_t)SCAN_B ? hi - b : (size_t)SCAN_B;
+        Fp4 v[SCAN_B];
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) v[k] = ld4(io + 4 * (b + k));
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) p = f4_mul(p, v[k]);
+    }
     st4(agg + 4 * ch, p);
 }
 // agg[ch] <- product of all chunks before ch (exclusive scan), one workgroup, log-step scan across threads
@@ -355,10 +387,18 @@ __global__ void pp_apply_excl_kernel(uint32_t* __restrict__ io, size_t n, size_t
     carry_in += 4 * carry_stride * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = ld4(carry_in + 4 * ch);
-    for (size_t i = lo; i < hi; ++i) {
-        const Fp4 a = ld4(io + 4 * i);
-        st4(io + 4 * i, p);
-        p = f4_mul(p, a);
+    for (size_t b = lo; b < hi; b += SCAN_B) {
+        const size_t nb = hi - b < (size_t)SCAN_B ? hi - b : (size_t)SCAN_B;
+        Fp4 v[SCAN_B];
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) v[k] = ld4(io + 4 * (b + k));
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) {
+                st4(io + 4 * (b + k), p);
+                p = f4_mul(p, v[k]);
+            }
     }
 }
 __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint32_t* __restrict__ carry_in, size_t chunks) {
@@ -368,9 +408,18 @@ __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint3
     carry_in += 4 * chunks * blockIdx.y;
     size_t lo = ch * PP_L, hi = lo + PP_L < n ? lo + PP_L : n;
     Fp4 p = ld4(carry_in + 4 * ch);
-    for (size_t i = lo; i < hi; ++i) {
-        p = f4_mul(p, ld4(io + 4 * i));
-        st4(io + 4 * i, p);
+    for (size_t b = lo; b < hi; b += SCAN_B) {
+        const size_t nb = hi - b < (size_t)SCAN_B ? hi - b : (size_t)SCAN_B;
+        Fp4 v[SCAN_B];
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) v[k] = ld4(io + 4 * (b + k));
+#pragma unroll
+        for (int k = 0; k < SCAN_B; ++k)
+            if ((size_t)k < nb) {
+                p = f4_mul(p, v[k]);
+                st4(io + 4 * (b + k), p);
+            }
     }
 }
 // entries [index[0], index[last]) are written.  The per-cycle grouping of upstream's scatter only orders writes that hit
