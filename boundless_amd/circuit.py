@@ -1,0 +1,85 @@
+"""ctypes mirror of include/bx_circuit.h: the circuit half of the segment prover as a plug-in table.
+
+Reference: below `ProverServer::prove_segment` (bento/crates/workflow/src/tasks/prove.rs:41-49) the prover reaches
+`risc0_zkp::hal::CircuitHal` (eval_check, accumulate) and the circuit crate's witness generation; `bx_circuit_ops` is that
+boundary as a C table.  `CircuitOps.from_object` adapts a Python object with the same method names (used by the tests to plug a
+circuit written outside the library into bx_prove_segment / bx_verify_segment); production circuits are native tables.
+"""
+import ctypes as C
+
+from .hal import BxBuf, load_library
+from .prover import SegmentParams
+
+
+class TapReader(C.Structure):
+    pass
+
+
+_TAP_AT = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32))
+TapReader._fields_ = [("ctx", C.c_void_p), ("at", _TAP_AT)]
+
+_NORMALIZE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams))
+_TAPS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams), C.c_int, C.c_uint32)
+_CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(C.c_void_p))
+_DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.c_uint64)
+_ACCUM = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, C.POINTER(C.c_uint32), C.c_uint64)
+_EVAL = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, BxBuf, BxBuf, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+_CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(TapReader), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                    C.POINTER(C.c_uint32))
+
+
+class CircuitOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("name", C.c_char_p), ("normalize", _NORMALIZE), ("taps", _TAPS), ("create", _CREATE),
+                ("destroy", _DESTROY), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL), ("constraints_at", _CONS)]
+
+    @staticmethod
+    def from_object(obj, name=b"python-circuit"):
+        """obj provides normalize(shape), taps(shape, group, col), witgen(ctx, code, data, seed), accumulate(ctx, accum, mix, seed),
+        eval_check(ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix) and constraints_at(shape, tap, poly_mix, mix) -> 4
+        words; ctx is the raw bx_ctx pointer, buffers are BxBuf, mixes are lists of 4 Montgomery words, tap(group, col, back)
+        returns 4 Montgomery words.  Exceptions become the error string of the call."""
+        errs = []
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return None
+                except Exception as e:  # noqa: BLE001 - crosses the ABI as a string
+                    errs.append(C.create_string_buffer(f"{type(e).__name__}: {e}".encode()))
+                    return C.cast(errs[-1], C.c_void_p).value
+            return wrapped
+
+        def w4(p):
+            return [p[i] for i in range(4)]
+
+        def constraints_at(_u, shape, reader, poly_mix, mix, out):
+            def tap(group, col, back):
+                buf = (C.c_uint32 * 4)()
+                msg = reader.contents.at(reader.contents.ctx, group, col, back, buf)
+                if msg:
+                    raise RuntimeError(C.cast(msg, C.c_char_p).value.decode())
+                return list(buf)
+
+            r = obj.constraints_at(shape.contents, tap, w4(poly_mix), w4(mix))
+            for i in range(4):
+                out[i] = int(r[i])
+
+        ops = CircuitOps(None, name,
+                         _NORMALIZE(guard(lambda _u, shape: obj.normalize(shape.contents))),
+                         _TAPS(lambda _u, shape, g, c: int(obj.taps(shape.contents, g, c))),
+                         _CREATE(), _DESTROY(),
+                         _WITGEN(guard(lambda _u, _s, ctx, code, data, seed: obj.witgen(ctx, code, data, seed))),
+                         _ACCUM(guard(lambda _u, _s, ctx, accum, mix, seed: obj.accumulate(ctx, accum, w4(mix), seed))),
+                         _EVAL(guard(lambda _u, _s, ctx, check, ce, de, ae, pm, mix: obj.eval_check(ctx, check, ce, de, ae, w4(pm), w4(mix)))),
+                         _CONS(guard(constraints_at)))
+        ops._keepalive = (obj, errs)
+        return ops
+
+
+def synthetic_circuit():
+    """Pointer to the library's built-in table (bx_synthetic_circuit)."""
+    lib = load_library()
+    lib.bx_synthetic_circuit.restype = C.POINTER(CircuitOps)
+    return lib.bx_synthetic_circuit()

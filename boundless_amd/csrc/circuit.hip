@@ -15,6 +15,7 @@
 #include "ctx.hpp"
 #include "circuit_dev.hpp"
 #include "lazy_ext.hpp"
+#include "../../include/bx_circuit.h"
 
 namespace bx {
 
@@ -334,4 +335,113 @@ const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_bu
     return nullptr;
 }
 
+// beta_e = beta^(floor(e/2)+1): the two accumulators of a pair share their challenge
+__global__ void beta_table_kernel(uint32_t* __restrict__ out, Fp4 beta, uint32_t n) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fp4 r = f4_pow(beta, e / 2 + 1);
+    out[4 * e + 0] = r.c[0]; out[4 * e + 1] = r.c[1]; out[4 * e + 2] = r.c[2]; out[4 * e + 3] = r.c[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the synthetic circuit as a bx_circuit_ops table (include/bx_circuit.h): what bx_prover_create plugs in by default
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t GOLDEN64 = 0x9E3779B97F4A7C15ull;
+struct SynthState {
+    Circuit cc;
+    bx_buf perm_offsets{nullptr, 0}, perm_index{nullptr, 0}, acc_src{nullptr, 0}, acc_run{nullptr, 0}, betas{nullptr, 0}, mixpows{nullptr, 0};
+};
+Circuit circuit_of(const bx_segment_params* s) { return Circuit(s->po2, s->w_code, s->w_data, s->w_accum, s->cons_terms, s->cons_degree); }
+
+const char* synth_normalize(void*, bx_segment_params* s) {
+    if (!s) return "circuit: null shape";
+    if (s->cons_terms > BX_CIRCUIT_MAX_TERMS || s->cons_degree > BX_CIRCUIT_MAX_DEGREE)
+        return "synthetic circuit: cons_terms must be <= 64 and cons_degree <= 5 (0 = default)";
+    if (!s->cons_terms) s->cons_terms = BX_CIRCUIT_DEFAULT_TERMS;
+    if (!s->cons_degree) s->cons_degree = BX_CIRCUIT_DEFAULT_DEGREE;
+    return nullptr;
+}
+uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_t col) { return circuit_of(s).taps_of(group, col); }
+void synth_destroy(void*, void* state) {
+    auto* st = (SynthState*)state;
+    if (!st) return;
+    for (bx_buf* b : {&st->perm_offsets, &st->perm_index, &st->acc_src, &st->acc_run, &st->betas, &st->mixpows})
+        if (b->dptr) (void)hipFree(b->dptr);
+    delete st;
+}
+const char* synth_create(void*, bx_ctx* c, const bx_segment_params* shape, void** state) {
+    auto* st = new (std::nothrow) SynthState();
+    BX_REQUIRE(c, st != nullptr, "synthetic circuit: out of host memory");
+    st->cc = circuit_of(shape);
+    const Circuit& cc = st->cc;
+    const size_t n = (size_t)1 << cc.po2;
+    const char* e = nullptr;
+    if (!e) e = bx_alloc(c, 8 * (cc.constraints() + 1), &st->mixpows);  // canonical table + centred copy
+    if (!e) e = bx_alloc(c, n * (cc.pairs ? cc.pairs : 1), &st->perm_offsets);
+    if (!e) e = bx_alloc(c, n + 1, &st->perm_index);
+    if (!e) e = bx_alloc(c, n * (cc.E ? cc.E : 1), &st->acc_src);
+    if (!e) e = bx_alloc(c, 4 * n * (cc.E ? cc.E : 1), &st->acc_run);
+    if (!e) e = bx_alloc(c, 4 * (cc.E ? cc.E : 1), &st->betas);
+    if (!e) e = circuit_perm_tables(c, cc, st->perm_offsets, st->perm_index);
+    if (e) {
+        synth_destroy(nullptr, st);
+        return e;
+    }
+    *state = st;
+    return nullptr;
+}
+const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, uint64_t seed) {
+    auto* st = (SynthState*)state;
+    BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 1, seed + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
+    return circuit_accum_gather(c, st->cc, st->acc_src, data);  // the prover interpolates `data` in place next
+}
+const char* synth_betas(bx_ctx* c, SynthState* st, const uint32_t mix[4]) {
+    if (!st->cc.E) return nullptr;
+    hipLaunchKernelGGL(beta_table_kernel, dim3((st->cc.E + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)st->betas.dptr,
+                       Fp4{{mix[0], mix[1], mix[2], mix[3]}}, st->cc.E);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+const char* synth_accumulate(void*, void* state, bx_ctx* c, bx_buf accum, const uint32_t mix[4], uint64_t seed) {
+    auto* st = (SynthState*)state;
+    const uint64_t gseed = (seed + GOLDEN64 * 3) ^ (((uint64_t)mix[0] << 32) | mix[1]);
+    BX_TRY(synth_betas(c, st, mix));
+    return circuit_accumulate(c, st->cc, accum, st->acc_run, st->acc_src, st->betas, gseed);
+}
+const char* synth_eval_check(void*, void* state, bx_ctx* c, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, const uint32_t poly_mix[4],
+                             const uint32_t mix[4]) {
+    auto* st = (SynthState*)state;
+    const Circuit& cc = st->cc;
+    BX_TRY(synth_betas(c, st, mix));
+    BX_TRY(circuit_mix_table(c, cc, st->mixpows, poly_mix));
+    // 1 / ((3x)^N - 1) takes four values on the domain x = w_4N^row: (3x)^N = 3^N w_4^(row mod 4)
+    uint32_t zinv[4];
+    const uint32_t t3n = fp_pow(MONT_THREE, (uint64_t)1 << cc.po2), w4 = fp_pow(fp_encode(137u), (uint64_t)1 << 25);  // ROU_FWD[2]
+    uint32_t cur = MONT_ONE;
+    for (int m = 0; m < 4; ++m) {
+        zinv[m] = fp_inv(fp_sub(fp_mul(t3n, cur), MONT_ONE));
+        cur = fp_mul(cur, w4);
+    }
+    return circuit_eval_check(c, cc, check, ecode, edata, eacc, st->mixpows, st->betas, zinv);
+}
+}  // namespace
+
+const char* synthetic_constraints_at(void*, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix[4],
+                                     const uint32_t mix[4], uint32_t out[4]);  // verify.cpp (host arithmetic only)
+
 }  // namespace bx
+
+extern "C" const bx_circuit_ops* bx_synthetic_circuit(void) {
+    static const bx_circuit_ops ops = {nullptr,
+                                       "bx-synthetic-air",
+                                       bx::synth_normalize,
+                                       bx::synth_taps,
+                                       bx::synth_create,
+                                       bx::synth_destroy,
+                                       bx::synth_witgen,
+                                       bx::synth_accumulate,
+                                       bx::synth_eval_check,
+                                       bx::synthetic_constraints_at};
+    return &ops;
+}

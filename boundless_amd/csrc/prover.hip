@@ -12,19 +12,11 @@
 #include "circuit.hpp"
 #include "ctx.hpp"
 #include "transcript.hpp"
-#include "../../include/bx_prover.h"
+#include "../../include/bx_circuit.h"
 
 namespace bx {
 
-constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
 
-// beta_e = beta^(floor(e/2)+1): the two accumulators of a pair share their challenge
-__global__ void beta_table_kernel(uint32_t* __restrict__ out, Fp4 beta, uint32_t n) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    Fp4 r = f4_pow(beta, e / 2 + 1);
-    out[4 * e + 0] = r.c[0]; out[4 * e + 1] = r.c[1]; out[4 * e + 2] = r.c[2]; out[4 * e + 3] = r.c[3];
-}
 // MerkleTreeProver::prove for a batch of queries (one workgroup per query).
 __global__ void merkle_query_gather_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
                                            const uint32_t* __restrict__ nodes, uint32_t rows, uint32_t cols,
@@ -104,14 +96,17 @@ using namespace bx;
 
 struct bx_prover {
     bx_ctx* c = nullptr;
-    bx_segment_params shape{};
-    Circuit cc;
+    bx_segment_params shape{};  // normalised by the circuit (defaults filled in)
+    const bx_circuit_ops* circ = nullptr;  // the circuit half: witgen / accumulate / eval_check / tap set (bx_circuit.h)
+    void* circ_state = nullptr;
     size_t N = 0;
     bool coeffs_bitrev = false;  // trace coefficients stay in bit-reversed order (N >= 2^15), see commit_group
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
-    DevBuf mixpows, combos, final_poly, which, xs, evals, rems, positions, qout;
-    DevBuf perm_offsets, perm_index, acc_src, acc_run, betas;  // the circuit's witness / accumulate scratch
+    DevBuf combos, final_poly, which, xs, evals, rems, positions, qout;
+    ~bx_prover() {
+        if (circ && circ_state && circ->destroy) circ->destroy(circ->user, circ_state);
+    }
     std::vector<FriRound> rounds;
     DevBuf final_coeffs;
     uint32_t last_roots[32];
@@ -200,21 +195,25 @@ extern "C" const char* bx_merkle_query_gather(bx_ctx* c, bx_buf out, bx_buf matr
 }
 
 extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shape, bx_prover** out) {
+    return bx_prover_create_with_circuit(c, shape, nullptr, out);
+}
+extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment_params* shape, const bx_circuit_ops* circuit, bx_prover** out) {
     if (!c) return "bx_prover_create: null ctx";
     BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
+    if (!circuit) circuit = bx_synthetic_circuit();
+    BX_REQUIRE(c, circuit->taps && circuit->witgen && circuit->accumulate && circuit->eval_check, "bx_prover_create: circuit table incomplete");
     BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 22, "bx_prover_create: po2 must be in [9, 22]");
     BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
     BX_REQUIRE(c, shape->w_code < 65536 && shape->w_data < 65536 && shape->w_accum < 65536, "bx_prover_create: group width out of range");
-    BX_REQUIRE(c, shape->cons_terms <= BX_CIRCUIT_MAX_TERMS && shape->cons_degree <= BX_CIRCUIT_MAX_DEGREE,
-               "bx_prover_create: cons_terms must be <= 64 and cons_degree <= 5 (0 = default)");
+
     BX_HIP(c, hipSetDevice(c->device));
     std::unique_ptr<bx_prover> p(new (std::nothrow) bx_prover());
     BX_REQUIRE(c, p != nullptr, "bx_prover_create: out of host memory");
     p->c = c;
     p->shape = *shape;
-    p->cc = Circuit(shape->po2, shape->w_code, shape->w_data, shape->w_accum, shape->cons_terms, shape->cons_degree);
-    p->shape.cons_terms = p->cc.T;
-    p->shape.cons_degree = p->cc.G;
+    p->circ = circuit;
+    if (circuit->normalize)
+        if (const char* e = circuit->normalize(circuit->user, &p->shape)) return set_msg(c, e);
     p->N = (size_t)1 << shape->po2;
     p->coeffs_bitrev = shape->po2 >= 15 && c->deep_bitrev;
     p->err[0] = 0;
@@ -231,23 +230,18 @@ extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shap
         BX_TRY(tree_init(c, G.tree, D, G.width));
         // the circuit's tap set: every column is opened at Z; data columns c % 4 == 0 and the accumulators also one row back
         G.taps.resize(G.width);
-        for (uint32_t col = 0; col < G.width; ++col) G.taps[col] = p->cc.taps_of(g, col);
+        for (uint32_t col = 0; col < G.width; ++col) {
+            G.taps[col] = g == 3 ? 1u : circuit->taps(circuit->user, &p->shape, g, col);
+            BX_REQUIRE(c, G.taps[col] == 1 || G.taps[col] == 2, "bx_prover_create: a column has 1 or 2 taps");
+        }
         std::vector<uint32_t> ids(G.width);
         for (uint32_t col = 0; col < G.width; ++col) ids[col] = g == 3 ? 2u : (G.taps[col] == 2 ? 1u : 0u);
         BX_TRY(G.combo_ids.alloc(c, G.width));
         BX_TRY(bx_h2d(c, G.combo_ids.b, ids.data(), G.width));
         for (uint32_t t : G.taps) total_taps += t;
     }
-    {
-        const Circuit& cc = p->cc;
-        BX_TRY(p->mixpows.alloc(c, 8 * (cc.constraints() + 1)));  // canonical table + centred copy
-        BX_TRY(p->perm_offsets.alloc(c, N * (cc.pairs ? cc.pairs : 1)));
-        BX_TRY(p->perm_index.alloc(c, N + 1));
-        BX_TRY(p->acc_src.alloc(c, N * (cc.E ? cc.E : 1)));
-        BX_TRY(p->acc_run.alloc(c, 4 * N * (cc.E ? cc.E : 1)));
-        BX_TRY(p->betas.alloc(c, 4 * (cc.E ? cc.E : 1)));
-        BX_TRY(circuit_perm_tables(c, cc, p->perm_offsets.b, p->perm_index.b));
-    }
+    if (circuit->create)
+        if (const char* e = circuit->create(circuit->user, c, &p->shape, &p->circ_state)) return e == c->err ? e : set_msg(c, e);
     BX_TRY(p->combos.alloc(c, 3 * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
     // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
@@ -318,7 +312,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
 
     // ---- header ----
     {
-        uint32_t hdr[BX_SEAL_HEADER_WORDS] = {po2, p->shape.w_code, p->shape.w_data, p->shape.w_accum, p->cc.T, p->cc.G};
+        uint32_t hdr[BX_SEAL_HEADER_WORDS] = {po2, p->shape.w_code, p->shape.w_data, p->shape.w_accum, p->shape.cons_terms, p->shape.cons_degree};
         uint32_t enc[BX_SEAL_HEADER_WORDS], dg[8];
         for (int i = 0; i < BX_SEAL_HEADER_WORDS; ++i) enc[i] = fp_encode(hdr[i]);
         T.write(hdr, BX_SEAL_HEADER_WORDS);
@@ -327,21 +321,14 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     }
     // ---- witness generation (code + data), then the commits in transcript order; the accumulate step needs the
     //      challenge drawn after the data commit, like upstream's accum mix ----
-    const Circuit& cc = p->cc;
+    const bx_circuit_ops* circ = p->circ;
     Fp4 beta = f4_zero();
-    PV(circuit_witness(c, cc, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed + GOLDEN * 1, seed + GOLDEN * 2, p->perm_offsets.b,
-                       p->perm_index.b));
-    PV(circuit_accum_gather(c, cc, p->acc_src.b, p->groups[1].coeffs.b));  // commit_group interpolates in place
+    PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed));
     for (int g = 0; g < 3; ++g) {
         Group& G = p->groups[g];
         if (g == 2) {
             beta = T.random_ext();
-            const uint64_t gseed = (seed + GOLDEN * 3) ^ (((uint64_t)beta.c[0] << 32) | beta.c[1]);
-            if (cc.E) {
-                hipLaunchKernelGGL(beta_table_kernel, dim3((cc.E + 63) / 64), dim3(64), 0, c->stream, (uint32_t*)p->betas.b.dptr, beta, cc.E);
-                if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: beta table launch failed");
-            }
-            PV(circuit_accumulate(c, cc, G.coeffs.b, p->acc_run.b, p->acc_src.b, p->betas.b, gseed));
+            PV(circ->accumulate(circ->user, p->circ_state, c, G.coeffs.b, beta.c, seed));  // CircuitHal::accumulate
         }
         PV(commit_group(p, G, T));
         memcpy(p->last_roots + 8 * g, G.tree.root, 32);
@@ -350,20 +337,9 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     Group& CK = p->groups[3];
     {
         Fp4 poly_mix = T.random_ext();
-        PV(circuit_mix_table(c, cc, p->mixpows.b, poly_mix.c));
-        // 1 / ((3x)^N - 1) takes four values on the domain x = w_4N^row: (3x)^N = 3^N w_4^(row mod 4)
-        uint32_t zinv[4];
-        {
-            const uint32_t t3n = fp_pow(MONT_THREE, (uint64_t)N), w4 = fp_pow(fp_encode(137u), (uint64_t)1 << 25);  // ROU_FWD[2]
-            uint32_t cur = MONT_ONE;
-            for (int m = 0; m < 4; ++m) {
-                zinv[m] = fp_inv(fp_sub(fp_mul(t3n, cur), MONT_ONE));
-                cur = fp_mul(cur, w4);
-            }
-        }
-        // the 16N-word check buffer holds the 4 ext planes over the 4N domain
-        PV(circuit_eval_check(c, cc, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b, p->groups[2].evaluated.b, p->mixpows.b,
-                              p->betas.b, zinv));
+        // the 16N-word check buffer holds the 4 ext planes over the 4N domain                       (CircuitHal::eval_check)
+        PV(circ->eval_check(circ->user, p->circ_state, c, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b,
+                            p->groups[2].evaluated.b, poly_mix.c, beta.c));
         PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
         PV(bx_zk_shift(c, CK.coeffs.b, BX_CHECK_SIZE));         // viewed as 16 polynomials of size N
         PV(bx_batch_expand_into_evaluate_ntt(c, CK.evaluated.b, CK.coeffs.b, BX_CHECK_SIZE, 2));

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/bx_prover.h"
+#include "../../include/bx_circuit.h"
 #include "circuit.hpp"
 #include "fp.hpp"
 #include "poseidon2_params.hpp"
@@ -114,7 +114,7 @@ struct TreeV {
     }
 };
 
-void verify(const uint32_t* seal, size_t words) {
+void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     HostPoseidon2 h;
     h.load(POSEIDON2_RC, POSEIDON2_DIAG);
     Transcript T(&h);
@@ -127,8 +127,14 @@ void verify(const uint32_t* seal, size_t words) {
     VCHECK(po2 >= 9 && po2 <= 24, "header: po2 out of range");
     VCHECK(widths[0] >= 1 && widths[1] >= 1 && widths[2] >= 1 && widths[0] < 65536 && widths[1] < 65536 && widths[2] < 65536,
            "header: bad group widths");
-    VCHECK(hdr[4] >= 1 && hdr[4] <= BX_CIRCUIT_MAX_TERMS && hdr[5] >= 1 && hdr[5] <= BX_CIRCUIT_MAX_DEGREE, "header: bad circuit knobs");
-    const Circuit cc(po2, widths[0], widths[1], widths[2], hdr[4], hdr[5]);
+    // the circuit's knobs are part of the statement: they must be a fixed point of the circuit's own normalisation
+    bx_segment_params shape{po2, widths[0], widths[1], widths[2], hdr[4], hdr[5]};
+    {
+        bx_segment_params norm = shape;
+        VCHECK(hdr[4] != 0 && hdr[5] != 0, "header: bad circuit knobs");
+        if (circ->normalize) VCHECK(circ->normalize(circ->user, &norm) == nullptr, "header: bad circuit knobs");
+        VCHECK(norm.cons_terms == shape.cons_terms && norm.cons_degree == shape.cons_degree, "header: bad circuit knobs");
+    }
     {
         uint32_t enc[6], dg[8];
         for (int i = 0; i < 6; ++i) enc[i] = fp_encode(hdr[i]);
@@ -150,7 +156,10 @@ void verify(const uint32_t* seal, size_t words) {
     size_t total_taps = 0;
     for (int g = 0; g < 4; ++g) {
         taps[g].resize(widths[g]);
-        for (uint32_t c = 0; c < widths[g]; ++c) taps[g][c] = cc.taps_of(g, c);
+        for (uint32_t c = 0; c < widths[g]; ++c) {
+            taps[g][c] = g == 3 ? 1u : circ->taps(circ->user, &shape, g, c);
+            VCHECK(taps[g][c] == 1 || taps[g][c] == 2, "circuit: a column has 1 or 2 taps");
+        }
         for (uint32_t t : taps[g]) total_taps += t;
     }
     const uint32_t* coeff_u = rd.take_elems(4 * total_taps);
@@ -176,6 +185,7 @@ void verify(const uint32_t* seal, size_t words) {
             }
         }
         auto at = [&](int g, uint32_t c, int back) -> Fp4 {  // the column's polynomial at Z (back 0) or Z * w_N^-1 (back 1)
+            VCHECK(g >= 0 && g < 4 && c < widths[g] && (back == 0 || back == 1), "internal: tap out of range");
             const uint32_t* w = coeff_u + where[g][c];
             if (taps[g][c] == 1) {
                 VCHECK(back == 0, "internal: back tap of a single-tap column");
@@ -183,45 +193,22 @@ void verify(const uint32_t* seal, size_t words) {
             }
             return f4_add(ld(w), f4_mul(ld(w + 4), back ? Zb : Z));  // u(x) = c0 + c1 x
         };
-        Fp4 rhs = f4_zero(), cur = f4_one();
-        for (uint32_t j = 0; j < cc.J; ++j) {
-            Fp4 pool[Circuit::POOL];
-            for (unsigned slot = 0; slot < Circuit::POOL; ++slot) {
-                const Circuit::Src src = cc.pool_src(j, slot);
-                pool[slot] = src.group < 0 ? f4_one() : at(src.group, src.col, src.back);
-            }
-            Fp4 sum = f4_zero();
-            for (uint32_t t = 0; t < cc.T; ++t) {
-                Fp4 prod = pool[Circuit::pool_idx(t, 0)];
-                for (uint32_t f = 1; f < cc.G; ++f) prod = f4_mul(prod, pool[Circuit::pool_idx(t, f)]);
-                sum = f4_add(sum, prod);
-            }
-            rhs = f4_add(rhs, f4_mul(cur, f4_sub(at(1, cc.F + j, 0), sum)));
-            cur = f4_mul(cur, poly_mix);
-        }
-        auto acc_at = [&](uint32_t e, int back) -> Fp4 {  // the ext-valued accumulator: sum_k X^k * column(4e+k)
-            Fp4 r = f4_zero();
-            for (int k = 0; k < 4; ++k) {
-                Fp4 xk = f4_zero();
-                xk.c[k] = MONT_ONE;
-                r = f4_add(r, f4_mul(xk, at(2, 4 * e + k, back)));
-            }
-            return r;
-        };
-        const Fp4 first = at(0, 0, 0);
-        Fp4 be = beta;
-        for (uint32_t e = 0; e < cc.E; ++e) {
-            Fp4 inner = f4_add(first, f4_mul(f4_sub(f4_one(), first), acc_at(e, 1)));
-            Fp4 cons = f4_sub(acc_at(e, 0), f4_mul(inner, f4_add(be, at(1, cc.acc_src(e), 0))));
-            rhs = f4_add(rhs, f4_mul(cur, cons));
-            cur = f4_mul(cur, poly_mix);
-            if (e & 1) be = f4_mul(be, beta);  // beta^(floor(e/2)+1)
-        }
-        for (uint32_t p = 0; p < cc.pairs; ++p) {
-            Fp4 cons = f4_mul(at(0, 1, 0), f4_sub(acc_at(2 * p + 1, 0), acc_at(2 * p, 0)));
-            rhs = f4_add(rhs, f4_mul(cur, cons));
-            cur = f4_mul(cur, poly_mix);
-        }
+        // the circuit evaluates sum_i poly_mix^i C_i from the taps (upstream: the circuit's poly_ext)
+        struct TapCtx {
+            decltype(at)* fn;
+        } tctx{&at};
+        bx_tap_reader reader{&tctx, [](const void* ctx, int g, uint32_t c, int back, uint32_t out[4]) -> const char* {
+                                 try {
+                                     const Fp4 v = (*((const TapCtx*)ctx)->fn)(g, c, back);
+                                     memcpy(out, v.c, 16);
+                                     return nullptr;
+                                 } catch (const Fail&) {
+                                     return "tap not available";
+                                 }
+                             }};
+        Fp4 rhs;
+        const char* ce = circ->constraints_at(circ->user, &shape, &reader, poly_mix.c, beta.c, rhs.c);
+        VCHECK(ce == nullptr, std::string("circuit: ") + (ce ? ce : ""));
         Fp4 lhs = f4_zero();
         const Fp4 zp[4] = {f4_one(), Z, f4_mul(Z, Z), f4_mul(f4_mul(Z, Z), Z)};
         for (int k = 0; k < 4; ++k) {
@@ -337,6 +324,63 @@ void verify(const uint32_t* seal, size_t words) {
 
 }  // namespace
 
+// sum_i poly_mix^i C_i of the synthetic circuit (include/bx_prover.h) from the tap values: the verifier-side half of the
+// bx_circuit_ops table built in circuit.hip.  Host arithmetic only.
+namespace bx {
+const char* synthetic_constraints_at(void*, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix_w[4],
+                                     const uint32_t mix_w[4], uint32_t out[4]) {
+    const Circuit cc(shape->po2, shape->w_code, shape->w_data, shape->w_accum, shape->cons_terms, shape->cons_degree);
+    const Fp4 poly_mix = ld(poly_mix_w), beta = ld(mix_w);
+    const char* err = nullptr;
+    auto at = [&](int g, uint32_t c, int back) -> Fp4 {
+        Fp4 v = f4_zero();
+        if (const char* e = taps->at(taps->ctx, g, c, back, v.c)) err = e;
+        return v;
+    };
+    Fp4 rhs = f4_zero(), cur = f4_one();
+    for (uint32_t j = 0; j < cc.J; ++j) {
+        Fp4 pool[Circuit::POOL];
+        for (unsigned slot = 0; slot < Circuit::POOL; ++slot) {
+            const Circuit::Src src = cc.pool_src(j, slot);
+            pool[slot] = src.group < 0 ? f4_one() : at(src.group, src.col, src.back);
+        }
+        Fp4 sum = f4_zero();
+        for (uint32_t t = 0; t < cc.T; ++t) {
+            Fp4 prod = pool[Circuit::pool_idx(t, 0)];
+            for (uint32_t f = 1; f < cc.G; ++f) prod = f4_mul(prod, pool[Circuit::pool_idx(t, f)]);
+            sum = f4_add(sum, prod);
+        }
+        rhs = f4_add(rhs, f4_mul(cur, f4_sub(at(1, cc.F + j, 0), sum)));
+        cur = f4_mul(cur, poly_mix);
+    }
+    auto acc_at = [&](uint32_t e, int back) -> Fp4 {  // the ext-valued accumulator: sum_k X^k * column(4e+k)
+        Fp4 r = f4_zero();
+        for (int k = 0; k < 4; ++k) {
+            Fp4 xk = f4_zero();
+            xk.c[k] = MONT_ONE;
+            r = f4_add(r, f4_mul(xk, at(2, 4 * e + k, back)));
+        }
+        return r;
+    };
+    const Fp4 first = at(0, 0, 0);
+    Fp4 be = beta;
+    for (uint32_t e = 0; e < cc.E; ++e) {
+        Fp4 inner = f4_add(first, f4_mul(f4_sub(f4_one(), first), acc_at(e, 1)));
+        Fp4 cons = f4_sub(acc_at(e, 0), f4_mul(inner, f4_add(be, at(1, cc.acc_src(e), 0))));
+        rhs = f4_add(rhs, f4_mul(cur, cons));
+        cur = f4_mul(cur, poly_mix);
+        if (e & 1) be = f4_mul(be, beta);  // beta^(floor(e/2)+1)
+    }
+    for (uint32_t p = 0; p < cc.pairs; ++p) {
+        Fp4 cons = f4_mul(at(0, 1, 0), f4_sub(acc_at(2 * p + 1, 0), acc_at(2 * p, 0)));
+        rhs = f4_add(rhs, f4_mul(cur, cons));
+        cur = f4_mul(cur, poly_mix);
+    }
+    memcpy(out, rhs.c, 16);
+    return err;
+}
+}  // namespace bx
+
 // The compiled-in Poseidon2 table (canonical integers): what bx_init loads into every new ctx and what the verifier uses.
 // Needs no ctx and no GPU, so that the fixture manifest (tests/golden/MANIFEST.json) can pin its SHA-256 on any host.
 extern "C" const char* bx_poseidon2_default_params(uint32_t* rc213, uint32_t* diag24) {
@@ -348,10 +392,15 @@ extern "C" const char* bx_poseidon2_default_params(uint32_t* rc213, uint32_t* di
 }
 
 extern "C" const char* bx_verify_segment(const uint32_t* seal, size_t seal_words) {
+    return bx_verify_segment_with_circuit(seal, seal_words, nullptr);
+}
+extern "C" const char* bx_verify_segment_with_circuit(const uint32_t* seal, size_t seal_words, const bx_circuit_ops* circuit) {
     static thread_local char err[256];
     if (!seal) return "bx_verify_segment: null seal";
+    if (!circuit) circuit = bx_synthetic_circuit();
+    if (!circuit->taps || !circuit->constraints_at) return "bx_verify_segment: circuit table incomplete";
     try {
-        verify(seal, seal_words);
+        verify(seal, seal_words, circuit);
     } catch (const Fail& f) {
         snprintf(err, sizeof err, "bx_verify_segment: %s", f.msg.c_str());
         return err;

@@ -68,15 +68,20 @@ def _declare(lib):
     lib.bx_prover_last_roots.restype = C.c_char_p
     lib.bx_verify_segment.argtypes = [C.c_void_p, sz]
     lib.bx_verify_segment.restype = C.c_char_p
+    lib.bx_prover_create_with_circuit.argtypes = [ctx, C.POINTER(SegmentParams), C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.bx_prover_create_with_circuit.restype = C.c_char_p
+    lib.bx_verify_segment_with_circuit.argtypes = [C.c_void_p, sz, C.c_void_p]
+    lib.bx_verify_segment_with_circuit.restype = C.c_char_p
     lib._bx_prover_declared = True
 
 
-def verify_seal(seal_words):
-    """Host-side verifier (include/bx_prover.h: bx_verify_segment); needs no GPU."""
+def verify_seal(seal_words, circuit=None):
+    """Host-side verifier (include/bx_prover.h: bx_verify_segment); needs no GPU.  `circuit` = a bx_circuit_ops table
+    (boundless_amd.circuit.CircuitOps) when the seal was made for another circuit than the built-in synthetic one."""
     lib = load_library()
     _declare(lib)
     a = np.ascontiguousarray(seal_words, dtype=np.uint32)
-    msg = lib.bx_verify_segment(a.ctypes.data, a.size)
+    msg = lib.bx_verify_segment_with_circuit(a.ctypes.data, a.size, C.addressof(circuit) if circuit is not None else None)
     if msg:
         raise HalError(msg.decode())
 
@@ -86,8 +91,9 @@ class HipProverServer:
 
     DEFAULT_WIDTHS = (16, 256, 64)  # SURVEY.md §8d synthetic segment
 
-    def __init__(self, device=0, po2=20, widths=DEFAULT_WIDTHS, hal=None, terms=0, degree=0):
-        """terms / degree: the synthetic circuit's knobs (product terms per constraint, factors per term); 0 = defaults."""
+    def __init__(self, device=0, po2=20, widths=DEFAULT_WIDTHS, hal=None, terms=0, degree=0, circuit=None):
+        """terms / degree: the circuit's knobs (synthetic circuit: product terms per constraint, factors per term); 0 = defaults.
+        circuit: a bx_circuit_ops table (boundless_amd.circuit.CircuitOps) to prove another circuit than the built-in one."""
         self.hal = hal or HipHal(device)
         self.lib = load_library()
         _declare(self.lib)
@@ -95,7 +101,9 @@ class HipProverServer:
         self.widths = tuple(widths)
         shape = SegmentParams(po2, *self.widths, terms, degree)
         handle = C.c_void_p()
-        msg = self.lib.bx_prover_create(self.hal.ctx, C.byref(shape), C.byref(handle))
+        self._circuit = circuit  # the table must outlive the prover
+        msg = self.lib.bx_prover_create_with_circuit(self.hal.ctx, C.byref(shape), C.addressof(circuit) if circuit is not None else None,
+                                                     C.byref(handle))
         if msg:
             raise HalError(msg.decode())
         self.handle = handle

@@ -1,0 +1,73 @@
+/*
+ * bx_circuit.h — the circuit half of the segment prover as a plug-in table: the C ABI counterpart of
+ * `risc0_zkp::hal::CircuitHal` plus the witness-generation entry of the circuit's prover.
+ *
+ * Reference boundary
+ * ------------------
+ *   bento/crates/workflow/src/tasks/prove.rs:41-49   prover.prove_segment(&ctx, &segment)
+ * reaches, below `ProverServer`, two trait objects [EXT, SURVEY.md App. A.3]:
+ *   risc0_zkp::hal::Hal          circuit-independent kernels            -> include/bx_hal.h
+ *   risc0_zkp::hal::CircuitHal   eval_check(check, groups, globals, poly_mix, po2, steps), accumulate(...)
+ * and the circuit crate's witness generation (risc0-circuit-rv32im 4.0.3 `witgen` / `step_exec`, -sys 4.0.1 kernels,
+ * reference Cargo.lock:8962,8996).  Those are machine-generated and not in the reference tree; this table is where they —
+ * recompiled for gfx950 against fp.hpp — plug into bx_prove_segment, and where this repository's SYNTHETIC circuit
+ * (bx_synthetic_circuit(), specified in bx_prover.h) plugs in today.  Everything else of the proof (commits, transcript,
+ * DEEP, FRI, queries, seal layout) is circuit-independent and stays in the prover.
+ *
+ * Conventions as in bx_hal.h: device stages enqueue on the ctx's stream and return NULL or an error string; matrices are
+ * column-major N x width (witness) or 4N x width (evaluations) of Montgomery u32 words; nothing aborts.
+ */
+#ifndef BX_CIRCUIT_H
+#define BX_CIRCUIT_H
+#include "bx_prover.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tap values handed to the verifier-side constraint evaluation: the value of column `col` of group `group` (0 code, 1 data,
+ * 2 accum) at the DEEP point Z (back = 0) or at Z * w_N^-1 (back = 1, only for columns whose taps() is 2).  out = 4 words. */
+typedef struct bx_tap_reader {
+    const void* ctx;
+    const char* (*at)(const void* ctx, int group, uint32_t col, int back, uint32_t out[4]);
+} bx_tap_reader;
+
+typedef struct bx_circuit_ops {
+    void* user;
+    const char* name;
+    /* Fills in defaults and validates the circuit's knobs in *shape (cons_terms / cons_degree are the circuit's to interpret;
+     * they travel in the seal header).  NULL = ok. */
+    const char* (*normalize)(void* user, bx_segment_params* shape);
+    /* Taps of column `col` of trace group `group`: 1 = opened at Z, 2 = also one row back.  (The tap set is circuit data:
+     * upstream reads it from the circuit's TapSet.) */
+    uint32_t (*taps)(void* user, const bx_segment_params* shape, int group, uint32_t col);
+    /* Per-prover device state of the circuit (tables, scratch).  Called once from bx_prover_create. */
+    const char* (*create)(void* user, bx_ctx* ctx, const bx_segment_params* shape, void** state);
+    void (*destroy)(void* user, void* state);
+    /* Witness generation for the code and data groups of segment `seed` (upstream: preflight trace -> witgen kernels).  The
+     * prover interpolates both buffers in place right afterwards, so whatever `accumulate` needs of them is kept by the
+     * circuit in its state. */
+    const char* (*witgen)(void* user, void* state, bx_ctx* ctx, bx_buf code, bx_buf data, uint64_t seed);
+    /* CircuitHal::accumulate: fills the accum group's witness; `mix` is the ext challenge drawn after the data commit. */
+    const char* (*accumulate)(void* user, void* state, bx_ctx* ctx, bx_buf accum, const uint32_t mix[4], uint64_t seed);
+    /* CircuitHal::eval_check: the four ext planes (check.len = 16N words) of  sum_i poly_mix^i C_i(x) / ((3x)^N - 1)  over the
+     * domain x = w_4N^row, from the committed 4N evaluations of the three trace groups.  `mix` as given to accumulate. */
+    const char* (*eval_check)(void* user, void* state, bx_ctx* ctx, bx_buf check, bx_buf code_eval, bx_buf data_eval, bx_buf accum_eval,
+                              const uint32_t poly_mix[4], const uint32_t mix[4]);
+    /* Verifier side (host, no GPU): sum_i poly_mix^i C_i evaluated from the tap values.  Upstream: the circuit's
+     * `poly_ext` called by risc0_zkp::verify. */
+    const char* (*constraints_at)(void* user, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix[4],
+                                  const uint32_t mix[4], uint32_t out[4]);
+} bx_circuit_ops;
+
+/* The synthetic circuit of bx_prover.h ("The synthetic circuit"); what bx_prover_create / bx_verify_segment use. */
+const bx_circuit_ops* bx_synthetic_circuit(void);
+
+/* bx_prover_create with an explicit circuit (NULL = the synthetic one).  The table must outlive the prover. */
+const char* bx_prover_create_with_circuit(bx_ctx* ctx, const bx_segment_params* shape, const bx_circuit_ops* circuit, bx_prover** out);
+/* bx_verify_segment against an explicit circuit (NULL = the synthetic one). */
+const char* bx_verify_segment_with_circuit(const uint32_t* seal, size_t seal_words, const bx_circuit_ops* circuit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

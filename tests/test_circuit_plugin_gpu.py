@@ -1,0 +1,187 @@
+"""GPU: a circuit written OUTSIDE the library plugs into bx_prove_segment / bx_verify_segment through include/bx_circuit.h.
+
+`bx_circuit_ops` is the C ABI counterpart of risc0's `CircuitHal` (+ witness generation): the slot where the generated rv32im
+kernels would go.  To show that the prover really is circuit-agnostic behind that table, this test implements a small AIR in
+numpy (host arithmetic, device buffers moved with bx_h2d / bx_d2h) and proves / verifies it with the library's pipeline:
+
+    data[1][r] = data[0][r]^2 + code[0][r] * data[0][r-1]          (one constraint of degree 2, one tap one row back)
+
+Everything else — commits, transcript, DEEP, FRI, queries — is the library's.  The seal must verify against this circuit,
+must NOT verify against the built-in synthetic circuit, and a witness that violates the constraint must be rejected.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+P = ol.P
+ROU_FWD2 = 284861408  # w_4 (canonical), SURVEY.md App. A.1
+
+
+def fmul(a, b):
+    return (np.asarray(a, np.uint64) * np.asarray(b, np.uint64)) % np.uint64(P)
+
+
+class Fp4:
+    """Canonical-integer arithmetic in Fp[X]/(X^4 + 11) for the verifier half."""
+
+    def __init__(self, c):
+        self.c = [int(v) % P for v in c]
+
+    @staticmethod
+    def from_mont(words):
+        return Fp4(ol.decode(np.array(words, np.uint32)).tolist())
+
+    def to_mont(self):
+        return ol.encode(self.c).tolist()
+
+    def __add__(self, o):
+        return Fp4([(a + b) % P for a, b in zip(self.c, o.c)])
+
+    def __sub__(self, o):
+        return Fp4([(a - b) % P for a, b in zip(self.c, o.c)])
+
+    def __mul__(self, o):
+        a, b, nb = self.c, o.c, P - 11
+        return Fp4([a[0] * b[0] + nb * (a[1] * b[3] + a[2] * b[2] + a[3] * b[1]),
+                    a[0] * b[1] + a[1] * b[0] + nb * (a[2] * b[3] + a[3] * b[2]),
+                    a[0] * b[2] + a[1] * b[1] + a[2] * b[0] + nb * (a[3] * b[3]),
+                    a[0] * b[3] + a[1] * b[2] + a[2] * b[1] + a[3] * b[0]])
+
+
+class SquareCircuit:
+    def __init__(self, lib, cheat_row=None):
+        self.lib = lib
+        self.cheat_row = cheat_row
+        self.calls = []
+
+    # ---- shape
+    def normalize(self, shape):
+        shape.cons_terms, shape.cons_degree = 1, 2
+
+    def taps(self, shape, group, col):
+        return 2 if (group == 1 and col == 0) else 1
+
+    # ---- device buffers <-> numpy (canonical integers on the host side)
+    def _put(self, ctx, buf, canon):
+        m = ol.encode(canon)
+        assert m.size == buf.len
+        msg = self.lib.bx_h2d(ctx, buf, m.ctypes.data, m.size)
+        assert not msg, msg
+
+    def _get(self, ctx, buf, offset, n):
+        out = np.empty(n, np.uint32)
+        sub = type(buf)(buf.dptr + 4 * offset, n)
+        msg = self.lib.bx_d2h(ctx, out.ctypes.data, sub, n)
+        assert not msg, msg
+        return ol.decode(out).astype(np.uint64)
+
+    # ---- prover side
+    def witgen(self, ctx, code, data, seed):
+        self.calls.append("witgen")
+        n, wc, wd = self.n, self.wc, self.wd
+        rng = np.random.default_rng(seed & 0xFFFFFFFF)
+        code_w = rng.integers(0, P, (wc, n), dtype=np.uint64)
+        data_w = rng.integers(0, P, (wd, n), dtype=np.uint64)
+        x = data_w[0]
+        data_w[1] = (fmul(x, x) + fmul(code_w[0], np.roll(x, 1))) % np.uint64(P)
+        if self.cheat_row is not None:
+            data_w[1][self.cheat_row] = (data_w[1][self.cheat_row] + np.uint64(1)) % np.uint64(P)
+        self._put(ctx, code, code_w.reshape(-1))
+        self._put(ctx, data, data_w.reshape(-1))
+
+    def accumulate(self, ctx, accum, mix, seed):
+        self.calls.append("accumulate")
+        rng = np.random.default_rng((seed ^ mix[0]) & 0xFFFFFFFF)
+        self._put(ctx, accum, rng.integers(0, P, self.wa * self.n, dtype=np.uint64))  # unconstrained columns
+
+    def eval_check(self, ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix):
+        self.calls.append("eval_check")
+        dom = 4 * self.n
+        c0 = self._get(ctx, code_eval, 0, dom)
+        d0 = self._get(ctx, data_eval, 0, dom)
+        d1 = self._get(ctx, data_eval, dom, dom)
+        cons = (d1 + np.uint64(2 * P) - fmul(d0, d0) - fmul(c0, np.roll(d0, 4))) % np.uint64(P)  # one row back = 4 domain points
+        t3n = pow(3, self.n, P)
+        zinv = np.array([pow((t3n * pow(ROU_FWD2, m, P) - 1) % P, -1, P) for m in range(4)], np.uint64)
+        planes = np.zeros(4 * dom, np.uint64)
+        planes[:dom] = fmul(cons, zinv[np.arange(dom) % 4])  # weight poly_mix^0 = 1: only the first ext component is non-zero
+        self._put(ctx, check, planes)
+
+    # ---- verifier side
+    def constraints_at(self, shape, tap, poly_mix, mix):
+        d0, d0b = Fp4.from_mont(tap(1, 0, 0)), Fp4.from_mont(tap(1, 0, 1))
+        d1, c0 = Fp4.from_mont(tap(1, 1, 0)), Fp4.from_mont(tap(0, 0, 0))
+        return (d1 - d0 * d0 - c0 * d0b).to_mont()
+
+    def bind(self, po2, widths):
+        self.n, (self.wc, self.wd, self.wa) = 1 << po2, widths
+
+
+def _prove(lib, circ_obj, po2, widths, seed):
+    from boundless_amd.circuit import CircuitOps
+    from boundless_amd.prover import HipProverServer, Segment
+
+    circ_obj.bind(po2, widths)
+    ops = CircuitOps.from_object(circ_obj, b"square-plus-back")
+    srv = HipProverServer(0, po2=po2, widths=widths, circuit=ops)
+    try:
+        return srv.prove_segment(Segment(index=0, po2=po2, seed=seed)), ops
+    finally:
+        srv.close()
+
+
+def test_a_foreign_circuit_is_proved_and_verified_through_the_plugin_table():
+    from boundless_amd.hal import HalError, load_library
+    from boundless_amd.prover import verify_seal
+
+    lib = load_library()
+    po2, widths = 10, (2, 3, 2)
+    circ = SquareCircuit(lib)
+    receipt, ops = _prove(lib, circ, po2, widths, seed=77)
+    assert circ.calls == ["witgen", "accumulate", "eval_check"]
+    assert receipt.seal[:6].tolist() == [po2, 2, 3, 2, 1, 2]  # the circuit's own knobs travel in the header
+    verify_seal(receipt.seal, circuit=ops)  # accepted against the circuit it was made for
+    with pytest.raises(HalError):  # ... and it is not a proof of the built-in synthetic circuit
+        verify_seal(receipt.seal)
+    bad = receipt.seal.copy()
+    bad[-1] ^= 1
+    with pytest.raises(HalError):
+        verify_seal(bad, circuit=ops)
+    # deterministic: the same segment twice gives the same seal
+    again, _ = _prove(lib, SquareCircuit(lib), po2, widths, seed=77)
+    assert np.array_equal(again.seal, receipt.seal)
+
+
+def test_a_foreign_circuit_with_a_false_witness_is_rejected():
+    from boundless_amd.hal import HalError, load_library
+    from boundless_amd.prover import verify_seal
+
+    lib = load_library()
+    receipt, ops = _prove(lib, SquareCircuit(lib, cheat_row=123), 10, (2, 3, 2), seed=5)
+    with pytest.raises(HalError, match="constraint identity"):
+        verify_seal(receipt.seal, circuit=ops)
+
+
+def test_errors_of_a_plugged_circuit_surface_as_error_strings():
+    from boundless_amd.circuit import CircuitOps
+    from boundless_amd.hal import HalError, load_library
+    from boundless_amd.prover import HipProverServer, Segment
+
+    class Broken(SquareCircuit):
+        def accumulate(self, ctx, accum, mix, seed):
+            raise RuntimeError("no accumulate kernel for this shape")
+
+    lib = load_library()
+    circ = Broken(lib)
+    circ.bind(10, (2, 3, 2))
+    ops = CircuitOps.from_object(circ)
+    srv = HipProverServer(0, po2=10, widths=(2, 3, 2), circuit=ops)
+    try:
+        with pytest.raises(HalError, match="no accumulate kernel for this shape"):
+            srv.prove_segment(Segment(index=0, po2=10, seed=1))
+    finally:
+        srv.close()
