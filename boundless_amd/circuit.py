@@ -19,7 +19,7 @@ _TAP_AT = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.PO
 TapReader._fields_ = [("ctx", C.c_void_p), ("at", _TAP_AT)]
 
 _NORMALIZE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams))
-_TAPS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams), C.c_int, C.c_uint32)
+_TAPS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams), C.c_int, C.c_uint32, C.POINTER(C.c_uint32))
 _CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(C.c_void_p))
 _DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 _WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.c_uint64)
@@ -35,7 +35,7 @@ class CircuitOps(C.Structure):
 
     @staticmethod
     def from_object(obj, name=b"python-circuit"):
-        """obj provides normalize(shape), taps(shape, group, col), witgen(ctx, code, data, seed), accumulate(ctx, accum, mix, seed),
+        """obj provides normalize(shape), taps(shape, group, col) -> list of rows back (first 0), witgen(ctx, code, data, seed), accumulate(ctx, accum, mix, seed),
         eval_check(ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix) and constraints_at(shape, tap, poly_mix, mix) -> 4
         words; ctx is the raw bx_ctx pointer, buffers are BxBuf, mixes are lists of 4 Montgomery words, tap(group, col, back)
         returns 4 Montgomery words.  Exceptions become the error string of the call."""
@@ -66,9 +66,15 @@ class CircuitOps(C.Structure):
             for i in range(4):
                 out[i] = int(r[i])
 
+        def taps(_u, shape, g, c, out):
+            backs = list(obj.taps(shape.contents, g, c))  # e.g. [0] or [0, 1, 3]: the rows back the column is opened at
+            for i, b in enumerate(backs):
+                out[i] = int(b)
+            return len(backs)
+
         ops = CircuitOps(None, name,
                          _NORMALIZE(guard(lambda _u, shape: obj.normalize(shape.contents))),
-                         _TAPS(lambda _u, shape, g, c: int(obj.taps(shape.contents, g, c))),
+                         _TAPS(taps),
                          _CREATE(), _DESTROY(),
                          _WITGEN(guard(lambda _u, _s, ctx, code, data, seed: obj.witgen(ctx, code, data, seed))),
                          _ACCUM(guard(lambda _u, _s, ctx, accum, mix, seed: obj.accumulate(ctx, accum, w4(mix), seed))),

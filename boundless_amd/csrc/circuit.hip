@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void witness_derive_kernel(uint32_t* __restric
     const uint32_t n = 1u << cc.po2;
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint32_t rb = (r + n - 1) & (n - 1);
+    const uint32_t rb1 = (r + n - 1) & (n - 1), rb2 = (r + n - 2) & (n - 1);
     // rings: the eight previous derived columns (csel(0..7) before the first), free columns j, j+1, j+2, code csel(j..j+3)
     const auto code_at = [&](unsigned i) -> uint32_t {
         const int col = cc.csel_col(i);
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void witness_derive_kernel(uint32_t* __restric
     for (uint32_t j = 0; j < cc.J; ++j) {
         uint32_t pool[Circuit::POOL];
         pool[0] = u[0];
-        pool[1] = (j & 3u) == 0 ? data[(size_t)j * n + rb] : u[0];
+        const int sb = Circuit::slot1_back(j);
+        pool[1] = sb == 0 ? u[0] : data[(size_t)j * n + (sb == 1 ? rb1 : rb2)];
         pool[2] = u[1]; pool[3] = u[2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) pool[4 + q] = ring[q];
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ 
     const uint32_t dom = 4u << cc.po2;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= dom) return;
-    const uint32_t ib = (i + dom - 4u) & (dom - 1u);  // one row back: x * w_N^-1 = w_4N^(row - 4)
+    const uint32_t ib = (i + dom - 4u) & (dom - 1u);   // one row back: x * w_N^-1 = w_4N^(row - 4)
+    const uint32_t ib2 = (i + dom - 8u) & (dom - 1u);  // two rows back
     LazyExtAcc mixacc;  // sum_j poly_mix^j * C_j over the derived-column constraints (ext weight x base value)
     mixacc.reset();
     const auto code_at = [&](unsigned q) -> uint32_t {
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ 
     for (uint32_t j = 0; j < cc.J; ++j) {
         uint32_t pool[Circuit::POOL];
         pool[0] = u[0];
-        pool[1] = (j & 3u) == 0 ? edata[(size_t)j * dom + ib] : u[0];
+        const int sb = Circuit::slot1_back(j);
+        pool[1] = sb == 0 ? u[0] : edata[(size_t)j * dom + (sb == 1 ? ib : ib2)];
         pool[2] = u[1]; pool[3] = u[2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) pool[4 + q] = ring[q];
@@ -362,7 +365,9 @@ const char* synth_normalize(void*, bx_segment_params* s) {
     if (!s->cons_degree) s->cons_degree = BX_CIRCUIT_DEFAULT_DEGREE;
     return nullptr;
 }
-uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_t col) { return circuit_of(s).taps_of(group, col); }
+uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_t col, uint32_t backs_out[BX_MAX_TAPS]) {
+    return circuit_of(s).backs_of(group, col, backs_out);
+}
 void synth_destroy(void*, void* state) {
     auto* st = (SynthState*)state;
     if (!st) return;

@@ -17,13 +17,13 @@
 namespace bx {
 
 struct Circuit {
-    // pool of a derived column: [0] free column j, [1] the same one row back (when it has that tap), [2] [3] free columns
+    // pool of a derived column: [0] free column j, [1] the same one or two rows back (slot1_back), [2] [3] free columns
     // j+1, j+2 (mod F), [4..11] the eight previous derived columns, [12..15] code columns csel(j..j+3)
     static constexpr unsigned POOL = 16;
     struct Src {
         int group;      // 0 code, 1 data, -1 = the constant one
         uint32_t col;
-        int back;       // 0 = this row, 1 = one row back
+        int back;       // rows back (0 = this row)
     };
     uint32_t po2, wc, wd, wa, T, G;
     uint32_t F, J, E, pairs;
@@ -43,7 +43,7 @@ struct Circuit {
     // where pool entry `slot` of derived column j comes from
     BX_CIRC_HD Src pool_src(uint32_t j, unsigned slot) const {
         if (slot == 0) return Src{1, j, 0};
-        if (slot == 1) return Src{1, j, (j & 3u) == 0 ? 1 : 0};
+        if (slot == 1) return Src{1, j, slot1_back(j)};
         if (slot <= 3) return Src{1, (j + slot - 1) % F, 0};
         if (slot <= 11) {
             const uint32_t s = slot - 3;  // 1..8
@@ -66,12 +66,17 @@ struct Circuit {
     BX_CIRC_HD uint32_t perm_row(uint32_t p, uint32_t r) const {
         return (uint32_t)(((uint64_t)r * 2654435761ull + 12345u + p) & (((uint64_t)1 << po2) - 1));
     }
-    // taps of column c of group g (0 code, 1 data, 2 accum, 3 check): 2 = also opened one row back
-    BX_CIRC_HD uint32_t taps_of(int g, uint32_t c) const {
-        if (g == 1) return c % 4 == 0 ? 2u : 1u;
-        if (g == 2) return c < 4 * E ? 2u : 1u;
-        return 1u;
+    // tap set of column c of group g (0 code, 1 data, 2 accum): the rows back it is opened at; returns their count.
+    // data: c % 8 == 0 -> {0,1}, c % 8 == 4 -> {0,1,2}; accumulator columns {0,1}; everything else {0}
+    BX_CIRC_HD uint32_t backs_of(int g, uint32_t c, uint32_t* out) const {
+        out[0] = 0;
+        if (g == 1 && c % 8 == 0) { out[1] = 1; return 2; }
+        if (g == 1 && c % 8 == 4) { out[1] = 1; out[2] = 2; return 3; }
+        if (g == 2 && c < 4 * E) { out[1] = 1; return 2; }
+        return 1;
     }
+    // the row offset pool slot 1 of derived column j reads free column j at (0 = this row: the slot repeats slot 0)
+    BX_CIRC_HD static constexpr int slot1_back(uint32_t j) { return j % 8 == 0 ? 1 : (j % 8 == 4 ? 2 : 0); }
 };
 
 }  // namespace bx

@@ -81,7 +81,8 @@ struct Group {
     uint32_t width = 0;
     DevBuf coeffs, evaluated, combo_ids;
     Tree tree;
-    std::vector<uint32_t> taps;  // number of taps per column (1 or 2)
+    std::vector<std::vector<uint32_t>> backs;  // tap set per column: the rows back it is opened at (backs[c][0] == 0)
+    std::vector<uint32_t> combo;               // combo of each column (columns with the same tap set share one)
 };
 
 struct FriRound {
@@ -104,6 +105,10 @@ struct bx_prover {
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
     DevBuf combos, final_poly, which, xs, evals, rems, positions, qout;
+    std::vector<std::vector<uint32_t>> combo_backs;  // trace combos in order of first appearance; the check combo comes after them
+    std::vector<uint32_t> tap_which;                 // polynomial index of every tap evaluation (fixed per shape)
+    size_t tap_first[5] = {0, 0, 0, 0, 0};           // first tap evaluation of each group
+    size_t n_div = 0;                                // DEEP divisions per proof
     ~bx_prover() {
         if (circ && circ_state && circ->destroy) circ->destroy(circ->user, circ_state);
     }
@@ -148,15 +153,15 @@ const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
     return nullptr;
 }
 
-// the mixed u polynomials (two ext coefficients per combo) come off the low end of the three combination polynomials
+// the mixed u polynomials (one ext coefficient per tap of the combo) come off the low end of the combination polynomials
 struct SubLow {
-    uint32_t v[24];
+    uint32_t v[BX_MAX_COMBOS * BX_MAX_TAPS * 4];
 };
-__global__ void sub_low_kernel(uint32_t* __restrict__ combos, uint32_t combo_words, SubLow s) {
-    const uint32_t i = threadIdx.x;
-    if (i < 24) {
-        uint32_t* p = combos + (size_t)(i / 8) * combo_words + (i % 8);
-        *p = fp_sub(*p, s.v[i]);
+__global__ void sub_low_kernel(uint32_t* __restrict__ combos, uint32_t combo_words, SubLow s, uint32_t n_combos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_combos * BX_MAX_TAPS * 4) {
+        uint32_t* p = combos + (size_t)(i / (BX_MAX_TAPS * 4)) * combo_words + (i % (BX_MAX_TAPS * 4));  // natural-order AoS: coefficient t at 4t
+        *p = fp_sub(*p, s.v[i]);  // unused slots hold 0
     }
 }
 
@@ -228,27 +233,51 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
         BX_TRY(G.coeffs.alloc(c, (size_t)G.width * N));
         BX_TRY(G.evaluated.alloc(c, (size_t)G.width * D));
         BX_TRY(tree_init(c, G.tree, D, G.width));
-        // the circuit's tap set: every column is opened at Z; data columns c % 4 == 0 and the accumulators also one row back
-        G.taps.resize(G.width);
+        // the circuit's tap set (bx_circuit.h): every column is opened at Z and at the rows back its set lists; columns with
+        // the same set share a combo, combos are numbered in order of first appearance, the check group's comes last
+        G.backs.resize(G.width);
+        G.combo.resize(G.width);
         for (uint32_t col = 0; col < G.width; ++col) {
-            G.taps[col] = g == 3 ? 1u : circuit->taps(circuit->user, &p->shape, g, col);
-            BX_REQUIRE(c, G.taps[col] == 1 || G.taps[col] == 2, "bx_prover_create: a column has 1 or 2 taps");
+            if (g == 3) {
+                G.backs[col] = {0};
+                continue;
+            }
+            uint32_t bk[BX_MAX_TAPS];
+            const uint32_t k = circuit->taps(circuit->user, &p->shape, g, col, bk);
+            BX_REQUIRE(c, k >= 1 && k <= BX_MAX_TAPS && bk[0] == 0, "bx_prover_create: a tap set has 1..8 entries and starts with 0");
+            for (uint32_t t = 1; t < k; ++t) BX_REQUIRE(c, bk[t] > bk[t - 1] && bk[t] < N, "bx_prover_create: tap sets are strictly increasing");
+            G.backs[col].assign(bk, bk + k);
+            size_t id = 0;
+            while (id < p->combo_backs.size() && p->combo_backs[id] != G.backs[col]) ++id;
+            if (id == p->combo_backs.size()) p->combo_backs.push_back(G.backs[col]);
+            G.combo[col] = (uint32_t)id;
         }
-        std::vector<uint32_t> ids(G.width);
-        for (uint32_t col = 0; col < G.width; ++col) ids[col] = g == 3 ? 2u : (G.taps[col] == 2 ? 1u : 0u);
-        BX_TRY(G.combo_ids.alloc(c, G.width));
-        BX_TRY(bx_h2d(c, G.combo_ids.b, ids.data(), G.width));
-        for (uint32_t t : G.taps) total_taps += t;
     }
+    BX_REQUIRE(c, p->combo_backs.size() + 1 <= BX_MAX_COMBOS, "bx_prover_create: too many distinct tap sets");
+    const size_t n_combos = p->combo_backs.size() + 1;
+    for (int g = 0; g < 4; ++g) {
+        Group& G = p->groups[g];
+        if (g == 3) G.combo.assign(G.width, (uint32_t)(n_combos - 1));
+        BX_TRY(G.combo_ids.alloc(c, G.width));
+        BX_TRY(bx_h2d(c, G.combo_ids.b, G.combo.data(), G.width));
+        for (uint32_t col = 0; col < G.width; ++col) {
+            for (size_t t = 0; t < G.backs[col].size(); ++t) p->tap_which.push_back(col);
+            total_taps += G.backs[col].size();
+        }
+        p->tap_first[g + 1] = p->tap_which.size();
+    }
+    p->n_div = 1;
+    for (auto& cb : p->combo_backs) p->n_div += cb.size();
     if (circuit->create)
         if (const char* e = circuit->create(circuit->user, c, &p->shape, &p->circ_state)) return e == c->err ? e : set_msg(c, e);
-    BX_TRY(p->combos.alloc(c, 3 * 4 * N));
+    BX_TRY(p->combos.alloc(c, n_combos * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
     // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
     BX_TRY(p->which.alloc(c, total_taps));
     BX_TRY(p->xs.alloc(c, 4 * total_taps));
     BX_TRY(p->evals.alloc(c, 4 * total_taps));
-    BX_TRY(p->rems.alloc(c, 16));
+    BX_TRY(p->rems.alloc(c, 4 * p->n_div));
+    BX_TRY(bx_h2d(c, p->which.slice(0, total_taps), p->tap_which.data(), total_taps));  // fixed per shape
     // FRI rounds
     size_t size = N;
     size_t fri_query_words = 0;
@@ -349,31 +378,53 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     }
     // ---- DEEP: evaluate every tap at Z * back_one^back, write/commit coeff_u ----
     const Fp4 Z = T.random_ext();
-    const uint32_t back_one = fp_inv(fp_pow(fp_encode(137u), (uint64_t)1 << (27 - po2)));  // ROU_REV[po2]
-    const Fp4 Zb = f4_scale(Z, back_one);
+    const uint32_t back_one = fp_inv(fp_pow(fp_encode(137u), (uint64_t)1 << (27 - po2)));  // ROU_REV[po2] = w_N^-1
     // check columns hold g(3z) of the split check(y) = sum_q y^q g_q(y^4), so their tap is z = Z^4 / 3: the verifier can
     // then test check(Z) against the trace taps (verify.cpp)
     const Fp4 Z4 = f4_scale(host_pow(Z, 4), fp_inv(MONT_THREE));
+    const size_t n_trace_combos = p->combo_backs.size(), n_combos = n_trace_combos + 1;
+    // per combo: the points Z * w_N^-b of its tap set and the matrix that turns the values there into the coefficients of the
+    // interpolating polynomial (PolyGroup / Prover::finalize: `poly_interpolate` per register; the points are shared by all
+    // registers of a combo, so the Lagrange basis is expanded once per combo)
+    std::vector<std::vector<Fp4>> pts(n_trace_combos), interp(n_trace_combos);
+    for (size_t id = 0; id < n_trace_combos; ++id) {
+        const auto& B = p->combo_backs[id];
+        const size_t k = B.size();
+        for (uint32_t b : B) pts[id].push_back(f4_scale(Z, fp_pow(back_one, b)));
+        interp[id].assign(k * k, f4_zero());  // interp[t * k + i] = coefficient t of the basis polynomial L_i
+        for (size_t i = 0; i < k; ++i) {
+            std::vector<Fp4> poly(1, f4_one());  // prod_{j != i} (x - x_j), low coefficient first
+            Fp4 denom = f4_one();
+            for (size_t j = 0; j < k; ++j) {
+                if (j == i) continue;
+                std::vector<Fp4> next(poly.size() + 1, f4_zero());
+                for (size_t d = 0; d < poly.size(); ++d) {
+                    next[d + 1] = f4_add(next[d + 1], poly[d]);
+                    next[d] = f4_sub(next[d], f4_mul(poly[d], pts[id][j]));
+                }
+                poly.swap(next);
+                denom = f4_mul(denom, f4_sub(pts[id][i], pts[id][j]));
+            }
+            const Fp4 inv = f4_inv(denom);
+            for (size_t t = 0; t < k; ++t) interp[id][t * k + i] = f4_mul(poly[t], inv);
+        }
+    }
     std::vector<uint32_t> coeff_u;  // flattened ext elems, column by column, group by group
     {
-        std::vector<uint32_t> which, xs;
-        size_t first[5] = {0, 0, 0, 0, 0};
+        std::vector<uint32_t> xs;
         for (int g = 0; g < 4; ++g) {
             Group& G = p->groups[g];
             for (uint32_t col = 0; col < G.width; ++col)
-                for (uint32_t t = 0; t < G.taps[col]; ++t) {
-                    which.push_back(col);
-                    const Fp4& x = g == 3 ? Z4 : (t == 0 ? Z : Zb);
+                for (size_t t = 0; t < G.backs[col].size(); ++t) {
+                    const Fp4& x = g == 3 ? Z4 : pts[G.combo[col]][t];
                     xs.insert(xs.end(), x.c, x.c + 4);
                 }
-            first[g + 1] = which.size();
         }
-        const size_t ne_all = which.size();
-        PV(bx_h2d(c, p->which.slice(0, ne_all), which.data(), ne_all));
+        const size_t ne_all = p->tap_which.size();
         PV(bx_h2d(c, p->xs.slice(0, 4 * ne_all), xs.data(), 4 * ne_all));
         for (int g = 0; g < 4; ++g) {
             Group& G = p->groups[g];
-            const size_t o = first[g], ne = first[g + 1] - first[g];
+            const size_t o = p->tap_first[g], ne = p->tap_first[g + 1] - p->tap_first[g];
             if (p->coeffs_bitrev && g < 3)
                 PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
             else
@@ -385,19 +436,21 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         for (int g = 0; g < 4; ++g) {
             Group& G = p->groups[g];
             for (uint32_t col = 0; col < G.width; ++col) {
-                if (G.taps[col] == 1) {
+                const size_t k = G.backs[col].size();
+                if (k == 1) {  // a single tap: the "polynomial" is the value itself
                     coeff_u.insert(coeff_u.end(), ev.begin() + 4 * e, ev.begin() + 4 * e + 4);
-                    e += 1;
                 } else {
-                    // line through (Z, y0), (Zb, y1): c1 = (y1 - y0)/(Zb - Z), c0 = y0 - c1*Z
-                    Fp4 y0{{ev[4 * e], ev[4 * e + 1], ev[4 * e + 2], ev[4 * e + 3]}};
-                    Fp4 y1{{ev[4 * e + 4], ev[4 * e + 5], ev[4 * e + 6], ev[4 * e + 7]}};
-                    Fp4 c1 = f4_mul(f4_sub(y1, y0), f4_inv(f4_sub(Zb, Z)));
-                    Fp4 c0 = f4_sub(y0, f4_mul(c1, Z));
-                    coeff_u.insert(coeff_u.end(), c0.c, c0.c + 4);
-                    coeff_u.insert(coeff_u.end(), c1.c, c1.c + 4);
-                    e += 2;
+                    const auto& M = interp[G.combo[col]];
+                    for (size_t t = 0; t < k; ++t) {
+                        Fp4 ct = f4_zero();
+                        for (size_t i = 0; i < k; ++i) {
+                            const uint32_t* y = &ev[4 * (e + i)];
+                            ct = f4_add(ct, f4_mul(M[t * k + i], Fp4{{y[0], y[1], y[2], y[3]}}));
+                        }
+                        coeff_u.insert(coeff_u.end(), ct.c, ct.c + 4);
+                    }
                 }
+                e += k;
             }
         }
     }
@@ -407,43 +460,46 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         p->h2.hash_elems(dg, coeff_u.data(), coeff_u.size());
         T.commit(dg);
     }
-    // ---- DEEP: mix every column into its combo, subtract the mixed u polynomials, divide ----
+    // ---- DEEP: mix every column into its combo, subtract the mixed u polynomials, divide by every tap point ----
     const Fp4 mix = T.random_ext();
     if (hipMemsetAsync(p->combos.b.dptr, 0, p->combos.b.len * 4, c->stream) != hipSuccess) return perr(p, "bx_prove_segment: memset failed");
     {
         Fp4 cur = f4_one();
-        Fp4 combo_u[3][2] = {{f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}};
+        std::vector<Fp4> combo_u(n_combos * BX_MAX_TAPS, f4_zero());
         size_t u = 0;
         for (int g = 0; g < 4; ++g) {
             Group& G = p->groups[g];
             PV(bx_mix_poly_coeffs(c, p->combos.b, cur.c, mix.c, G.coeffs.b, G.combo_ids.b, G.width, N));
             for (uint32_t col = 0; col < G.width; ++col) {
-                int id = g == 3 ? 2 : (G.taps[col] == 2 ? 1 : 0);
-                for (uint32_t t = 0; t < G.taps[col]; ++t, u += 4) {
+                const uint32_t id = G.combo[col];
+                for (size_t t = 0; t < G.backs[col].size(); ++t, u += 4) {
                     Fp4 cu{{coeff_u[u], coeff_u[u + 1], coeff_u[u + 2], coeff_u[u + 3]}};
-                    combo_u[id][t] = f4_add(combo_u[id][t], f4_mul(cur, cu));
+                    combo_u[id * BX_MAX_TAPS + t] = f4_add(combo_u[id * BX_MAX_TAPS + t], f4_mul(cur, cu));
                 }
                 cur = f4_mul(cur, mix);
             }
         }
-        // combos 0 and 1 collect the trace groups (bit-reversed storage), combo 2 only the check group (natural order)
-        if (p->coeffs_bitrev) PV(bx_batch_bit_reverse_ext(c, p->combos.slice(0, 8 * N), 2));
-        {   // subtract the mixed u polynomials (degree < 2) from the low coefficients of the three combos, on the device
+        // the trace combos collect bit-reversed coefficient storage, the last combo only the check group (natural order)
+        if (p->coeffs_bitrev) PV(bx_batch_bit_reverse_ext(c, p->combos.slice(0, 4 * N * n_trace_combos), n_trace_combos));
+        {   // subtract the mixed u polynomials (degree < taps of the combo) from the low coefficients of the combos, on the device
             SubLow sl;
-            for (int id = 0; id < 3; ++id)
-                for (int t = 0; t < 2; ++t)
-                    for (int k = 0; k < 4; ++k) sl.v[8 * id + 4 * t + k] = combo_u[id][t].c[k];
-            hipLaunchKernelGGL(sub_low_kernel, dim3(1), dim3(32), 0, c->stream, (uint32_t*)p->combos.b.dptr, (uint32_t)(4 * N), sl);
+            memset(&sl, 0, sizeof sl);
+            for (size_t id = 0; id < n_combos; ++id)
+                for (size_t t = 0; t < BX_MAX_TAPS; ++t)
+                    for (int k = 0; k < 4; ++k) sl.v[(id * BX_MAX_TAPS + t) * 4 + k] = combo_u[id * BX_MAX_TAPS + t].c[k];
+            hipLaunchKernelGGL(sub_low_kernel, dim3((unsigned)((n_combos * BX_MAX_TAPS * 4 + 63) / 64)), dim3(64), 0, c->stream,
+                               (uint32_t*)p->combos.b.dptr, (uint32_t)(4 * N), sl, (uint32_t)n_combos);
             if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: sub_low launch failed");
         }
-        PV(bx_poly_divide(c, p->combos.slice(0, 4 * N), Z.c, p->rems.slice(0, 4)));
-        PV(bx_poly_divide(c, p->combos.slice(4 * N, 4 * N), Z.c, p->rems.slice(4, 4)));
-        PV(bx_poly_divide(c, p->combos.slice(4 * N, 4 * N), Zb.c, p->rems.slice(8, 4)));
-        PV(bx_poly_divide(c, p->combos.slice(8 * N, 4 * N), Z4.c, p->rems.slice(12, 4)));
-        uint32_t rems[16];
-        PV(bx_d2h(c, rems, p->rems.b, 16));
-        for (int i = 0; i < 16; ++i)
-            if (rems[i] != 0) return perr(p, "bx_prove_segment: DEEP quotient has a non-zero remainder");
+        size_t d = 0;
+        for (size_t id = 0; id < n_trace_combos; ++id)
+            for (size_t t = 0; t < pts[id].size(); ++t, ++d)
+                PV(bx_poly_divide(c, p->combos.slice(4 * N * id, 4 * N), pts[id][t].c, p->rems.slice(4 * d, 4)));
+        PV(bx_poly_divide(c, p->combos.slice(4 * N * n_trace_combos, 4 * N), Z4.c, p->rems.slice(4 * d, 4)));
+        std::vector<uint32_t> rems(4 * p->n_div);
+        PV(bx_d2h(c, rems.data(), p->rems.b, rems.size()));
+        for (uint32_t r : rems)
+            if (r != 0) return perr(p, "bx_prove_segment: DEEP quotient has a non-zero remainder");
     }
     PV(bx_eltwise_sum_extelem(c, p->final_poly.b, p->combos.b));
     PV(bx_batch_bit_reverse(c, p->final_poly.b, 4));

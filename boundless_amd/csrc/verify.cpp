@@ -152,16 +152,35 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     trees[3].read_and_commit(rd, T, h, D, widths[3]);
     const Fp4 Z = T.random_ext();
     // ---- taps ----
-    std::vector<std::vector<uint32_t>> taps(4);
+    // tap set of every column (the rows back it is opened at) and the combo it belongs to: columns with the same set share
+    // a DEEP combination polynomial, combos in order of first appearance, the check group's last (as in prover.hip)
+    std::vector<std::vector<std::vector<uint32_t>>> backs(4);
+    std::vector<std::vector<uint32_t>> combo(4);
+    std::vector<std::vector<uint32_t>> combo_backs;
     size_t total_taps = 0;
     for (int g = 0; g < 4; ++g) {
-        taps[g].resize(widths[g]);
+        backs[g].resize(widths[g]);
+        combo[g].resize(widths[g]);
         for (uint32_t c = 0; c < widths[g]; ++c) {
-            taps[g][c] = g == 3 ? 1u : circ->taps(circ->user, &shape, g, c);
-            VCHECK(taps[g][c] == 1 || taps[g][c] == 2, "circuit: a column has 1 or 2 taps");
+            if (g == 3) {
+                backs[g][c] = {0};
+            } else {
+                uint32_t bk[BX_MAX_TAPS];
+                const uint32_t k = circ->taps(circ->user, &shape, g, c, bk);
+                VCHECK(k >= 1 && k <= BX_MAX_TAPS && bk[0] == 0, "circuit: a tap set has 1..8 entries and starts with 0");
+                for (uint32_t t = 1; t < k; ++t) VCHECK(bk[t] > bk[t - 1] && bk[t] < N, "circuit: tap sets are strictly increasing");
+                backs[g][c].assign(bk, bk + k);
+                size_t id = 0;
+                while (id < combo_backs.size() && combo_backs[id] != backs[g][c]) ++id;
+                if (id == combo_backs.size()) combo_backs.push_back(backs[g][c]);
+                combo[g][c] = (uint32_t)id;
+            }
+            total_taps += backs[g][c].size();
         }
-        for (uint32_t t : taps[g]) total_taps += t;
     }
+    VCHECK(combo_backs.size() + 1 <= BX_MAX_COMBOS, "circuit: too many distinct tap sets");
+    const size_t n_trace_combos = combo_backs.size(), n_combos = n_trace_combos + 1;
+    for (uint32_t c = 0; c < widths[3]; ++c) combo[3][c] = (uint32_t)n_trace_combos;
     const uint32_t* coeff_u = rd.take_elems(4 * total_taps);
     {
         uint32_t dg[8];
@@ -169,8 +188,8 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
         T.commit(dg);
     }
     const uint32_t back_one = fp_inv(rou(po2));
-    const Fp4 Zb = f4_scale(Z, back_one);
     const Fp4 Z4 = f4_scale(f4_pow(Z, 4), fp_inv(MONT_THREE));
+    auto zback = [&](uint32_t b) { return f4_scale(Z, fp_pow(back_one, b)); };  // Z * w_N^-b
     // ---- the constraint identity at Z:  check(Z) * ((3Z)^N - 1)  ==  sum_i poly_mix^i C_i(taps)  with
     //      check(Z) = sum_k X^k sum_q Z^(rev2 q) g_{4k+q}(Z^4/3) from the check group's taps ----
     {
@@ -181,17 +200,21 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
             where[g].resize(widths[g]);
             for (uint32_t c = 0; c < widths[g]; ++c) {
                 where[g][c] = u;
-                u += 4 * taps[g][c];
+                u += 4 * backs[g][c].size();
             }
         }
         auto at = [&](int g, uint32_t c, int back) -> Fp4 {  // the column's polynomial at Z (back 0) or Z * w_N^-1 (back 1)
-            VCHECK(g >= 0 && g < 4 && c < widths[g] && (back == 0 || back == 1), "internal: tap out of range");
+            VCHECK(g >= 0 && g < 4 && c < widths[g] && back >= 0, "internal: tap out of range");
+            const auto& B = backs[g][c];
+            bool member = false;
+            for (uint32_t b : B) member |= b == (uint32_t)back;
+            VCHECK(member, "circuit: reads a tap that is not in the column's tap set");
             const uint32_t* w = coeff_u + where[g][c];
-            if (taps[g][c] == 1) {
-                VCHECK(back == 0, "internal: back tap of a single-tap column");
-                return ld(w);
-            }
-            return f4_add(ld(w), f4_mul(ld(w + 4), back ? Zb : Z));  // u(x) = c0 + c1 x
+            if (B.size() == 1) return ld(w);
+            const Fp4 x = g == 3 ? Z4 : zback((uint32_t)back);  // u(x) = sum_t c_t x^t (Horner)
+            Fp4 v = f4_zero();
+            for (size_t t = B.size(); t-- > 0;) v = f4_add(f4_mul(v, x), ld(w + 4 * t));
+            return v;
         };
         // the circuit evaluates sum_i poly_mix^i C_i from the taps (upstream: the circuit's poly_ext)
         struct TapCtx {
@@ -223,15 +246,16 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     }
     const Fp4 mix = T.random_ext();
     // mixed u polynomials per combo (as the prover subtracts them) and per-column mix powers
-    Fp4 combo_u[3][2] = {{f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}, {f4_zero(), f4_zero()}};
+    std::vector<Fp4> combo_u(n_combos * BX_MAX_TAPS, f4_zero());
     std::vector<Fp4> mixpow;
     {
         Fp4 cur = f4_one();
         size_t u = 0;
         for (int g = 0; g < 4; ++g)
             for (uint32_t c = 0; c < widths[g]; ++c) {
-                int id = g == 3 ? 2 : (taps[g][c] == 2 ? 1 : 0);
-                for (uint32_t t = 0; t < taps[g][c]; ++t, u += 4) combo_u[id][t] = f4_add(combo_u[id][t], f4_mul(cur, ld(coeff_u + u)));
+                const uint32_t id = combo[g][c];
+                for (size_t t = 0; t < backs[g][c].size(); ++t, u += 4)
+                    combo_u[id * BX_MAX_TAPS + t] = f4_add(combo_u[id * BX_MAX_TAPS + t], f4_mul(cur, ld(coeff_u + u)));
                 mixpow.push_back(cur);
                 cur = f4_mul(cur, mix);
             }
@@ -265,23 +289,24 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
         size_t pos = T.random_bits(ilog2u(D)) % D;
         const Fp4 y = from_base(fp_pow(rou(po2 + 2), pos));  // evaluation point of row `pos` (coset shift lives in the coefficients)
         // DEEP quotient from the opened rows
-        Fp4 num[3] = {f4_zero(), f4_zero(), f4_zero()};
+        std::vector<Fp4> num(n_combos, f4_zero());
         size_t col_global = 0;
         for (int g = 0; g < 4; ++g) {
             const uint32_t* vals = trees[g].verify_open(rd, h, pos);
             for (uint32_t c = 0; c < widths[g]; ++c, ++col_global) {
-                int id = g == 3 ? 2 : (taps[g][c] == 2 ? 1 : 0);
+                const uint32_t id = combo[g][c];
                 num[id] = f4_add(num[id], f4_scale(mixpow[col_global], vals[c]));
             }
         }
+        // goal = sum over combos of (combo(y) - u_combo(y)) / prod_{b in its tap set} (y - Z w_N^-b); the check combo's point is Z^4/3
         Fp4 goal = f4_zero();
-        {
-            Fp4 n0 = f4_sub(num[0], combo_u[0][0]);
-            goal = f4_add(goal, f4_mul(n0, f4_inv(f4_sub(y, Z))));
-            Fp4 n1 = f4_sub(num[1], f4_add(combo_u[1][0], f4_mul(combo_u[1][1], y)));
-            goal = f4_add(goal, f4_mul(n1, f4_inv(f4_mul(f4_sub(y, Z), f4_sub(y, Zb)))));
-            Fp4 n2 = f4_sub(num[2], combo_u[2][0]);
-            goal = f4_add(goal, f4_mul(n2, f4_inv(f4_sub(y, Z4))));
+        for (size_t id = 0; id < n_combos; ++id) {
+            const size_t k = id < n_trace_combos ? combo_backs[id].size() : 1;
+            Fp4 uy = f4_zero();
+            for (size_t t = k; t-- > 0;) uy = f4_add(f4_mul(uy, y), combo_u[id * BX_MAX_TAPS + t]);
+            Fp4 den = f4_one();
+            for (size_t t = 0; t < k; ++t) den = f4_mul(den, f4_sub(y, id < n_trace_combos ? zback(combo_backs[id][t]) : Z4));
+            goal = f4_add(goal, f4_mul(f4_sub(num[id], uy), f4_inv(den)));
         }
         // FRI chain
         size_t domain = D;

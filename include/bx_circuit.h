@@ -24,8 +24,11 @@
 extern "C" {
 #endif
 
+#define BX_MAX_TAPS 8   /* back offsets per column */
+#define BX_MAX_COMBOS 16 /* distinct tap sets ("combos", as in upstream's TapSet) over the three trace groups + the check group */
+
 /* Tap values handed to the verifier-side constraint evaluation: the value of column `col` of group `group` (0 code, 1 data,
- * 2 accum) at the DEEP point Z (back = 0) or at Z * w_N^-1 (back = 1, only for columns whose taps() is 2).  out = 4 words. */
+ * 2 accum) at Z * w_N^-back, for a `back` that belongs to the column's tap set.  out = 4 words. */
 typedef struct bx_tap_reader {
     const void* ctx;
     const char* (*at)(const void* ctx, int group, uint32_t col, int back, uint32_t out[4]);
@@ -37,9 +40,12 @@ typedef struct bx_circuit_ops {
     /* Fills in defaults and validates the circuit's knobs in *shape (cons_terms / cons_degree are the circuit's to interpret;
      * they travel in the seal header).  NULL = ok. */
     const char* (*normalize)(void* user, bx_segment_params* shape);
-    /* Taps of column `col` of trace group `group`: 1 = opened at Z, 2 = also one row back.  (The tap set is circuit data:
-     * upstream reads it from the circuit's TapSet.) */
-    uint32_t (*taps)(void* user, const bx_segment_params* shape, int group, uint32_t col);
+    /* Tap set of column `col` of trace group `group` (the tap set is circuit data: upstream reads it from the circuit's
+     * TapSet): writes the row offsets the column is opened at — strictly increasing, backs_out[0] == 0 (every column is
+     * opened at Z), back b meaning the point Z * w_N^-b — and returns their count, 1..BX_MAX_TAPS.  Columns with the same set
+     * share a DEEP combination polynomial ("combo"); combos are numbered in order of first appearance over code, data,
+     * accum, and the check group's combo comes last. */
+    uint32_t (*taps)(void* user, const bx_segment_params* shape, int group, uint32_t col, uint32_t backs_out[BX_MAX_TAPS]);
     /* Per-prover device state of the circuit (tables, scratch).  Called once from bx_prover_create. */
     const char* (*create)(void* user, bx_ctx* ctx, const bx_segment_params* shape, void** state);
     void (*destroy)(void* user, void* state);

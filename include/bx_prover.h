@@ -33,13 +33,14 @@
  *                  data[4p+3][perm_p(r)] = data[4p+2][r],  perm_p(r) = (r * 2654435761 + 12345 + p) mod N
  *              (placed with Hal::scatter).  pairs = the number of p with 2p+1 < E and 4p+3 < F (0 when w_code < 2).
  *              derived column F+j: with the 16-entry pool
- *                  pool_j = [ u = data[j][r],  ub = data[j][r-1] if j % 4 == 0 else u,  data[(j+1) mod F][r],  data[(j+2) mod F][r],
+ *                  pool_j = [ u = data[j][r],  ub = data[j][r-1] if j % 8 == 0, data[j][r-2] if j % 8 == 4, else u,  data[(j+1) mod F][r],  data[(j+2) mod F][r],
  *                             p_1 .. p_8 with p_s = data[F+j-s][r] (csel(s-j-1)[r] when j < s),  csel(j)[r] .. csel(j+3)[r] ]
  *                  data[F+j][r] = sum_{t<T} prod_{f<G} pool_j[idx(t,f)],  idx(t,f) = (7t + 3f + floor(t/4) f + floor(t/16)) mod 16
  *   accum      drawn after the data commit: beta (ext).  E = floor(w_accum / 4) ext accumulators, accumulator e in columns
  *              4e..4e+3 (component k in column 4e+k):  acc_e(r) = prod_{i<=r} (beta_e + data[src(e)][i]),  beta_e = beta^(floor(e/2)+1)   (Hal::prefix_products)
  *              src(e) = 4p+2 / 4p+3 for e = 2p / 2p+1 when p < pairs, else e mod F.  Columns >= 4E: word(gseed_2 ^ (beta.c0<<32|beta.c1), c, r).
- *   taps       every column at Z; one row back (Z * w_N^-1) as well: data columns with c % 4 == 0, accum columns c < 4E.
+ *   taps       every column at Z; data columns c % 8 == 0 and the accumulator columns (c < 4E) also one row back (Z * w_N^-1); data
+ *              columns c % 8 == 4 one and two rows back.  Columns with the same tap set share a DEEP combination polynomial.
  *   constraints, in mixing order (constraint i is weighted poly_mix^i):
  *              j < J :  data[F+j][r] - sum_t prod_f pool_j[idx(t,f)]                                          = 0
  *              e < E :  acc_e(r) - (first(r) + (1 - first(r)) * acc_e(r-1)) * (beta_e + data[src(e)][r])        = 0

@@ -126,11 +126,18 @@ static uint32_t acc_src(const circ_t* c, uint32_t e) {
 }
 /* the row permutation of pair p: data[4p+3][perm(r)] = data[4p+2][r] */
 static size_t perm_row(const circ_t* c, uint32_t p, size_t r) { return (r * 2654435761ull + 12345u + p) & (c->n - 1); }
-static uint32_t taps_of(const circ_t* c, int g, uint32_t col) {
-    if (g == 1) return col % 4 == 0 ? 2 : 1;
-    if (g == 2) return col < 4 * c->E ? 2 : 1;
+/* tap set of a column: the rows back it is opened at (first entry 0); returns their number */
+#define MAX_TAPS 8
+#define MAX_COMBOS 16
+static uint32_t backs_of(const circ_t* c, int g, uint32_t col, uint32_t* out) {
+    out[0] = 0;
+    if (g == 1 && col % 8 == 0) { out[1] = 1; return 2; }
+    if (g == 1 && col % 8 == 4) { out[1] = 1; out[2] = 2; return 3; }
+    if (g == 2 && col < 4 * c->E) { out[1] = 1; return 2; }
     return 1;
 }
+/* rows back at which pool slot 1 of derived column j reads free column j (0: the slot repeats slot 0) */
+static unsigned slot1_back(uint32_t j) { return j % 8 == 0 ? 1u : (j % 8 == 4 ? 2u : 0u); }
 
 /* ---- MerkleTreeProver ---- */
 typedef struct {
@@ -182,7 +189,9 @@ typedef struct {
     uint32_t* coeffs;     /* width x N, natural-order coefficients after the bit reverse */
     uint32_t* evaluated;  /* width x 4N */
     tree_t tree;
-    uint32_t* taps;       /* taps per column */
+    uint32_t* ntaps;      /* taps per column */
+    uint32_t (*backs)[MAX_TAPS]; /* their row offsets */
+    uint32_t* combo;      /* combo of the column (columns with the same tap set share one) */
 } group_t;
 /* [EXT] Prover::commit_group + PolyGroup::new; `coeffs` holds the witness evaluations on entry */
 static void commit_group(group_t* g, size_t n, iop_t* io) {
@@ -198,7 +207,9 @@ static void group_free(group_t* g) {
     free(g->coeffs);
     free(g->evaluated);
     free(g->tree.nodes);
-    free(g->taps);
+    free(g->ntaps);
+    free(g->backs);
+    free(g->combo);
 }
 
 /* Test hook: corrupt one witness cell (group, column, row) after witness generation, so that the statement being proved
@@ -224,6 +235,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
     group_t grp[4];
     memset(grp, 0, sizeof grp);
     uint32_t *code_w = NULL, *data_w = NULL; /* witness copies of the code and data groups (commit_group works in place) */
+    uint32_t combo_backs[MAX_COMBOS][MAX_TAPS], combo_len[MAX_COMBOS], n_trace_combos = 0; /* distinct tap sets of the trace groups */
 
     /* header */
     {
@@ -274,7 +286,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                      * columns (control columns before the first), control columns csel(j..j+3) */
                     uint32_t pool[POOL];
                     pool[0] = w[(size_t)j * n + r];
-                    pool[1] = j % 4 == 0 ? w[(size_t)j * n + (r + n - 1) % n] : pool[0];
+                    pool[1] = slot1_back(j) ? w[(size_t)j * n + (r + n - slot1_back(j)) % n] : pool[0];
                     pool[2] = w[(size_t)((j + 1) % cc.F) * n + r];
                     pool[3] = w[(size_t)((j + 2) % cc.F) * n + r];
                     for (uint32_t s_ = 1; s_ <= 8; s_++) {
@@ -331,8 +343,22 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             data_w = (uint32_t*)malloc((size_t)G->width * n * 4);
             memcpy(data_w, w, (size_t)G->width * n * 4);
         }
-        G->taps = (uint32_t*)malloc(G->width * 4);
-        for (uint32_t c = 0; c < G->width; c++) G->taps[c] = taps_of(&cc, g, c);
+        G->ntaps = (uint32_t*)malloc(G->width * 4);
+        G->backs = malloc(G->width * sizeof *G->backs);
+        G->combo = (uint32_t*)malloc(G->width * 4);
+        for (uint32_t c = 0; c < G->width; c++) {
+            G->ntaps[c] = backs_of(&cc, g, c, G->backs[c]);
+            /* combos in order of first appearance over code, data, accum */
+            uint32_t id = 0;
+            for (; id < n_trace_combos; id++)
+                if (combo_len[id] == G->ntaps[c] && memcmp(combo_backs[id], G->backs[c], 4 * G->ntaps[c]) == 0) break;
+            if (id == n_trace_combos) {
+                combo_len[id] = G->ntaps[c];
+                memcpy(combo_backs[id], G->backs[c], 4 * G->ntaps[c]);
+                n_trace_combos++;
+            }
+            G->combo[c] = id;
+        }
         commit_group(G, n, &io);
         if (roots_out) memcpy(roots_out + 8 * g, G->tree.nodes + 8, 32);
     }
@@ -371,7 +397,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             for (uint32_t j = 0; j < cc.J; j++) {
                 uint32_t pool[POOL];
                 pool[0] = edata[(size_t)j * dom + i];
-                pool[1] = j % 4 == 0 ? edata[(size_t)j * dom + ib] : pool[0];
+                pool[1] = slot1_back(j) ? edata[(size_t)j * dom + (i + dom - 4 * slot1_back(j)) % dom] : pool[0];
                 pool[2] = edata[(size_t)((j + 1) % cc.F) * dom + i];
                 pool[3] = edata[(size_t)((j + 2) % cc.F) * dom + i];
                 for (uint32_t s_ = 1; s_ <= 8; s_++) {
@@ -423,8 +449,14 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         free(betas);
         bxo_batch_interpolate_ntt(check, 4, dom);
         CK->coeffs = check; /* now viewed as 16 polynomials of size n */
-        CK->taps = (uint32_t*)malloc(CHECK_SIZE * 4);
-        for (int c = 0; c < CHECK_SIZE; c++) CK->taps[c] = 1;
+        CK->ntaps = (uint32_t*)malloc(CHECK_SIZE * 4);
+        CK->backs = malloc(CHECK_SIZE * sizeof *CK->backs);
+        CK->combo = (uint32_t*)malloc(CHECK_SIZE * 4);
+        for (int c = 0; c < CHECK_SIZE; c++) {
+            CK->ntaps[c] = 1;
+            CK->backs[c][0] = 0;
+            CK->combo[c] = n_trace_combos; /* the check group's combo comes last */
+        }
         bxo_zk_shift(CK->coeffs, CHECK_SIZE, n);
         CK->evaluated = (uint32_t*)malloc((size_t)CHECK_SIZE * dom * 4);
         bxo_batch_expand_into_evaluate_ntt(CK->evaluated, CK->coeffs, CHECK_SIZE, n, 2);
@@ -433,47 +465,64 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         tree_commit(&CK->tree, &io);
         if (roots_out) memcpy(roots_out + 24, CK->tree.nodes + 8, 32);
     }
-    /* DEEP: taps */
+    /* DEEP: taps.  Column c of a trace group is opened at Z * w_N^-b for every b of its tap set; the check columns at Z^4 / 3 */
     e4 Z = iop_random_ext(&io);
-    e4 Zb = e4scale(Z, bxo_rou_rev(po2));
-    e4 Z4 = e4scale(e4mul(e4mul(Z, Z), e4mul(Z, Z)), bxo_fp_inv(bxo_fp_encode(3))); /* tap of the check columns: Z^4 / 3 */
+    e4 Z4 = e4scale(e4mul(e4mul(Z, Z), e4mul(Z, Z)), bxo_fp_inv(bxo_fp_encode(3)));
+    const uint32_t n_combos = n_trace_combos + 1;
     size_t total_taps = 0;
     for (int g = 0; g < 4; g++)
-        for (uint32_t c = 0; c < grp[g].width; c++) total_taps += grp[g].taps[c];
+        for (uint32_t c = 0; c < grp[g].width; c++) total_taps += grp[g].ntaps[c];
     uint32_t* coeff_u = (uint32_t*)malloc(total_taps * 16);
     {
         size_t u = 0;
         for (int g = 0; g < 4; g++) {
             /* one batch_evaluate_any per group, like upstream (which = column, xs = Z * back_one^back) */
             size_t ne = 0;
-            for (uint32_t c = 0; c < grp[g].width; c++) ne += grp[g].taps[c];
+            for (uint32_t c = 0; c < grp[g].width; c++) ne += grp[g].ntaps[c];
             uint32_t* which = (uint32_t*)malloc(ne * 4);
             uint32_t* xs = (uint32_t*)malloc(ne * 16);
             uint32_t* ev = (uint32_t*)malloc(ne * 16);
             size_t e = 0;
             for (uint32_t c = 0; c < grp[g].width; c++)
-                for (uint32_t t = 0; t < grp[g].taps[c]; t++, e++) {
+                for (uint32_t t = 0; t < grp[g].ntaps[c]; t++, e++) {
                     which[e] = c;
-                    memcpy(xs + 4 * e, g == 3 ? Z4.c : (t == 0 ? Z.c : Zb.c), 16);
+                    e4 x = g == 3 ? Z4 : e4scale(Z, bxo_fp_pow(bxo_rou_rev(po2), grp[g].backs[c][t]));
+                    memcpy(xs + 4 * e, x.c, 16);
                 }
             bxo_batch_evaluate_any(grp[g].coeffs, n, which, xs, ev, ne);
             e = 0;
             for (uint32_t c = 0; c < grp[g].width; c++) {
-                e4 y0, y1;
-                memcpy(y0.c, ev + 4 * e, 16);
-                if (grp[g].taps[c] == 1) {
-                    memcpy(coeff_u + u, y0.c, 16);
-                    u += 4;
-                    e += 1;
-                } else {
-                    memcpy(y1.c, ev + 4 * e + 4, 16);
-                    e4 c1 = e4mul(e4sub(y1, y0), e4inv(e4sub(Zb, Z)));
-                    e4 c0 = e4sub(y0, e4mul(c1, Z));
-                    memcpy(coeff_u + u, c0.c, 16);
-                    memcpy(coeff_u + u + 4, c1.c, 16);
-                    u += 8;
-                    e += 2;
+                /* [EXT] poly_interpolate: the polynomial of degree < k through the k tap points, by Newton's divided
+                 * differences, then expanded into monomial coefficients */
+                const uint32_t k = grp[g].ntaps[c];
+                e4 px[MAX_TAPS], dd[MAX_TAPS], co[MAX_TAPS];
+                for (uint32_t t = 0; t < k; t++) {
+                    memcpy(px[t].c, xs + 4 * (e + t), 16);
+                    memcpy(dd[t].c, ev + 4 * (e + t), 16);
                 }
+                for (uint32_t lvl = 1; lvl < k; lvl++)
+                    for (uint32_t t = k - 1; t >= lvl; t--)
+                        dd[t] = e4mul(e4sub(dd[t], dd[t - 1]), e4inv(e4sub(px[t], px[t - lvl])));
+                /* Horner from the highest divided difference: co <- co * (x - px[t]) + dd[t], polynomial arithmetic on co */
+                {
+                    e4 tmp[MAX_TAPS];
+                    for (uint32_t t = 0; t < k; t++) memset(co[t].c, 0, 16);
+                    co[0] = dd[k - 1];
+                    uint32_t deg = 0;
+                    for (uint32_t t = k - 1; t-- > 0;) {
+                        for (uint32_t d = 0; d <= deg + 1; d++) memset(tmp[d].c, 0, 16);
+                        for (uint32_t d = 0; d <= deg; d++) {
+                            for (int q = 0; q < 4; q++) tmp[d + 1].c[q] = bxo_fp_add(tmp[d + 1].c[q], co[d].c[q]);
+                            tmp[d] = e4sub(tmp[d], e4mul(co[d], px[t]));
+                        }
+                        for (int q = 0; q < 4; q++) tmp[0].c[q] = bxo_fp_add(tmp[0].c[q], dd[t].c[q]);
+                        deg++;
+                        for (uint32_t d = 0; d <= deg; d++) co[d] = tmp[d];
+                    }
+                }
+                for (uint32_t t = 0; t < k; t++) memcpy(coeff_u + u + 4 * t, co[t].c, 16);
+                u += 4 * k;
+                e += k;
             }
             free(which);
             free(xs);
@@ -484,20 +533,18 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         bxo_hash_elem_slice(dg, coeff_u, 4 * total_taps, 1);
         iop_commit(&io, dg);
     }
-    /* DEEP: mix, subtract u, divide */
+    /* DEEP: mix, subtract u, divide by every tap point of the combo */
     e4 mix = iop_random_ext(&io);
-    uint32_t* combos = (uint32_t*)calloc(3 * 4 * n, 4);
+    uint32_t* combos = (uint32_t*)calloc((size_t)n_combos * 4 * n, 4);
     int ok = 1;
     {
         e4 cur = e4one();
         size_t u = 0;
         for (int g = 0; g < 4; g++) {
-            uint32_t* ids = (uint32_t*)malloc(grp[g].width * 4);
-            for (uint32_t c = 0; c < grp[g].width; c++) ids[c] = g == 3 ? 2u : (grp[g].taps[c] == 2 ? 1u : 0u);
-            bxo_mix_poly_coeffs(combos, cur.c, mix.c, grp[g].coeffs, ids, grp[g].width, n);
+            bxo_mix_poly_coeffs(combos, cur.c, mix.c, grp[g].coeffs, grp[g].combo, grp[g].width, n);
             for (uint32_t c = 0; c < grp[g].width; c++) {
-                uint32_t* target = combos + (size_t)ids[c] * 4 * n;
-                for (uint32_t t = 0; t < grp[g].taps[c]; t++, u += 4) {
+                uint32_t* target = combos + (size_t)grp[g].combo[c] * 4 * n;
+                for (uint32_t t = 0; t < grp[g].ntaps[c]; t++, u += 4) {
                     e4 cu;
                     memcpy(cu.c, coeff_u + u, 16);
                     e4 m = e4mul(cur, cu);
@@ -505,16 +552,17 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                 }
                 cur = e4mul(cur, mix);
             }
-            free(ids);
         }
         uint32_t rem[4];
-        ok &= bxo_poly_divide(combos, n, Z.c, rem);
-        ok &= bxo_poly_divide(combos + 4 * n, n, Z.c, rem);
-        ok &= bxo_poly_divide(combos + 4 * n, n, Zb.c, rem);
-        ok &= bxo_poly_divide(combos + 8 * n, n, Z4.c, rem);
+        for (uint32_t id = 0; id < n_trace_combos; id++)
+            for (uint32_t t = 0; t < combo_len[id]; t++) {
+                e4 x = e4scale(Z, bxo_fp_pow(bxo_rou_rev(po2), combo_backs[id][t]));
+                ok &= bxo_poly_divide(combos + (size_t)id * 4 * n, n, x.c, rem);
+            }
+        ok &= bxo_poly_divide(combos + (size_t)n_trace_combos * 4 * n, n, Z4.c, rem);
     }
     uint32_t* fin = (uint32_t*)malloc(4 * n * 4);
-    bxo_eltwise_sum_extelem(fin, combos, n, 3);
+    bxo_eltwise_sum_extelem(fin, combos, n, n_combos);
     bxo_batch_bit_reverse(fin, 4, n);
     free(combos);
     free(coeff_u);

@@ -4,7 +4,8 @@
 kernels would go.  To show that the prover really is circuit-agnostic behind that table, this test implements a small AIR in
 numpy (host arithmetic, device buffers moved with bx_h2d / bx_d2h) and proves / verifies it with the library's pipeline:
 
-    data[1][r] = data[0][r]^2 + code[0][r] * data[0][r-1]          (one constraint of degree 2, one tap one row back)
+    data[1][r] = data[0][r]^2 + code[0][r] * data[0][r-1] + data[0][r-3]   (degree 2; data column 0 is opened at rows back {0, 1, 3},
+                                                                            a tap set the built-in circuit does not have)
 
 Everything else — commits, transcript, DEEP, FRI, queries — is the library's.  The seal must verify against this circuit,
 must NOT verify against the built-in synthetic circuit, and a witness that violates the constraint must be rejected.
@@ -63,7 +64,7 @@ class SquareCircuit:
         shape.cons_terms, shape.cons_degree = 1, 2
 
     def taps(self, shape, group, col):
-        return 2 if (group == 1 and col == 0) else 1
+        return [0, 1, 3] if (group == 1 and col == 0) else [0]
 
     # ---- device buffers <-> numpy (canonical integers on the host side)
     def _put(self, ctx, buf, canon):
@@ -87,7 +88,7 @@ class SquareCircuit:
         code_w = rng.integers(0, P, (wc, n), dtype=np.uint64)
         data_w = rng.integers(0, P, (wd, n), dtype=np.uint64)
         x = data_w[0]
-        data_w[1] = (fmul(x, x) + fmul(code_w[0], np.roll(x, 1))) % np.uint64(P)
+        data_w[1] = (fmul(x, x) + fmul(code_w[0], np.roll(x, 1)) + np.roll(x, 3)) % np.uint64(P)
         if self.cheat_row is not None:
             data_w[1][self.cheat_row] = (data_w[1][self.cheat_row] + np.uint64(1)) % np.uint64(P)
         self._put(ctx, code, code_w.reshape(-1))
@@ -104,7 +105,8 @@ class SquareCircuit:
         c0 = self._get(ctx, code_eval, 0, dom)
         d0 = self._get(ctx, data_eval, 0, dom)
         d1 = self._get(ctx, data_eval, dom, dom)
-        cons = (d1 + np.uint64(2 * P) - fmul(d0, d0) - fmul(c0, np.roll(d0, 4))) % np.uint64(P)  # one row back = 4 domain points
+        # one row back = 4 domain points
+        cons = (d1 + np.uint64(3 * P) - fmul(d0, d0) - fmul(c0, np.roll(d0, 4)) - np.roll(d0, 12)) % np.uint64(P)
         t3n = pow(3, self.n, P)
         zinv = np.array([pow((t3n * pow(ROU_FWD2, m, P) - 1) % P, -1, P) for m in range(4)], np.uint64)
         planes = np.zeros(4 * dom, np.uint64)
@@ -113,9 +115,9 @@ class SquareCircuit:
 
     # ---- verifier side
     def constraints_at(self, shape, tap, poly_mix, mix):
-        d0, d0b = Fp4.from_mont(tap(1, 0, 0)), Fp4.from_mont(tap(1, 0, 1))
+        d0, d0b, d0b3 = Fp4.from_mont(tap(1, 0, 0)), Fp4.from_mont(tap(1, 0, 1)), Fp4.from_mont(tap(1, 0, 3))
         d1, c0 = Fp4.from_mont(tap(1, 1, 0)), Fp4.from_mont(tap(0, 0, 0))
-        return (d1 - d0 * d0 - c0 * d0b).to_mont()
+        return (d1 - d0 * d0 - c0 * d0b - d0b3).to_mont()
 
     def bind(self, po2, widths):
         self.n, (self.wc, self.wd, self.wa) = 1 << po2, widths

@@ -13,7 +13,7 @@ def test_oracle_prover_runs_and_is_deterministic():
     assert a[:6].tolist() == [10, 4, 8, 4, 64, 4]  # po2, widths, the circuit's default knobs (terms, degree)
     # layout: header 6 | 4 trace tops (32 digests each) | coeff_u | fri tops | final coeffs | 50 queries
     n = 1 << 10
-    taps = 4 + (8 + 2) + (4 + 4) + 16  # data columns 0 and 4 and the accumulator's four columns are also opened one row back
+    taps = 4 + (8 + 1 + 2) + (4 + 4) + 16  # data column 0 and the accumulator's columns also one row back, data column 4 one and two
     rows_fri = 4 * n // 16
     per_query = sum(w + 8 * (12 - 5) for w in (4, 8, 4, 16)) + (64 + 8 * (8 - 5))
     expect = 6 + 4 * 32 * 8 + 4 * taps + 32 * 8 + 4 * (n // 16) + 50 * per_query

@@ -21,11 +21,11 @@ def test_honest_seal_is_accepted(po2, widths, seed):
 
 def _regions(n):
     """Word offsets into the seal of the (10, 4/8/4) segment, one or two per region."""
-    taps = 4 + (8 + 2) + (4 + 4) + 16
+    taps = 4 + (8 + 1 + 2) + (4 + 4) + 16
     h = 6
     return {
         "header": 1, "header_terms": 4, "code_top": h + 5, "data_top": h + 256 + 9, "accum_top": h + 512 + 3, "check_top": h + 768 + 100,
-        "coeff_u": h + 1024 + 7, "coeff_u_2tap": h + 1024 + 4 * 4 + 5, "coeff_u_check": h + 1024 + 4 * (taps - 3), "fri_top": h + 1024 + 4 * taps + 11,
+        "coeff_u": h + 1024 + 7, "coeff_u_2tap": h + 1024 + 4 * 4 + 5, "coeff_u_3tap": h + 1024 + 4 * (4 + 5 + 2) + 1, "coeff_u_check": h + 1024 + 4 * (taps - 3), "fri_top": h + 1024 + 4 * taps + 11,
         "final": h + 1024 + 4 * taps + 256 + 5, "query_first": h + 1024 + 4 * taps + 256 + 256 + 2,
         "query_sibling": h + 1024 + 4 * taps + 256 + 256 + 4 + 3, "last": n - 1,
     }
