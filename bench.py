@@ -365,7 +365,7 @@ def main():
         circ_ops = ("witgen_fill", "scatter", "witgen_derive", "accum_gather", "accum_build", "prefix_products", "accum_store", "eval_check")
         circ_ms = sum(src_c[k]["ms_per_step"] for k in circ_ops if k in src_c)
         all_ms = sum(v["ms_per_step"] for v in src_c.values())
-        circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: no image id / claim / ZK blinding; lift is not included",
+        circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: public words bound to the trace, but no image id and no ZK blinding; lift is not included",
                         "included": ["witness generation (synthetic)", "accumulate (prefix_products)", "eval_check (synthetic constraints / vanishing polynomial)",
                                      "3 trace commits + check commit", "DEEP", "FRI", "50 queries"],
                         "excluded": ["rv32im preflight/witgen/eval_check (generated code, not in the reference tree)", "lift (recursion circuit)",

@@ -20,24 +20,27 @@ TapReader._fields_ = [("ctx", C.c_void_p), ("at", _TAP_AT)]
 
 _NORMALIZE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams))
 _TAPS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams), C.c_int, C.c_uint32, C.POINTER(C.c_uint32))
+_NGLOBALS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams))
 _CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(C.c_void_p))
 _DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
-_WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.c_uint64)
+_WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.c_uint64, C.POINTER(C.c_uint32))
 _ACCUM = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, C.POINTER(C.c_uint32), C.c_uint64)
-_EVAL = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, BxBuf, BxBuf, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
-_CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(TapReader), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+_EVAL = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, BxBuf, BxBuf, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                     C.POINTER(C.c_uint32))
+_CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(TapReader), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
 
 class CircuitOps(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("name", C.c_char_p), ("normalize", _NORMALIZE), ("taps", _TAPS), ("create", _CREATE),
+    _fields_ = [("user", C.c_void_p), ("name", C.c_char_p), ("normalize", _NORMALIZE), ("taps", _TAPS), ("n_globals", _NGLOBALS), ("create", _CREATE),
                 ("destroy", _DESTROY), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL), ("constraints_at", _CONS)]
 
     @staticmethod
     def from_object(obj, name=b"python-circuit"):
-        """obj provides normalize(shape), taps(shape, group, col) -> list of rows back (first 0), witgen(ctx, code, data, seed), accumulate(ctx, accum, mix, seed),
-        eval_check(ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix) and constraints_at(shape, tap, poly_mix, mix) -> 4
-        words; ctx is the raw bx_ctx pointer, buffers are BxBuf, mixes are lists of 4 Montgomery words, tap(group, col, back)
+        """obj provides normalize(shape), taps(shape, group, col) -> list of rows back (first 0), n_globals(shape),
+        witgen(ctx, code, data, seed) -> list of the n_globals public words, accumulate(ctx, accum, mix, seed),
+        eval_check(ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix, globals) and
+        constraints_at(shape, tap, poly_mix, mix, globals) -> 4 words; ctx is the raw bx_ctx pointer, buffers are BxBuf, mixes are lists of 4 Montgomery words, tap(group, col, back)
         returns 4 Montgomery words.  Exceptions become the error string of the call."""
         errs = []
 
@@ -54,7 +57,21 @@ class CircuitOps(C.Structure):
         def w4(p):
             return [p[i] for i in range(4)]
 
-        def constraints_at(_u, shape, reader, poly_mix, mix, out):
+        n_glob = {}
+
+        def n_globals(_u, shape):
+            n_glob["n"] = int(obj.n_globals(shape.contents)) if hasattr(obj, "n_globals") else 0
+            return n_glob["n"]
+
+        def witgen(_u, _s, ctx, code, data, seed, globals_out):
+            g = obj.witgen(ctx, code, data, seed) or []
+            for i, v in enumerate(g):
+                globals_out[i] = int(v)
+
+        def glist(p):
+            return [p[i] for i in range(n_glob.get("n", 0))]
+
+        def constraints_at(_u, shape, reader, poly_mix, mix, globals_, out):
             def tap(group, col, back):
                 buf = (C.c_uint32 * 4)()
                 msg = reader.contents.at(reader.contents.ctx, group, col, back, buf)
@@ -62,7 +79,7 @@ class CircuitOps(C.Structure):
                     raise RuntimeError(C.cast(msg, C.c_char_p).value.decode())
                 return list(buf)
 
-            r = obj.constraints_at(shape.contents, tap, w4(poly_mix), w4(mix))
+            r = obj.constraints_at(shape.contents, tap, w4(poly_mix), w4(mix), glist(globals_))
             for i in range(4):
                 out[i] = int(r[i])
 
@@ -74,11 +91,11 @@ class CircuitOps(C.Structure):
 
         ops = CircuitOps(None, name,
                          _NORMALIZE(guard(lambda _u, shape: obj.normalize(shape.contents))),
-                         _TAPS(taps),
+                         _TAPS(taps), _NGLOBALS(n_globals),
                          _CREATE(), _DESTROY(),
-                         _WITGEN(guard(lambda _u, _s, ctx, code, data, seed: obj.witgen(ctx, code, data, seed))),
+                         _WITGEN(guard(witgen)),
                          _ACCUM(guard(lambda _u, _s, ctx, accum, mix, seed: obj.accumulate(ctx, accum, w4(mix), seed))),
-                         _EVAL(guard(lambda _u, _s, ctx, check, ce, de, ae, pm, mix: obj.eval_check(ctx, check, ce, de, ae, w4(pm), w4(mix)))),
+                         _EVAL(guard(lambda _u, _s, ctx, check, ce, de, ae, pm, mix, gl: obj.eval_check(ctx, check, ce, de, ae, w4(pm), w4(mix), glist(gl)))),
                          _CONS(guard(constraints_at)))
         ops._keepalive = (obj, errs)
         return ops

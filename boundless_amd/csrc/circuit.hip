@@ -138,6 +138,7 @@ __global__ void accum_store_kernel(uint32_t* __restrict__ accum, const uint32_t*
 // ---- eval_check: check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1) on the 4N domain, one thread per domain point ----
 struct ZInv {
     uint32_t v[4];  // 1 / (3^N w_4^m - 1), m = row mod 4
+    uint32_t g[2];  // the statement's public words (Circuit::globals())
 };
 template <int TT, int GG>
 __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ check, const uint32_t* __restrict__ ecode,
@@ -208,6 +209,16 @@ __global__ __launch_bounds__(256) void eval_check_kernel(uint32_t* __restrict__ 
                 d.c[k] = fp_sub(eacc[(size_t)(4 * (2 * p + 1) + k) * dom + i], eacc[(size_t)(4 * (2 * p) + k) * dom + i]);
             const uint4 m = *reinterpret_cast<const uint4*>(mixpows + 4 * (size_t)(cc.J + cc.E + p));
             tot = f4_add(tot, f4_mul(Fp4{{m.x, m.y, m.z, m.w}}, f4_scale(d, last)));
+        }
+    }
+    {   // boundary constraints tying the public words to the trace: first * (data[0] - g0), last * (data[wd-1] - g1)
+        const size_t b0 = (size_t)cc.J + cc.E + cc.pairs;
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mixpows + 4 * b0);
+        tot = f4_add(tot, f4_scale(Fp4{{m0.x, m0.y, m0.z, m0.w}}, fp_mul(first, fp_sub(edata[i], zinv.g[0]))));
+        if (cc.globals() > 1) {
+            const uint4 m1 = *reinterpret_cast<const uint4*>(mixpows + 4 * (b0 + 1));
+            const uint32_t last = ecode[(size_t)dom + i];
+            tot = f4_add(tot, f4_scale(Fp4{{m1.x, m1.y, m1.z, m1.w}}, fp_mul(last, fp_sub(edata[(size_t)(cc.wd - 1) * dom + i], zinv.g[1]))));
         }
     }
     tot = f4_scale(tot, zinv.v[i & 3u]);
@@ -322,13 +333,15 @@ const char* circuit_mix_table(bx_ctx* c, const Circuit& cc, bx_buf mixpows, cons
 
 // eval_check over the committed 4N evaluations; `check` receives the four ext planes of check(x) over the domain
 const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, bx_buf mixpows, bx_buf betas_dev,
-                               const uint32_t zinv[4]) {
+                               const uint32_t zinv[4], const uint32_t* globals) {
     const size_t dom = (size_t)4 << cc.po2;
     BX_REQUIRE(c, check.len == 4 * dom && ecode.len == dom * cc.wc && edata.len == dom * cc.wd && eacc.len == dom * cc.wa,
                "circuit_eval_check: buffer size mismatch");
     BX_REQUIRE(c, mixpows.len >= 8 * cc.constraints(), "circuit_eval_check: mix power table too small");
     ZInv z;
     for (int m = 0; m < 4; ++m) z.v[m] = zinv[m];
+    z.g[0] = globals[0];
+    z.g[1] = cc.globals() > 1 ? globals[1] : 0u;
     // every committed evaluation is read once (plus the one-row-back taps), the check planes are written once
     OpScope op(c, "eval_check", 4.0 * (double)dom * (cc.wc + cc.wd + cc.J / 4.0 + 2.0 * cc.wa + 4.0));
     BX_CIRCUIT_DISPATCH(eval_check_kernel, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)check.dptr,
@@ -396,10 +409,23 @@ const char* synth_create(void*, bx_ctx* c, const bx_segment_params* shape, void*
     *state = st;
     return nullptr;
 }
-const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, uint64_t seed) {
+uint32_t synth_n_globals(void*, const bx_segment_params* s) { return circuit_of(s).globals(); }
+__global__ void globals_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ data, Circuit cc) {
+    const size_t n = (size_t)1 << cc.po2;
+    if (threadIdx.x == 0) out[0] = data[0];                                  // data[0][0]
+    if (threadIdx.x == 1) out[1] = data[(size_t)(cc.wd - 1) * n + (n - 1)];  // data[wd-1][N-1]
+}
+const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, uint64_t seed, uint32_t* globals_out) {
     auto* st = (SynthState*)state;
     BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 1, seed + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
-    return circuit_accum_gather(c, st->cc, st->acc_src, data);  // the prover interpolates `data` in place next
+    BX_TRY(circuit_accum_gather(c, st->cc, st->acc_src, data));  // the prover interpolates `data` in place next
+    // the statement's public words come out of the witness (one small copy; the derived cell is only known on the device)
+    hipLaunchKernelGGL(globals_kernel, dim3(1), dim3(64), 0, c->stream, (uint32_t*)st->betas.dptr, (const uint32_t*)data.dptr, st->cc);
+    BX_LAUNCH_CHECK(c);
+    uint32_t g[2] = {0, 0};
+    BX_TRY(bx_d2h(c, g, bx_buf{st->betas.dptr, 2}, 2));  // betas is written by accumulate later: free to borrow here
+    for (uint32_t i = 0; i < st->cc.globals(); ++i) globals_out[i] = g[i];
+    return nullptr;
 }
 const char* synth_betas(bx_ctx* c, SynthState* st, const uint32_t mix[4]) {
     if (!st->cc.E) return nullptr;
@@ -415,7 +441,7 @@ const char* synth_accumulate(void*, void* state, bx_ctx* c, bx_buf accum, const 
     return circuit_accumulate(c, st->cc, accum, st->acc_run, st->acc_src, st->betas, gseed);
 }
 const char* synth_eval_check(void*, void* state, bx_ctx* c, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, const uint32_t poly_mix[4],
-                             const uint32_t mix[4]) {
+                             const uint32_t mix[4], const uint32_t* globals) {
     auto* st = (SynthState*)state;
     const Circuit& cc = st->cc;
     BX_TRY(synth_betas(c, st, mix));
@@ -428,12 +454,12 @@ const char* synth_eval_check(void*, void* state, bx_ctx* c, bx_buf check, bx_buf
         zinv[m] = fp_inv(fp_sub(fp_mul(t3n, cur), MONT_ONE));
         cur = fp_mul(cur, w4);
     }
-    return circuit_eval_check(c, cc, check, ecode, edata, eacc, st->mixpows, st->betas, zinv);
+    return circuit_eval_check(c, cc, check, ecode, edata, eacc, st->mixpows, st->betas, zinv, globals);
 }
 }  // namespace
 
 const char* synthetic_constraints_at(void*, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix[4],
-                                     const uint32_t mix[4], uint32_t out[4]);  // verify.cpp (host arithmetic only)
+                                     const uint32_t mix[4], const uint32_t* globals, uint32_t out[4]);  // verify.cpp (host arithmetic only)
 
 }  // namespace bx
 
@@ -442,6 +468,7 @@ extern "C" const bx_circuit_ops* bx_synthetic_circuit(void) {
                                        "bx-synthetic-air",
                                        bx::synth_normalize,
                                        bx::synth_taps,
+                                       bx::synth_n_globals,
                                        bx::synth_create,
                                        bx::synth_destroy,
                                        bx::synth_witgen,

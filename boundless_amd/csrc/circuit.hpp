@@ -38,7 +38,10 @@ struct Circuit {
         while (2 * pairs + 1 < E && 4 * pairs + 3 < F) ++pairs;
         if (wc < 2) pairs = 0;  // the closing constraint needs the `last` selector (code column 1)
     }
-    size_t constraints() const { return (size_t)J + E + pairs; }
+    // public words of the statement: the first cell of data column 0 ("where the segment starts") and, with a `last` selector,
+    // the last cell of the last data column ("what it computed"); each is tied to the trace by a boundary constraint
+    BX_CIRC_HD uint32_t globals() const { return wc >= 2 ? 2u : 1u; }
+    size_t constraints() const { return (size_t)J + E + pairs + globals(); }
     BX_CIRC_HD static constexpr unsigned pool_idx(unsigned t, unsigned f) { return (7 * t + 3 * f + (t >> 2) * f + (t >> 4)) & 15u; }
     // where pool entry `slot` of derived column j comes from
     BX_CIRC_HD Src pool_src(uint32_t j, unsigned slot) const {

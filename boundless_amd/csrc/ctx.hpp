@@ -153,6 +153,6 @@ const char* circuit_accum_gather(bx_ctx* c, const Circuit& cc, bx_buf srcvals, b
 const char* circuit_accumulate(bx_ctx* c, const Circuit& cc, bx_buf accum, bx_buf run, bx_buf srcvals, bx_buf betas_dev, uint64_t seed_accum);
 const char* circuit_mix_table(bx_ctx* c, const Circuit& cc, bx_buf mixpows, const uint32_t poly_mix[4]);
 const char* circuit_eval_check(bx_ctx* c, const Circuit& cc, bx_buf check, bx_buf ecode, bx_buf edata, bx_buf eacc, bx_buf mixpows, bx_buf betas_dev,
-                               const uint32_t zinv[4]);
+                               const uint32_t zinv[4], const uint32_t* globals);
 
 }  // namespace bx

@@ -109,6 +109,7 @@ struct bx_prover {
     std::vector<uint32_t> tap_which;                 // polynomial index of every tap evaluation (fixed per shape)
     size_t tap_first[5] = {0, 0, 0, 0, 0};           // first tap evaluation of each group
     size_t n_div = 0;                                // DEEP divisions per proof
+    uint32_t n_globals = 0;                          // public words of the statement (bx_circuit_ops::n_globals)
     ~bx_prover() {
         if (circ && circ_state && circ->destroy) circ->destroy(circ->user, circ_state);
     }
@@ -270,6 +271,8 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     for (auto& cb : p->combo_backs) p->n_div += cb.size();
     if (circuit->create)
         if (const char* e = circuit->create(circuit->user, c, &p->shape, &p->circ_state)) return e == c->err ? e : set_msg(c, e);
+    p->n_globals = circuit->n_globals ? circuit->n_globals(circuit->user, &p->shape) : 0;
+    BX_REQUIRE(c, p->n_globals <= BX_MAX_GLOBALS, "bx_prover_create: too many public words");
     BX_TRY(p->combos.alloc(c, n_combos * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
     // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
@@ -303,7 +306,7 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     BX_TRY(p->positions.alloc(c, BX_QUERIES * (4 + p->rounds.size())));
     BX_TRY(p->qout.alloc(c, (trace_query_words + fri_query_words) * BX_QUERIES));
     // seal bound: header + tops + coeff_u + final coeffs + queries
-    size_t bound = BX_SEAL_HEADER_WORDS;
+    size_t bound = BX_SEAL_HEADER_WORDS + p->n_globals;
     for (int g = 0; g < 4; ++g) bound += 8 * p->groups[g].tree.top_size();
     for (auto& r : p->rounds) bound += 8 * r.tree.top_size();
     bound += 4 * total_taps + 4 * size + BX_QUERIES * (trace_query_words + fri_query_words);
@@ -352,7 +355,17 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     //      challenge drawn after the data commit, like upstream's accum mix ----
     const bx_circuit_ops* circ = p->circ;
     Fp4 beta = f4_zero();
-    PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed));
+    uint32_t globals[BX_MAX_GLOBALS];
+    memset(globals, 0, sizeof globals);
+    PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed, globals));
+    if (p->n_globals) {  // the statement's public words: in the seal and in the transcript before any commitment
+        uint32_t dg[8];
+        for (uint32_t i = 0; i < p->n_globals; ++i)
+            if (globals[i] >= P) return perr(p, "bx_prove_segment: the circuit produced a non-canonical public word");
+        T.write(globals, p->n_globals);
+        p->h2.hash_elems(dg, globals, p->n_globals);
+        T.commit(dg);
+    }
     for (int g = 0; g < 3; ++g) {
         Group& G = p->groups[g];
         if (g == 2) {
@@ -368,7 +381,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         Fp4 poly_mix = T.random_ext();
         // the 16N-word check buffer holds the 4 ext planes over the 4N domain                       (CircuitHal::eval_check)
         PV(circ->eval_check(circ->user, p->circ_state, c, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b,
-                            p->groups[2].evaluated.b, poly_mix.c, beta.c));
+                            p->groups[2].evaluated.b, poly_mix.c, beta.c, globals));
         PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
         PV(bx_zk_shift(c, CK.coeffs.b, BX_CHECK_SIZE));         // viewed as 16 polynomials of size N
         PV(bx_batch_expand_into_evaluate_ntt(c, CK.evaluated.b, CK.coeffs.b, BX_CHECK_SIZE, 2));

@@ -142,6 +142,15 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
         T.commit(dg);
     }
     const size_t N = (size_t)1 << po2, D = 4 * N;
+    // ---- the statement's public words ----
+    const uint32_t n_globals = circ->n_globals ? circ->n_globals(circ->user, &shape) : 0;
+    VCHECK(n_globals <= BX_MAX_GLOBALS, "circuit: too many public words");
+    const uint32_t* globals = rd.take_elems(n_globals);
+    if (n_globals) {
+        uint32_t dg[8];
+        h.hash_elems(dg, globals, n_globals);
+        T.commit(dg);
+    }
     // ---- trace commitments ----
     TreeV trees[4];
     trees[0].read_and_commit(rd, T, h, D, widths[0]);
@@ -230,7 +239,7 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
                                  }
                              }};
         Fp4 rhs;
-        const char* ce = circ->constraints_at(circ->user, &shape, &reader, poly_mix.c, beta.c, rhs.c);
+        const char* ce = circ->constraints_at(circ->user, &shape, &reader, poly_mix.c, beta.c, globals, rhs.c);
         VCHECK(ce == nullptr, std::string("circuit: ") + (ce ? ce : ""));
         Fp4 lhs = f4_zero();
         const Fp4 zp[4] = {f4_one(), Z, f4_mul(Z, Z), f4_mul(f4_mul(Z, Z), Z)};
@@ -353,7 +362,7 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
 // bx_circuit_ops table built in circuit.hip.  Host arithmetic only.
 namespace bx {
 const char* synthetic_constraints_at(void*, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix_w[4],
-                                     const uint32_t mix_w[4], uint32_t out[4]) {
+                                     const uint32_t mix_w[4], const uint32_t* globals, uint32_t out[4]) {
     const Circuit cc(shape->po2, shape->w_code, shape->w_data, shape->w_accum, shape->cons_terms, shape->cons_degree);
     const Fp4 poly_mix = ld(poly_mix_w), beta = ld(mix_w);
     const char* err = nullptr;
@@ -399,6 +408,13 @@ const char* synthetic_constraints_at(void*, const bx_segment_params* shape, cons
     for (uint32_t p = 0; p < cc.pairs; ++p) {
         Fp4 cons = f4_mul(at(0, 1, 0), f4_sub(acc_at(2 * p + 1, 0), acc_at(2 * p, 0)));
         rhs = f4_add(rhs, f4_mul(cur, cons));
+        cur = f4_mul(cur, poly_mix);
+    }
+    // boundary constraints tying the public words to the trace
+    rhs = f4_add(rhs, f4_mul(cur, f4_mul(first, f4_sub(at(1, 0, 0), from_base(globals[0])))));
+    cur = f4_mul(cur, poly_mix);
+    if (cc.globals() > 1) {
+        rhs = f4_add(rhs, f4_mul(cur, f4_mul(at(0, 1, 0), f4_sub(at(1, cc.wd - 1, 0), from_base(globals[1])))));
         cur = f4_mul(cur, poly_mix);
     }
     memcpy(out, rhs.c, 16);

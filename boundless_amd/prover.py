@@ -46,6 +46,11 @@ class SegmentReceipt:
     def get_seal_bytes(self):
         return self.seal.tobytes()
 
+    def public_words(self, n=2):
+        """The statement's public words ("globals", include/bx_circuit.h) as Montgomery words: they follow the 6-word header.
+        The built-in synthetic circuit has two (the first cell of data column 0, the last cell of the last data column)."""
+        return self.seal[6:6 + n].copy()
+
     def verify_integrity(self):
         """`SegmentReceipt::verify_integrity_with_context` (bento/crates/workflow/src/tasks/prove.rs:53-55): CPU check of the
         whole seal (transcript, check identity, Merkle openings, DEEP quotients, FRI chain).  Raises on rejection."""

@@ -26,6 +26,7 @@ extern "C" {
 
 #define BX_MAX_TAPS 8   /* back offsets per column */
 #define BX_MAX_COMBOS 16 /* distinct tap sets ("combos", as in upstream's TapSet) over the three trace groups + the check group */
+#define BX_MAX_GLOBALS 64 /* public words ("globals" / io of upstream's circuits) a segment's statement may carry */
 
 /* Tap values handed to the verifier-side constraint evaluation: the value of column `col` of group `group` (0 code, 1 data,
  * 2 accum) at Z * w_N^-back, for a `back` that belongs to the column's tap set.  out = 4 words. */
@@ -46,23 +47,27 @@ typedef struct bx_circuit_ops {
      * share a DEEP combination polynomial ("combo"); combos are numbered in order of first appearance over code, data,
      * accum, and the check group's combo comes last. */
     uint32_t (*taps)(void* user, const bx_segment_params* shape, int group, uint32_t col, uint32_t backs_out[BX_MAX_TAPS]);
+    /* Number of public words of a segment's statement ("globals" in CircuitHal::eval_check: what the receipt's claim is made
+     * of).  They are produced by witgen, written to the seal right after the header, bound into the transcript before any
+     * commitment, and handed to eval_check / constraints_at, which tie them to the trace (boundary constraints). */
+    uint32_t (*n_globals)(void* user, const bx_segment_params* shape);
     /* Per-prover device state of the circuit (tables, scratch).  Called once from bx_prover_create. */
     const char* (*create)(void* user, bx_ctx* ctx, const bx_segment_params* shape, void** state);
     void (*destroy)(void* user, void* state);
     /* Witness generation for the code and data groups of segment `seed` (upstream: preflight trace -> witgen kernels).  The
      * prover interpolates both buffers in place right afterwards, so whatever `accumulate` needs of them is kept by the
      * circuit in its state. */
-    const char* (*witgen)(void* user, void* state, bx_ctx* ctx, bx_buf code, bx_buf data, uint64_t seed);
+    const char* (*witgen)(void* user, void* state, bx_ctx* ctx, bx_buf code, bx_buf data, uint64_t seed, uint32_t* globals_out /* host, n_globals Montgomery words */);
     /* CircuitHal::accumulate: fills the accum group's witness; `mix` is the ext challenge drawn after the data commit. */
     const char* (*accumulate)(void* user, void* state, bx_ctx* ctx, bx_buf accum, const uint32_t mix[4], uint64_t seed);
     /* CircuitHal::eval_check: the four ext planes (check.len = 16N words) of  sum_i poly_mix^i C_i(x) / ((3x)^N - 1)  over the
      * domain x = w_4N^row, from the committed 4N evaluations of the three trace groups.  `mix` as given to accumulate. */
     const char* (*eval_check)(void* user, void* state, bx_ctx* ctx, bx_buf check, bx_buf code_eval, bx_buf data_eval, bx_buf accum_eval,
-                              const uint32_t poly_mix[4], const uint32_t mix[4]);
+                              const uint32_t poly_mix[4], const uint32_t mix[4], const uint32_t* globals /* host */);
     /* Verifier side (host, no GPU): sum_i poly_mix^i C_i evaluated from the tap values.  Upstream: the circuit's
      * `poly_ext` called by risc0_zkp::verify. */
     const char* (*constraints_at)(void* user, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix[4],
-                                  const uint32_t mix[4], uint32_t out[4]);
+                                  const uint32_t mix[4], const uint32_t* globals, uint32_t out[4]);
 } bx_circuit_ops;
 
 /* The synthetic circuit of bx_prover.h ("The synthetic circuit"); what bx_prover_create / bx_verify_segment use. */

@@ -45,6 +45,10 @@
  *              j < J :  data[F+j][r] - sum_t prod_f pool_j[idx(t,f)]                                          = 0
  *              e < E :  acc_e(r) - (first(r) + (1 - first(r)) * acc_e(r-1)) * (beta_e + data[src(e)][r])        = 0
  *              p < pairs :  last(r) * (acc_{2p+1}(r) - acc_{2p}(r))                                             = 0
+ *              first(r) * (data[0][r] - g_0) = 0   and, when w_code >= 2,   last(r) * (data[w_data-1][r] - g_1) = 0
+ *   globals    the statement's public words g_0 = data[0][0], g_1 = data[w_data-1][N-1] (Montgomery words): written to the seal
+ *              right after the header and bound into the transcript before the first commitment; the two boundary constraints
+ *              above tie them to the trace, so the seal proves "a trace of this circuit that starts at g_0 ends at g_1".
  *   check      check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1), evaluated on the 4N domain x = w_4N^row from the
  *              committed evaluations (which are F(3x): the coset shift lives in the coefficients), then split into the
  *              16 check columns exactly as upstream splits its check polynomial.
@@ -75,7 +79,7 @@ typedef struct bx_segment_params {
 #define BX_CIRCUIT_DEFAULT_DEGREE 4
 #define BX_CIRCUIT_MAX_TERMS 64
 #define BX_CIRCUIT_MAX_DEGREE 5
-#define BX_SEAL_HEADER_WORDS 6 /* po2, w_code, w_data, w_accum, T, G */
+#define BX_SEAL_HEADER_WORDS 6 /* po2, w_code, w_data, w_accum, T, G; the circuit's public words (globals) follow */
 
 /* Allocates every device buffer the pipeline needs for this shape (nothing is allocated per proof). */
 const char* bx_prover_create(bx_ctx* ctx, const bx_segment_params* shape, bx_prover** out);

@@ -236,6 +236,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
     memset(grp, 0, sizeof grp);
     uint32_t *code_w = NULL, *data_w = NULL; /* witness copies of the code and data groups (commit_group works in place) */
     uint32_t combo_backs[MAX_COMBOS][MAX_TAPS], combo_len[MAX_COMBOS], n_trace_combos = 0; /* distinct tap sets of the trace groups */
+    uint32_t globals[2] = {0, 0}, n_globals = 0; /* the statement's public words */
 
     /* header */
     {
@@ -359,6 +360,20 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             }
             G->combo[c] = id;
         }
+        /* The statement's public words come out of the data witness and are bound into the transcript before any
+         * commitment: the code group is committed only once they are known. */
+        if (g == 0) continue;
+        if (g == 1) {
+            n_globals = cc.wc >= 2 ? 2 : 1;
+            globals[0] = data_w[0];                                        /* data[0][0] */
+            globals[1] = data_w[(size_t)(cc.wd - 1) * n + (n - 1)];          /* data[wd-1][N-1] */
+            uint32_t dg[8];
+            iop_write(&io, globals, n_globals);
+            bxo_hash_elem_slice(dg, globals, n_globals, 1);
+            iop_commit(&io, dg);
+            commit_group(&grp[0], n, &io);
+            if (roots_out) memcpy(roots_out, grp[0].tree.nodes + 8, 32);
+        }
         commit_group(G, n, &io);
         if (roots_out) memcpy(roots_out + 8 * g, G->tree.nodes + 8, 32);
     }
@@ -370,7 +385,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         CK->width = CHECK_SIZE;
         e4 poly_mix = iop_random_ext(&io);
         uint32_t* check = (uint32_t*)calloc(16 * n, 4); /* 4 planes x 4N */
-        const size_t n_cons = (size_t)cc.J + cc.E + cc.pairs;
+        const size_t n_cons = (size_t)cc.J + cc.E + cc.pairs + n_globals;
         e4* mixpow = (e4*)malloc((n_cons + 1) * sizeof(e4));
         mixpow[0] = e4one();
         for (size_t i = 1; i <= n_cons; i++) mixpow[i] = e4mul(mixpow[i - 1], poly_mix);
@@ -441,6 +456,15 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                     d.c[k] = bxo_fp_sub(eacc[(size_t)(4 * (2 * p + 1) + k) * dom + i], eacc[(size_t)(4 * (2 * p) + k) * dom + i]);
                 d = e4mul(mixpow[cc.J + cc.E + p], e4scale(d, last));
                 for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], d.c[k]);
+            }
+            {   /* boundary constraints: first * (data[0] - g0), last * (data[wd-1] - g1) */
+                const size_t b0 = (size_t)cc.J + cc.E + cc.pairs;
+                uint32_t v = bxo_fp_mul(first, bxo_fp_sub(edata[i], globals[0]));
+                for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], bxo_fp_mul(mixpow[b0].c[k], v));
+                if (n_globals > 1) {
+                    v = bxo_fp_mul(last, bxo_fp_sub(edata[(size_t)(cc.wd - 1) * dom + i], globals[1]));
+                    for (int k = 0; k < 4; k++) tot.c[k] = bxo_fp_add(tot.c[k], bxo_fp_mul(mixpow[b0 + 1].c[k], v));
+                }
             }
             tot = e4scale(tot, zinv[i & 3]);
             for (int k = 0; k < 4; k++) check[(size_t)k * dom + i] = tot.c[k];

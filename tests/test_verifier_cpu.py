@@ -22,9 +22,9 @@ def test_honest_seal_is_accepted(po2, widths, seed):
 def _regions(n):
     """Word offsets into the seal of the (10, 4/8/4) segment, one or two per region."""
     taps = 4 + (8 + 1 + 2) + (4 + 4) + 16
-    h = 6
+    h = 6 + 2  # header + the two public words
     return {
-        "header": 1, "header_terms": 4, "code_top": h + 5, "data_top": h + 256 + 9, "accum_top": h + 512 + 3, "check_top": h + 768 + 100,
+        "header": 1, "header_terms": 4, "global_start": 6, "global_end": 7, "code_top": h + 5, "data_top": h + 256 + 9, "accum_top": h + 512 + 3, "check_top": h + 768 + 100,
         "coeff_u": h + 1024 + 7, "coeff_u_2tap": h + 1024 + 4 * 4 + 5, "coeff_u_3tap": h + 1024 + 4 * (4 + 5 + 2) + 1, "coeff_u_check": h + 1024 + 4 * (taps - 3), "fri_top": h + 1024 + 4 * taps + 11,
         "final": h + 1024 + 4 * taps + 256 + 5, "query_first": h + 1024 + 4 * taps + 256 + 256 + 2,
         "query_sibling": h + 1024 + 4 * taps + 256 + 256 + 4 + 3, "last": n - 1,
@@ -70,6 +70,40 @@ def test_non_canonical_words_are_rejected():
     bad[10] = 0xFFFFFFFF  # the INVALID marker of unset cells is not a field element either
     with pytest.raises(HalError, match="non-canonical"):
         verify_seal(bad)
+
+
+def test_the_public_words_are_bound_to_the_trace():
+    """The seal carries the statement's public words (the first cell of data column 0 and the last cell of the last data
+    column) and proves a trace that starts and ends there: claiming other values for the same proof is refused, and a prover
+    that honestly proves a trace with another end cell gets another (valid) claim, not the old one."""
+    L = ol.lib()
+    widths = (4, 16, 8)
+    seal, _ = ol.prove_segment(10, *widths, 99)
+    verify_seal(seal)
+    g0, g1 = int(seal[6]), int(seal[7])
+    for off in (6, 7):  # a different claim for the same proof
+        bad = seal.copy()
+        bad[off] = (int(bad[off]) + 1) % ol.P
+        with pytest.raises(HalError):
+            verify_seal(bad)
+    try:  # the witness changed in the very cell g_1 reports: the constraint that defines that derived cell now fails
+        L.bxo_set_witness_fault(1, widths[1] - 1, (1 << 10) - 1)
+        forged, _ = ol.prove_segment(10, *widths, 99)
+    finally:
+        L.bxo_set_witness_fault(-1, 0, 0)
+    assert int(forged[6]) == g0 and int(forged[7]) != g1
+    with pytest.raises(HalError, match="constraint identity"):
+        verify_seal(forged)
+    try:  # a trace with another first cell reports another g_0 ...
+        L.bxo_set_witness_fault(1, 0, 0)
+        other, _ = ol.prove_segment(10, *widths, 99)
+    finally:
+        L.bxo_set_witness_fault(-1, 0, 0)
+    assert int(other[6]) != g0
+    swapped = other.copy()
+    swapped[6] = g0  # ... and rewriting the claim back to the original g_0 is refused
+    with pytest.raises(HalError):
+        verify_seal(swapped)
 
 
 def test_a_seal_of_a_different_circuit_is_rejected():
