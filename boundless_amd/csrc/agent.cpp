@@ -206,6 +206,8 @@ bool parse_json(const char* text, JVal* out) {
 
 // ---------------------------------------------------------------------------------------------------------- metrics ----
 const double TASK_BUCKETS[] = {0.1, 0.5, 1.0, 2.5, 5.0, 10.0, 25.0, 50.0, 100.0, 250.0, 500.0};  // metrics.rs:108-112
+// next-gen worker loop (prover/crates/workflow-common/src/metrics.rs:55-61)
+const double E2E_BUCKETS[] = {0.01, 0.05, 0.1, 0.25, 0.5, 1.0, 2.5, 5.0, 10.0, 25.0, 50.0, 100.0, 250.0, 500.0};
 const double REDIS_BUCKETS[] = {0.001, 0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1.0};            // metrics.rs:66-70
 
 struct Hist {
@@ -248,6 +250,7 @@ struct Family {
             snprintf(buf, sizeof buf, "} %llu\n", (unsigned long long)kv.second.count);
             out += std::string(counter_name) + "{" + labels_of(kv.first) + buf;
         }
+        if (!hist_name) return;  // a plain counter family
         out += std::string("# HELP ") + hist_name + " " + hist_help + "\n# TYPE " + hist_name + " histogram\n";
         for (auto& kv : series) {
             std::string l = labels_of(kv.first);
@@ -273,6 +276,34 @@ struct Metrics {
     Family redis{"redis_operations_total", "redis_operation_duration_seconds", "Total number of Redis operations by type",
                  "Duration of Redis operations", {"operation_type", "status"}, REDIS_BUCKETS,
                  sizeof REDIS_BUCKETS / sizeof *REDIS_BUCKETS, {}};
+    // the next-gen worker loop's own series (prover/crates/workflow-common/src/metrics.rs:44-80; recorded from
+    // prover/crates/workflow/src/lib.rs:613-672)
+    Family claims{"task_claims_total", nullptr, "Total number of task claim attempts by stream and result", nullptr,
+                  {"task_stream", "result"}, nullptr, 0, {}};
+    Family processing{"task_processing_total", "task_processing_end_to_end_seconds",
+                      "Total number of task processing attempts by type and status",
+                      "End-to-end duration of task processing in the worker loop", {"task_type", "status"}, E2E_BUCKETS,
+                      sizeof E2E_BUCKETS / sizeof *E2E_BUCKETS, {}};
+    Family retries{"task_retry_attempts_total", nullptr, "Total number of task retry transitions by type", nullptr,
+                   {"task_type"}, nullptr, 0, {}};
+    Family exhausted{"task_max_retries_exhausted_total", nullptr,
+                     "Total number of tasks that stopped retrying and failed permanently", nullptr, {"task_type"}, nullptr, 0, {}};
+    void record_task_claim(const char* stream, const char* result) {
+        std::lock_guard<std::mutex> g(mu);
+        claims.observe({stream, result}, 0);
+    }
+    void record_task_processing(const std::string& type, const char* status, double s) {
+        std::lock_guard<std::mutex> g(mu);
+        processing.observe({type, status}, s);
+    }
+    void record_task_retry_attempt(const std::string& type) {
+        std::lock_guard<std::mutex> g(mu);
+        retries.observe({type}, 0);
+    }
+    void record_task_max_retries_exhausted(const std::string& type) {
+        std::lock_guard<std::mutex> g(mu);
+        exhausted.observe({type}, 0);
+    }
     // helpers::record_task_operation / record_task (metrics.rs:298-300,323-335)
     void record_task_operation(const char* task_name, const char* op, const char* status, double s) {
         std::lock_guard<std::mutex> g(mu);
@@ -287,6 +318,10 @@ struct Metrics {
         std::string out;
         task.render(out);
         redis.render(out);
+        claims.render(out);
+        processing.render(out);
+        retries.render(out);
+        exhausted.render(out);
         return out;
     }
 };
@@ -456,7 +491,7 @@ struct Lane {
 // a proved segment on its way through the host half of the task
 struct Pending {
     bx_ready_task task;
-    Clock::time_point start;
+    Clock::time_point start, claimed;
     std::string job_prefix, segment_key;
     uint64_t seg_index = 0;
     uint32_t po2 = 0;
@@ -715,14 +750,30 @@ struct bx_agent {
         return "";
     }
 
+    // Agent::task_type_label (prover/crates/workflow/src/lib.rs:299-310) + TaskType::to_job_type_str (workflow-common lib.rs:176-187)
+    static std::string task_type_label(const bx_ready_task& task) {
+        JVal def;
+        if (!parse_json(task.task_def, &def)) return "invalid_task";
+        std::string variant;
+        if (def.kind == JVal::Obj && def.obj.size() == 1) variant = def.obj[0].first;
+        else if (def.kind == JVal::Str) variant = def.s;  // unit variant: "Finalize"
+        static const char* names[][2] = {{"Executor", "executor"}, {"Prove", "prove-lift"}, {"Join", "join"},   {"Resolve", "resolve"},
+                                         {"Finalize", "finalize"}, {"Snark", "snark"},      {"Keccak", "keccak"}, {"Union", "union"}};
+        for (auto& n : names)
+            if (variant == n[0]) return n[1];
+        return "invalid_task";
+    }
+
     // the error arm of poll_work (lib.rs:381-436); returns "" or a fatal task-db error
     std::string handle_failure(const bx_ready_task& task, std::string err) {
         char eb[256] = {0};
+        const std::string type = task_type_label(task);
         if (task.max_retries > 0) {
             int32_t cur = 0;
             int found = taskdb.current_retries(taskdb.user, task.job_id, task.task_id, &cur, eb, sizeof eb);
             if (found < 0) return std::string("[BENTO-WF-109] Failed to read current retries: ") + eb;
             if (found == 1 && cur + 1 > task.max_retries) {
+                metrics.record_task_max_retries_exhausted(type);
                 if (err.size() > 1024) err.resize(1024);
                 std::string final_err = err.empty() ? "retry max hit" : "retry max hit: " + err;
                 if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, final_err.c_str(), eb, sizeof eb) < 0)
@@ -731,7 +782,11 @@ struct bx_agent {
             }
             int rc = taskdb.update_task_retry(taskdb.user, task.job_id, task.task_id, eb, sizeof eb);
             if (rc < 0) return std::string("[BENTO-WF-111] Failed to update task retries: ") + eb;
+            // update_task_retry's bool (lib.rs:664-669): requeued, or the task db itself stopped retrying
+            if (rc > 0) metrics.record_task_retry_attempt(type);
+            else metrics.record_task_max_retries_exhausted(type);
         } else {
+            metrics.record_task_max_retries_exhausted(type);
             if (err.size() > 1024) err.resize(1024);
             if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, err.c_str(), eb, sizeof eb) < 0)
                 return std::string("[BENTO-WF-112] Failed to report task failure: ") + eb;
@@ -761,6 +816,9 @@ struct bx_agent {
                     } catch (const std::exception& e) {
                         err = std::string("[BENTO-WF-115] Prove failed: exception in the host half: ") + e.what();
                     }
+                    // end to end = both halves of process_work; with the host half of segment k overlapping the device half
+                    // of k+1 this is the task's latency, not the lane's occupancy
+                    metrics.record_task_processing(task_type_label(p->task), err.empty() ? "success" : "error", secs_since(p->claimed));
                     if (err.empty()) {
                         done->fetch_add(1);
                         lanes[lane]->done.fetch_add(1);
@@ -787,6 +845,7 @@ struct bx_agent {
             bx_ready_task task;
             char eb[256] = {0};
             int rc = taskdb.request_work(taskdb.user, cfg.task_stream, &task, eb, sizeof eb);
+            metrics.record_task_claim(cfg.task_stream, rc < 0 ? "error" : rc == 0 ? "empty" : "claimed");  // lib.rs:613-623
             if (rc < 0) {
                 set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + eb);
                 break;
@@ -803,6 +862,7 @@ struct bx_agent {
             }
             idle = 0;
             Pending* p = &slots[cur];
+            p->claimed = Clock::now();  // processing_start, lib.rs:629
             std::string err;
             try {
                 err = dispatch(lane, task, p);
@@ -812,6 +872,7 @@ struct bx_agent {
             if (!err.empty()) {
                 std::string f;
                 try {
+                    metrics.record_task_processing(task_type_label(task), "error", secs_since(p->claimed));
                     f = handle_failure(task, err);
                 } catch (const std::exception& e) {
                     f = std::string("exception while recording a task failure: ") + e.what();
@@ -1057,9 +1118,11 @@ const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok
     if (!a || !task) return "bx_agent_process_one: NULL argument";
     try {
         Pending p;
+        p.claimed = Clock::now();
         bool fatal = false;
         std::string err = a->dispatch(0, *task, &p);
         if (err.empty()) err = a->complete(&p, &fatal);
+        a->metrics.record_task_processing(bx_agent::task_type_label(*task), err.empty() ? "success" : "error", secs_since(p.claimed));
         if (ok) *ok = err.empty();
         if (err.empty()) {
             a->lanes[0]->done.fetch_add(1);

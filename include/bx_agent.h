@@ -191,8 +191,14 @@ const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* ta
 void bx_agent_stop(bx_agent* a);
 /* Run one already-claimed task on lane 0 (process_work + the error bookkeeping of poll_work). *ok = 1 when it succeeded. */
 const char* bx_agent_process_one(bx_agent* a, const bx_ready_task* task, int* ok);
-/* Prometheus text exposition of task_operations_total, task_duration_seconds, redis_operations_total and
- * redis_operation_duration_seconds with the reference's labels and buckets; returns the needed size. */
+/* Prometheus text exposition, with the reference's names, labels, help strings and buckets, of
+ *   task_operations_total / task_duration_seconds, redis_operations_total / redis_operation_duration_seconds
+ *       (bento/crates/workflow-common/src/metrics.rs:60-120), and
+ *   task_claims_total{task_stream,result}, task_processing_total / task_processing_end_to_end_seconds{task_type,status},
+ *   task_retry_attempts_total{task_type}, task_max_retries_exhausted_total{task_type}
+ *       (the next-gen worker loop: prover/crates/workflow-common/src/metrics.rs:44-80, recorded as in
+ *       prover/crates/workflow/src/lib.rs:613-675; task_type is TaskType::to_job_type_str, "prove-lift" for a Prove task).
+ * Returns the needed size. */
 size_t bx_agent_metrics(bx_agent* a, char* out, size_t cap);
 /* Lanes of the agent (n_devices * inflight; lane l belongs to devices[l / inflight]), the device of a lane (informational
  * with an injected prover, which receives the lane index) and how many tasks the lane completed. */

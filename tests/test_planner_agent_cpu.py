@@ -156,6 +156,16 @@ def test_prove_task_key_scheme_cleanup_and_metrics():
     for op in ("get", "set_ex", "unlink"):
         assert f'redis_operations_total{{operation_type="{op}",status="success"}} 1' in text
     assert 'redis_operation_duration_seconds_bucket{operation_type="get",status="success",le="0.001"}' in text
+    # the next-gen worker loop's series (prover/crates/workflow/src/lib.rs:613-637): one claim served, then the queue is empty
+    assert 'task_claims_total{task_stream="prove",result="claimed"} 1' in text
+    # ... 1 or 2 times: a poll that finds the queue empty while the finisher still holds a task is repeated once it is idle
+    import re
+    assert int(re.search(r'task_claims_total\{task_stream="prove",result="empty"\} (\d+)', text).group(1)) in (1, 2)
+    assert 'task_processing_total{task_type="prove-lift",status="success"} 1' in text  # to_job_type_str, workflow-common lib.rs:179
+    assert 'task_processing_end_to_end_seconds_bucket{task_type="prove-lift",status="success",le="0.01"}' in text
+    assert 'task_processing_end_to_end_seconds_count{task_type="prove-lift",status="success"} 1' in text
+    assert "# TYPE task_claims_total counter" in text and "# TYPE task_processing_end_to_end_seconds histogram" in text
+    assert "task_retry_attempts_total{" not in text and "task_max_retries_exhausted_total{" not in text
     a.close()
 
 
@@ -179,6 +189,12 @@ def test_poll_loop_retries_then_succeeds_and_fails_after_max_retries():
     assert a.poll_work(max_idle_polls=1) == 1
     row = a.taskdb.rows()[0]
     assert row.state == "done" and row.retries == 2
+    text = a.metrics_text()  # lib.rs:664-666: every requeue is a retry attempt; each attempt is one processing sample
+    assert 'task_retry_attempts_total{task_type="prove-lift"} 2' in text
+    assert 'task_processing_total{task_type="prove-lift",status="error"} 2' in text
+    assert 'task_processing_total{task_type="prove-lift",status="success"} 1' in text
+    assert 'task_claims_total{task_stream="prove",result="claimed"} 3' in text
+    assert "task_max_retries_exhausted_total{" not in text
     a.close()
     # a task whose segment blob is missing exhausts its retries and is failed with "retry max hit: ..." (lib.rs:395-413);
     # the agent survives and serves the next task
@@ -191,7 +207,21 @@ def test_poll_loop_retries_then_succeeds_and_fails_after_max_retries():
     assert states == {"missing": ("failed", 1), "ok": ("done", 0)}
     err = a2.taskdb.task("j", "missing").error
     assert err.startswith("retry max hit: [BENTO-WF-115] Prove failed: segment data not found for segment key: job:j:segments:5")
+    text = a2.metrics_text()  # one requeue, then the limit (lib.rs:650-661)
+    assert 'task_retry_attempts_total{task_type="prove-lift"} 1' in text
+    assert 'task_max_retries_exhausted_total{task_type="prove-lift"} 1' in text
     a2.close()
+    # max_retries == 0: the first failure is final (lib.rs:670-675); a task_def that does not parse is labelled invalid_task
+    a3 = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01)
+    a3.taskdb.create_task("j", "t", {"Prove": {"index": 0}}, max_retries=0)
+    assert a3.process_one("j", "t", '{"Nope":{}}', max_retries=0) is False
+    a3.taskdb.create_task("j", "u", {"Prove": {"index": 0}}, max_retries=0)
+    assert a3.process_one("j", "u", '{"Join":{"idx":1,"left":2,"right":3}}', max_retries=0) is False
+    text = a3.metrics_text()
+    assert 'task_max_retries_exhausted_total{task_type="invalid_task"} 1' in text
+    assert 'task_max_retries_exhausted_total{task_type="join"} 1' in text
+    assert 'task_processing_total{task_type="invalid_task",status="error"} 1' in text
+    a3.close()
 
 
 def test_long_errors_are_truncated_before_reaching_the_db():
