@@ -125,12 +125,49 @@ inline int ilog2(size_t n) {
     return k;
 }
 
-// RAII bracket: records hipEvents around an entry point when profiling is on.
+// roctx ranges for rocprofv3 --marker-trace (bx_trace_enable, bx_hal.h): process-wide, off by default.  The roctx library
+// is looked up with dlopen when tracing is switched on, so the HAL has no link-time dependency on the profiler.
+int trace_level();  // 0 off, 1 ranges, 2 ranges + a stream sync at the end of every prover stage
+void trace_push(const char* name);
+void trace_pop();
+// A named stage of bx_prove_segment (upstream brackets the same stages with nvtx ranges / tracing spans).  At level 2 the
+// ctx's stream is drained before the range closes, so the host-side range is the stage's device time.
+struct TraceRange {
+    bx_ctx* c;
+    bool on;
+    TraceRange(bx_ctx* ctx, const char* name) : c(ctx), on(trace_level() > 0) {
+        if (on) trace_push(name);
+    }
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+
+// The same for a run of consecutive stages in straight-line code: next() closes the open range and opens another.
+struct TraceStages {
+    bx_ctx* c;
+    bool open = false;
+    explicit TraceStages(bx_ctx* ctx) : c(ctx) {}
+    void close();
+    void next(const char* name) {
+        close();
+        if (trace_level() > 0) {
+            trace_push(name);
+            open = true;
+        }
+    }
+    ~TraceStages() { close(); }
+    TraceStages(const TraceStages&) = delete;
+    TraceStages& operator=(const TraceStages&) = delete;
+};
+
+// RAII bracket: records hipEvents around an entry point when profiling is on, and a roctx range when tracing is.
 struct OpScope {
     bx_ctx* c;
     const char* name;
     double bytes;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool traced = false;
     OpScope(bx_ctx* ctx, const char* n, double b);
     ~OpScope();
 };

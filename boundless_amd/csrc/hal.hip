@@ -3,8 +3,12 @@
 // Counterpart of the device/buffer half of risc0_zkp::hal::Hal (alloc_*, copy_from_*, Buffer::view) that the
 // agent's prover object owns for the process lifetime (bento/crates/workflow/src/lib.rs:192,246-249: one
 // `Rc<dyn ProverServer>` per agent process = one per GPU, compose.yml:113).
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 
 #include "ctx.hpp"
@@ -23,13 +27,67 @@ static hipEvent_t get_event(bx_ctx* c) {
     return e;
 }
 
+// ---- roctx ranges ----
+namespace {
+struct TraceApi {
+    std::atomic<int> level{0};
+    std::mutex mu;
+    void* lib = nullptr;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+} g_trace;
+}  // namespace
+int trace_level() { return g_trace.level.load(std::memory_order_acquire); }
+void trace_push(const char* name) { (void)g_trace.push(name); }
+void trace_pop() { (void)g_trace.pop(); }
+TraceRange::~TraceRange() {
+    if (!on) return;
+    if (trace_level() >= 2 && c) (void)hipStreamSynchronize(c->stream);
+    trace_pop();
+}
+void TraceStages::close() {
+    if (!open) return;
+    if (trace_level() >= 2 && c) (void)hipStreamSynchronize(c->stream);
+    trace_pop();
+    open = false;
+}
+static const char* trace_set(int level) {
+    if (level < 0 || level > 2) return "bx_trace_enable: level must be 0, 1 or 2";
+    std::lock_guard<std::mutex> g(g_trace.mu);
+    if (level > 0 && !g_trace.push) {
+        // rocprofv3 intercepts the rocprofiler-sdk flavour; libroctx64 is roctracer's (rocprof v1/v2)
+        static const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+        for (const char* n : names) {
+            void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            auto pu = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            auto po = (int (*)())dlsym(h, "roctxRangePop");
+            if (pu && po) {
+                g_trace.lib = h;
+                g_trace.pop = po;
+                g_trace.push = pu;
+                break;
+            }
+            dlclose(h);
+        }
+        if (!g_trace.push) return "bx_trace_enable: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) could be loaded";
+    }
+    g_trace.level.store(level, std::memory_order_release);
+    return nullptr;
+}
+
 OpScope::OpScope(bx_ctx* ctx, const char* n, double b) : c(ctx), name(n), bytes(b) {
+    if (trace_level() > 0) {
+        traced = true;
+        trace_push(name);
+    }
     if (!c->profile) return;
     e0 = get_event(c);
     e1 = get_event(c);
     if (e0) (void)hipEventRecord(e0, c->stream);
 }
 OpScope::~OpScope() {
+    if (traced) trace_pop();
     if (!c->profile || !e0 || !e1) return;
     (void)hipEventRecord(e1, c->stream);
     c->prof_pending.push_back(ProfRec{name, bytes, e0, e1});
@@ -56,9 +114,18 @@ static void drain_profile(bx_ctx* c) {
 
 using namespace bx;
 
+extern "C" const char* bx_trace_enable(int level) { return trace_set(level); }
+extern "C" int bx_trace_level(void) { return trace_level(); }
+
 extern "C" const char* bx_init(int device, bx_ctx** out) {
     if (!out) return "bx_init: null out pointer";
     *out = nullptr;
+    if (const char* env = getenv("BX_TRACE")) {  // BX_TRACE=1|2: ranges on from the first context on
+        static std::once_flag once;
+        const char* terr = nullptr;
+        std::call_once(once, [&] { terr = trace_set(atoi(env)); });
+        if (terr) return terr;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return "bx_init: no HIP device visible (the HIP HAL has no CPU fallback)";
     if (device < 0 || device >= n) return "bx_init: device index out of range";

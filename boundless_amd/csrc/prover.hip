@@ -341,6 +341,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     const uint32_t po2 = p->shape.po2;
     Transcript T(&p->h2);
     T.seal.reserve(p->seal_bound);
+    TraceRange whole(c, "bx:prove_segment");
 
     // ---- header ----
     {
@@ -357,7 +358,10 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     Fp4 beta = f4_zero();
     uint32_t globals[BX_MAX_GLOBALS];
     memset(globals, 0, sizeof globals);
-    PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed, globals));
+    {
+        TraceRange tr(c, "bx:witgen");
+        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed, globals));
+    }
     if (p->n_globals) {  // the statement's public words: in the seal and in the transcript before any commitment
         uint32_t dg[8];
         for (uint32_t i = 0; i < p->n_globals; ++i)
@@ -368,10 +372,13 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     }
     for (int g = 0; g < 3; ++g) {
         Group& G = p->groups[g];
+        static const char* const commit_names[3] = {"bx:commit_code", "bx:commit_data", "bx:commit_accum"};
         if (g == 2) {
             beta = T.random_ext();
+            TraceRange tr(c, "bx:accumulate");
             PV(circ->accumulate(circ->user, p->circ_state, c, G.coeffs.b, beta.c, seed));  // CircuitHal::accumulate
         }
+        TraceRange tr(c, commit_names[g]);
         PV(commit_group(p, G, T));
         memcpy(p->last_roots + 8 * g, G.tree.root, 32);
     }
@@ -380,8 +387,12 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     {
         Fp4 poly_mix = T.random_ext();
         // the 16N-word check buffer holds the 4 ext planes over the 4N domain                       (CircuitHal::eval_check)
-        PV(circ->eval_check(circ->user, p->circ_state, c, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b,
-                            p->groups[2].evaluated.b, poly_mix.c, beta.c, globals));
+        {
+            TraceRange tr(c, "bx:eval_check");
+            PV(circ->eval_check(circ->user, p->circ_state, c, CK.coeffs.b, p->groups[0].evaluated.b, p->groups[1].evaluated.b,
+                                p->groups[2].evaluated.b, poly_mix.c, beta.c, globals));
+        }
+        TraceRange tr(c, "bx:commit_check");
         PV(bx_batch_interpolate_ntt(c, CK.coeffs.b, 4));        // 4 polynomials of size 4N
         PV(bx_zk_shift(c, CK.coeffs.b, BX_CHECK_SIZE));         // viewed as 16 polynomials of size N
         PV(bx_batch_expand_into_evaluate_ntt(c, CK.evaluated.b, CK.coeffs.b, BX_CHECK_SIZE, 2));
@@ -390,6 +401,8 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         memcpy(p->last_roots + 24, CK.tree.root, 32);
     }
     // ---- DEEP: evaluate every tap at Z * back_one^back, write/commit coeff_u ----
+    TraceStages stage(c);
+    stage.next("bx:deep_taps");
     const Fp4 Z = T.random_ext();
     const uint32_t back_one = fp_inv(fp_pow(fp_encode(137u), (uint64_t)1 << (27 - po2)));  // ROU_REV[po2] = w_N^-1
     // check columns hold g(3z) of the split check(y) = sum_q y^q g_q(y^4), so their tap is z = Z^4 / 3: the verifier can
@@ -474,6 +487,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         T.commit(dg);
     }
     // ---- DEEP: mix every column into its combo, subtract the mixed u polynomials, divide by every tap point ----
+    stage.next("bx:deep_combos");
     const Fp4 mix = T.random_ext();
     if (hipMemsetAsync(p->combos.b.dptr, 0, p->combos.b.len * 4, c->stream) != hipSuccess) return perr(p, "bx_prove_segment: memset failed");
     {
@@ -518,6 +532,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     PV(bx_batch_bit_reverse(c, p->final_poly.b, 4));
 
     // ---- fri_prove ----
+    stage.next("bx:fri_prove");
     {
         bx_buf coeffs = p->final_poly.b;
         for (FriRound& r : p->rounds) {
@@ -538,6 +553,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
     }
     // ---- queries: positions come only from the RNG (writes do not feed it), so draw all 50 first, gather each tree
     //      for the whole batch on the device, then lay the seal out in upstream's query-major order ----
+    stage.next("bx:queries");
     {
         const unsigned bits = (unsigned)ilog2(D);
         uint32_t pos0[BX_QUERIES];
@@ -567,6 +583,7 @@ extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* s
         for (int q = 0; q < BX_QUERIES; ++q)
             for (size_t t = 0; t < n_trees; ++t) T.write(host_all.data() + off[t] + (size_t)q * qw[t], qw[t]);
     }
+    stage.close();
     if (seal_words) *seal_words = T.seal.size();
     if (T.seal.size() > seal_cap) return perr(p, "bx_prove_segment: seal buffer too small");
     memcpy(seal_out, T.seal.data(), T.seal.size() * 4);

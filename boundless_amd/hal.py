@@ -106,10 +106,26 @@ def load_library():
         fn.restype = cp
     L.bx_get_stream.argtypes = [ctx]
     L.bx_get_stream.restype = C.c_void_p
+    L.bx_trace_enable.argtypes = [C.c_int]
+    L.bx_trace_enable.restype = cp
+    L.bx_trace_level.argtypes = []
+    L.bx_trace_level.restype = C.c_int
     _lib = L
     return L
 
 
+
+
+def trace_enable(level=1):
+    """roctx ranges around every HAL entry point and prover stage, for `rocprofv3 --marker-trace` (bx_trace_enable, bx_hal.h):
+    0 off, 1 ranges, 2 ranges + a stream sync at the end of every prover stage.  Process-wide; no GPU needed to switch."""
+    msg = load_library().bx_trace_enable(int(level))
+    if msg:
+        raise HalError(msg.decode())
+
+
+def trace_level():
+    return int(load_library().bx_trace_level())
 
 
 def _words(a):

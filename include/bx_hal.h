@@ -158,6 +158,15 @@ const char* bx_timer_stop(bx_ctx* ctx, float* ms_out); /* blocks */
 const char* bx_profile_enable(bx_ctx* ctx, int on);
 const char* bx_profile_reset(bx_ctx* ctx);
 const char* bx_profile_report(bx_ctx* ctx, char* json_out, size_t cap); /* blocks */
+/* Tracing: roctx ranges around every HAL entry point (named as in bx_profile_report) and around the stages of
+ * bx_prove_segment ("bx:witgen", "bx:commit_code", ... "bx:queries"), for `rocprofv3 --marker-trace --kernel-trace`.
+ * [EXT] risc0's prover brackets its stages the same way (nvtx `scope!` ranges under its CUDA HAL); the reference's own
+ * crates only log task-level `tracing` events (bento/crates/workflow/src/tasks/prove.rs:28,50-51,115).  Process-wide.  level 0 = off (default),
+ * 1 = ranges, 2 = ranges + the ctx's stream drained at the end of every prover stage, so that a stage's host-side range is
+ * its device time (costs the overlap between stages: a measurement mode).  The roctx library is dlopen'ed on first use;
+ * an error is returned if none is installed.  The environment variable BX_TRACE=1|2 switches it on at the first bx_init. */
+const char* bx_trace_enable(int level);
+int bx_trace_level(void);
 /* Tunables (NTT pass split, tile sizes); name/value pairs documented in DESIGN.md.  Unknown names error. */
 const char* bx_set_tunable(bx_ctx* ctx, const char* name, long value);
 

@@ -41,6 +41,20 @@ def test_python_binding_declares_the_same_surface(libpath):
         assert getattr(lib, s) is not None
 
 
+def test_tracing_switch_needs_no_gpu_and_rejects_bad_levels(libpath):
+    """bx_trace_enable dlopen's the roctx library of the ROCm install; without a profiler attached the ranges are no-ops."""
+    from boundless_amd import hal
+
+    assert hal.trace_level() == 0  # off unless asked for (BX_TRACE is read by bx_init, which this process never reaches)
+    hal.trace_enable(2)
+    assert hal.trace_level() == 2
+    with pytest.raises(hal.HalError, match="level must be 0, 1 or 2"):
+        hal.trace_enable(3)
+    assert hal.trace_level() == 2
+    hal.trace_enable(0)
+    assert hal.trace_level() == 0
+
+
 def test_init_fails_loudly_without_gpu(libpath):
     import torch
 

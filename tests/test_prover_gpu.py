@@ -80,6 +80,25 @@ def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
     assert np.array_equal(seals[1], want)
 
 
+def test_roctx_ranges_do_not_change_the_seal():
+    """bx_trace_enable: ranges only (1) and ranges + a stream drain per stage (2) give the seal of the untraced run."""
+    from boundless_amd import hal as H
+    from boundless_amd.prover import HipProverServer, Segment
+
+    srv = HipProverServer(0, po2=13, widths=(3, 9, 4))
+    try:
+        seals = []
+        for level in (0, 1, 2):
+            H.trace_enable(level)
+            seals.append(srv.prove_segment(Segment(0, 13, 99)).seal)
+    finally:
+        H.trace_enable(0)
+        srv.close()
+    assert np.array_equal(seals[0], seals[1]) and np.array_equal(seals[0], seals[2])
+    want, _ = ol.prove_segment(13, 3, 9, 4, 99)
+    assert np.array_equal(seals[0], want)
+
+
 def test_seal_is_deterministic_and_shape_errors():
     from boundless_amd.hal import HalError
     from boundless_amd.prover import HipProverServer, Segment
