@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="BASELINE configs[2]: prove this many segments in total, claimed from a shared queue (--steal) instead of --steps per rank")
     ap.add_argument("--steal", action="store_true", help="claim-when-idle ticket queue instead of the static rank split")
     ap.add_argument("--dist-backend", type=str, default=None, help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 path be exercised on a single-GPU box")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank (under torchrun): exercises the RCCL rendezvous, barrier and all-reduce of the N>1 path on a one-GPU box")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index for every rank (testing only; default LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
@@ -181,7 +182,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
-    rank, world, local_rank, dist = init_distributed(args.dist_backend)
+    rank, world, local_rank, dist = init_distributed(args.dist_backend, force=args.force_dist)
     if args.device is not None:
         local_rank = args.device
     torch.cuda.set_device(local_rank)
@@ -391,6 +392,7 @@ def main():
                        "po2": args.po2, "segments_proved": proved_total, "segments_in_flight_per_gpu": len(servers),
                        "queue": ("claim-when-idle ticket queue (c10d store)" if args.steal else "static rank split"),
                        "parallelism": f"segments sharded over {world} GPU(s), no collective",
+                       "rendezvous": (None if dist is None else f"torch.distributed/{dist.get_backend()}"),
                        "circuit": circuit_view},
             "seal_words": int(receipt.seal.size),
             "roofline": roofline,

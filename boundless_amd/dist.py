@@ -10,12 +10,15 @@ import os
 import time
 
 
-def init_distributed(backend=None):
-    """Returns (rank, world, local_rank, dist or None).  Rendezvous from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+def init_distributed(backend=None, force=False):
+    """Returns (rank, world, local_rank, dist or None).  Rendezvous from RANK/WORLD_SIZE/MASTER_* (torchrun).
+
+    A single process needs no process group; `force` creates one anyway (under torchrun), so that the RCCL start-up, barrier
+    and all-reduce the N > 1 runs depend on can be exercised on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world <= 1:
+    if world <= 1 and not (force and "MASTER_PORT" in os.environ):
         return rank, 1, local_rank, None
     import torch
     import torch.distributed as dist
@@ -46,7 +49,7 @@ class SegmentQueue:
         self._store = None
         self._key = f"{name}:next"
         self._local = 0
-        if mode == "steal" and world > 1:
+        if mode == "steal" and dist is not None:
             from torch.distributed import distributed_c10d
 
             self._store = distributed_c10d._get_default_store()

@@ -198,3 +198,37 @@ def test_default_multi_rank_bench_path_static_split_is_bit_exact(tmp_path):
         for i in dumps[k]["indices"].tolist():
             want, _ = ol.prove_segment(po2, 4, 12, 4, Segment.synthetic(i, po2=po2).seed)
             assert np.array_equal(dumps[k][f"seal_{i}"], want), f"segment {i} proved by rank {k}"
+
+
+def test_rccl_rendezvous_barrier_and_all_reduce_of_the_multi_rank_path(tmp_path):
+    """The driver's N > 1 command uses the default backend (nccl = RCCL), which two ranks cannot share one GPU for.  What a
+    one-GPU box can run of it is one rank with the process group forced on: RCCL initialises on the device, the barriers of
+    the timed region and the max / sum all-reduces of the timing run on it, the ticket queue goes through the c10d store."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from boundless_amd.prover import Segment
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    po2 = 12
+    for extra, want_indices in ((["--steps", "2"], [0, 1, 2, 3]), (["--steps", "1", "--steal", "--batch", "5"], [0, 1, 2, 3, 4])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+               "--no-agent-mode", "--po2", str(po2), "--widths", "4,12,4", "--warmup", "1", "--inflight", "2", "--dump", str(tmp_path)] + extra
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["config"]["rendezvous"] == "torch.distributed/nccl" and out["n_gpus"] == 1
+        d = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+        assert sorted(d["indices"].tolist()) == want_indices
+        for i in want_indices:
+            want, _ = ol.prove_segment(po2, 4, 12, 4, Segment.synthetic(i, po2=po2).seed)
+            assert np.array_equal(d[f"seal_{i}"], want)

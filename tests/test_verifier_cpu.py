@@ -31,6 +31,22 @@ def _regions(n):
     }
 
 
+def test_honest_seals_of_random_shapes_are_accepted_and_one_flipped_bit_is_not():
+    """The same seeded shape sweep the GPU parity test proves (tests/test_prover_gpu.py), here oracle -> verifier."""
+    rng = np.random.default_rng(20260927)
+    for _ in range(12):
+        po2 = int(rng.integers(9, 14))
+        widths = (int(rng.integers(1, 24)), int(rng.integers(1, 48)), int(rng.integers(1, 14)))
+        terms, degree, seed = int(rng.integers(1, 65)), int(rng.integers(1, 6)), int(rng.integers(0, 2**63))
+        seal, _ = ol.prove_segment(po2, *widths, seed, terms=terms, degree=degree)
+        verify_seal(seal)
+        bad = seal.copy()
+        at = int(rng.integers(0, seal.size))
+        bad[at] ^= np.uint32(1 << int(rng.integers(0, 30)))
+        with pytest.raises(HalError):
+            verify_seal(bad)
+
+
 def test_tampering_anywhere_is_rejected():
     seal, _ = ol.prove_segment(10, 4, 8, 4, 1234)
     verify_seal(seal)
