@@ -368,19 +368,6 @@ struct SynthState {
     Circuit cc;
     bx_buf perm_offsets{nullptr, 0}, perm_index{nullptr, 0}, acc_src{nullptr, 0}, acc_run{nullptr, 0}, betas{nullptr, 0}, mixpows{nullptr, 0};
 };
-Circuit circuit_of(const bx_segment_params* s) { return Circuit(s->po2, s->w_code, s->w_data, s->w_accum, s->cons_terms, s->cons_degree); }
-
-const char* synth_normalize(void*, bx_segment_params* s) {
-    if (!s) return "circuit: null shape";
-    if (s->cons_terms > BX_CIRCUIT_MAX_TERMS || s->cons_degree > BX_CIRCUIT_MAX_DEGREE)
-        return "synthetic circuit: cons_terms must be <= 64 and cons_degree <= 5 (0 = default)";
-    if (!s->cons_terms) s->cons_terms = BX_CIRCUIT_DEFAULT_TERMS;
-    if (!s->cons_degree) s->cons_degree = BX_CIRCUIT_DEFAULT_DEGREE;
-    return nullptr;
-}
-uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_t col, uint32_t backs_out[BX_MAX_TAPS]) {
-    return circuit_of(s).backs_of(group, col, backs_out);
-}
 void synth_destroy(void*, void* state) {
     auto* st = (SynthState*)state;
     if (!st) return;
@@ -409,7 +396,6 @@ const char* synth_create(void*, bx_ctx* c, const bx_segment_params* shape, void*
     *state = st;
     return nullptr;
 }
-uint32_t synth_n_globals(void*, const bx_segment_params* s) { return circuit_of(s).globals(); }
 __global__ void globals_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ data, Circuit cc) {
     const size_t n = (size_t)1 << cc.po2;
     if (threadIdx.x == 0) out[0] = data[0];                                  // data[0][0]

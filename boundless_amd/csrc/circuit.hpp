@@ -82,4 +82,20 @@ struct Circuit {
     BX_CIRC_HD static constexpr int slot1_back(uint32_t j) { return j % 8 == 0 ? 1 : (j % 8 == 4 ? 2 : 0); }
 };
 
+// The host-only entries of the synthetic circuit's bx_circuit_ops table (shape handling; no device work): shared by the
+// library's table (circuit.hip) and by host-only builds of the verifier (tests/verify_fuzz_check.cpp).
+inline Circuit circuit_of(const bx_segment_params* s) { return Circuit(s->po2, s->w_code, s->w_data, s->w_accum, s->cons_terms, s->cons_degree); }
+inline const char* synth_normalize(void*, bx_segment_params* s) {
+    if (!s) return "circuit: null shape";
+    if (s->cons_terms > BX_CIRCUIT_MAX_TERMS || s->cons_degree > BX_CIRCUIT_MAX_DEGREE)
+        return "synthetic circuit: cons_terms must be <= 64 and cons_degree <= 5 (0 = default)";
+    if (!s->cons_terms) s->cons_terms = BX_CIRCUIT_DEFAULT_TERMS;
+    if (!s->cons_degree) s->cons_degree = BX_CIRCUIT_DEFAULT_DEGREE;
+    return nullptr;
+}
+inline uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_t col, uint32_t* backs_out /* BX_MAX_TAPS */) {
+    return circuit_of(s).backs_of(group, col, backs_out);
+}
+inline uint32_t synth_n_globals(void*, const bx_segment_params* s) { return circuit_of(s).globals(); }
+
 }  // namespace bx

@@ -81,6 +81,7 @@ struct JScan {
     const char* p;
     const char* end;
     bool ok = true;
+    int depth = 0;  // nesting of the value being skipped (bounded: the recursion below is on the C stack)
     void ws() {
         while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
     }
@@ -124,6 +125,12 @@ struct JScan {
         if (p >= end) return ok = false;
         if (*p == '"') return str(nullptr);
         if (*p == '{' || *p == '[') {
+            if (depth >= 64) return ok = false;
+            struct Nest {
+                int& d;
+                explicit Nest(int& x) : d(x) { ++d; }
+                ~Nest() { --d; }
+            } nest(depth);
             const char open = *p, close = open == '{' ? '}' : ']';
             ++p;
             ws();
@@ -178,12 +185,26 @@ const std::string* member(const std::vector<std::pair<std::string, std::string>>
         if (kv.first == key) return &kv.second;
     return nullptr;
 }
+// an i32 as serde reads one: an integer literal in range, nothing else (a string, a fraction or an overflow is a decode error)
+bool json_i32_value(const std::string& raw, int32_t* out) {
+    if (raw.empty() || raw.size() > 11) return false;
+    size_t i = raw[0] == '-' ? 1 : 0;
+    if (i == raw.size()) return false;
+    for (size_t k = i; k < raw.size(); ++k)
+        if (raw[k] < '0' || raw[k] > '9') return false;
+    long long v = strtoll(raw.c_str(), nullptr, 10);
+    if (v < INT32_MIN || v > INT32_MAX) return false;
+    *out = (int32_t)v;
+    return true;
+}
 bool json_string_value(const std::string& raw, std::string* out) {
     JScan j{raw.data(), raw.data() + raw.size()};
     return j.str(out);
 }
 
 // ---- one HTTP/1.1 exchange ----
+// a segment blob is ~80 MB (bento/crates/workflow/src/tasks/executor.rs:45); nothing this client fetches comes near the cap
+constexpr size_t MAX_RESPONSE_BYTES = (size_t)1 << 31;
 struct Response {
     int status = 0;
     std::string body;
@@ -252,6 +273,10 @@ std::string http_call(bx_rest_client* c, const char* method, const std::string& 
             return e;
         }
         if (k == 0) break;
+        if (raw.size() + (size_t)k > MAX_RESPONSE_BYTES) {
+            close(fd);
+            return "response larger than " + std::to_string(MAX_RESPONSE_BYTES >> 20) + " MiB";
+        }
         raw.append(buf, (size_t)k);
     }
     close(fd);
@@ -268,9 +293,12 @@ std::string http_call(bx_rest_client* c, const char* method, const std::string& 
         for (;;) {
             size_t le = payload.find("\r\n", pos);
             if (le == std::string::npos) return "malformed chunked body";
-            size_t n = strtoul(payload.substr(pos, le - pos).c_str(), nullptr, 16);
+            char* num_end = nullptr;
+            const std::string num = payload.substr(pos, le - pos);
+            size_t n = strtoull(num.c_str(), &num_end, 16);
+            if (num_end == num.c_str()) return "malformed chunked body";  // no hex digits where a chunk size belongs
             if (n == 0) break;
-            if (le + 2 + n > payload.size()) return "truncated chunked body";
+            if (n > payload.size() - (le + 2)) return "truncated chunked body";  // (also: a size that would wrap the offsets)
             de.append(payload, le + 2, n);
             pos = le + 2 + n + 2;
         }
@@ -325,11 +353,13 @@ int rest_request_work(void* user, const char* stream, bx_ready_task* out, char* 
             return put_err(eb, cap, "GPU work claim response lacks job_id / task_id / task_def / max_retries"), -1;
         if (job_s.size() >= sizeof out->job_id || task_s.size() >= sizeof out->task_id || def->size() >= sizeof out->task_def)
             return put_err(eb, cap, "claimed task " + job_s + ":" + task_s + " does not fit bx_ready_task"), -1;
+        int32_t max_retries = 0;
+        if (!json_i32_value(*mr, &max_retries)) return put_err(eb, cap, "failed to decode GPU work claim response: max_retries is not an i32"), -1;
         memset(out, 0, sizeof *out);
         memcpy(out->job_id, job_s.data(), job_s.size());
         memcpy(out->task_id, task_s.data(), task_s.size());
         memcpy(out->task_def, def->data(), def->size());  // the raw JSON text of task_def, e.g. {"Prove":{"index":3}}
-        out->max_retries = (int32_t)strtol(mr->c_str(), nullptr, 10);
+        out->max_retries = max_retries;
         return 1;
     } catch (const std::exception& ex) {
         return put_err(eb, cap, std::string("claim: ") + ex.what()), -1;
@@ -369,7 +399,7 @@ int rest_current_retries(void* user, const char* job, const char* task, int32_t*
         const std::string* v = json_members(r.body, &m) ? member(m, "retries") : nullptr;
         if (!v) return put_err(eb, cap, std::string("failed to decode retries-running response for ") + job + ":" + task), -1;
         if (*v == "null") return 0;  // Option::None: no running row
-        *retries = (int32_t)strtol(v->c_str(), nullptr, 10);
+        if (!json_i32_value(*v, retries)) return put_err(eb, cap, std::string("failed to decode retries-running response for ") + job + ":" + task), -1;
         return 1;
     } catch (const std::exception& ex) {
         return put_err(eb, cap, ex.what()), -1;

@@ -47,6 +47,29 @@ def test_honest_seals_of_random_shapes_are_accepted_and_one_flipped_bit_is_not()
             verify_seal(bad)
 
 
+def test_truncated_padded_and_garbage_seals_are_rejected_without_reading_out_of_bounds():
+    """Every prefix of a seal, a seal with trailing words, and arbitrary word strings are errors — the reader is bounded
+    (tests/test_verifier_sanitizers_cpu.py runs the same mutations under ASan/UBSan)."""
+    seal, _ = ol.prove_segment(9, 2, 3, 2, 11)
+    rng = np.random.default_rng(5)
+    lengths = sorted(set(list(range(0, 48)) + rng.integers(48, seal.size, 150).tolist() + [seal.size - 1]))
+    for n in lengths:
+        with pytest.raises(HalError):
+            verify_seal(seal[:n].copy())
+    with pytest.raises(HalError):
+        verify_seal(np.concatenate([seal, np.zeros(1, np.uint32)]))
+    for _ in range(50):
+        junk = rng.integers(0, 2**32, int(rng.integers(1, 4096)), dtype=np.uint32)
+        junk[0] = rng.integers(0, 30)  # a plausible po2, so the header gets past the first check sometimes
+        with pytest.raises(HalError):
+            verify_seal(junk)
+    # header fields at their extremes: the size computation must not overflow into acceptance
+    for hdr in ([22, 65535, 65535, 65535, 64, 5], [9, 0, 1, 1, 64, 4], [9, 1, 1, 1, 65, 4], [9, 1, 1, 1, 64, 6], [23, 1, 1, 1, 1, 1],
+                [0xFFFFFFFF] * 6):
+        with pytest.raises(HalError):
+            verify_seal(np.concatenate([np.array(hdr, np.uint32), seal[6:]]))
+
+
 def test_tampering_anywhere_is_rejected():
     seal, _ = ol.prove_segment(10, 4, 8, 4, 1234)
     verify_seal(seal)
