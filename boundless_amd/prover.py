@@ -99,6 +99,7 @@ class HipProverServer:
     def __init__(self, device=0, po2=20, widths=DEFAULT_WIDTHS, hal=None, terms=0, degree=0, circuit=None):
         """terms / degree: the circuit's knobs (synthetic circuit: product terms per constraint, factors per term); 0 = defaults.
         circuit: a bx_circuit_ops table (boundless_amd.circuit.CircuitOps) to prove another circuit than the built-in one."""
+        self._own_hal = hal is None  # a context created here is released by close(); a caller's is the caller's
         self.hal = hal or HipHal(device)
         self.lib = load_library()
         _declare(self.lib)
@@ -130,6 +131,9 @@ class HipProverServer:
         if getattr(self, "handle", None):
             self.lib.bx_prover_destroy(self.handle)
             self.handle = None
+        if getattr(self, "_own_hal", False):
+            self._own_hal = False
+            self.hal.close()
 
     def __del__(self):
         try:
