@@ -80,7 +80,9 @@ struct bx_ctx {
     long ntt_group_cols = 0;   // forward transform: columns per pass-A + pass-B group (0 = all columns per pass)
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
     long hash_rows_block = 256;
-    long fold_fuse_below = 1 << 15;  // Merkle layers with at most this many inputs are folded 9 levels per launch
+    long fold_quad = 1;              // small Merkle layers: four lanes per node (hash_fold_quad_kernel) instead of one
+    long fold_quad_wg = 512;         // ... input digests per workgroup of that kernel (a power of two, 16..512)
+    long fold_fuse_below = 1 << 17;  // Merkle layers with at most this many inputs are folded 9 levels per launch
     long deep_bitrev = 1;            // segment prover: keep trace coefficients bit-reversed through the DEEP phase (read at bx_prover_create)
 
     // timing

@@ -347,6 +347,12 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         c->ntt_tile_b_wide = value != 0;
     } else if (!strcmp(name, "deep_bitrev")) {
         c->deep_bitrev = value != 0;
+    } else if (!strcmp(name, "fold_quad")) {
+        BX_REQUIRE(c, value == 0 || value == 1, "fold_quad must be 0 or 1");
+        c->fold_quad = value;
+    } else if (!strcmp(name, "fold_quad_wg")) {
+        BX_REQUIRE(c, value >= 16 && value <= 512 && (value & (value - 1)) == 0, "fold_quad_wg must be a power of two in [16, 512]");
+        c->fold_quad_wg = value;
     } else if (!strcmp(name, "fold_fuse_below")) {
         BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
         c->fold_fuse_below = value;

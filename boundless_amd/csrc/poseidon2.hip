@@ -206,6 +206,165 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same permutation spread over a QUAD of lanes, for the layers that no longer fill the chip.  There the cost of a level
+// is the latency of one permutation on one lane (6.6 k dependent-ish instructions, ~12 us), not throughput; four lanes per
+// permutation cut the per-lane instruction stream to ~2.3 k.  Lane q of a quad holds cells 4k + q (slot k = 0..5):
+//   * an external layer's M4 block k is the slot-k values of the four lanes: each lane computes its own row of M4 from the
+//     three other lanes' values (v_mov_b32_dpp quad_perm rotations) with per-lane coefficients; the column sums T_j are lane-local;
+//   * the S-boxes and the returns to 32 bits are per cell and reuse the stage-wise helpers at width 6;
+//   * an internal round sums six cells per lane and all-reduces the 64-bit partial sums over the quad with two DPP steps;
+//     every lane runs the S-box of its slot 0 and only lane 0 (cell 0) keeps it.
+// Per-lane round constants and diagonal entries come from a copy of the parameter table in LDS.  The arithmetic per cell is
+// exactly poseidon2_mix's (same representation tracking, same bounds), so the words that leave are the same words.
+constexpr int QS = CELLS / 4;  // slots per lane
+__device__ __forceinline__ i32 quad_rot1(i32 v) { return __builtin_amdgcn_update_dpp(0, v, 0x39, 0xf, 0xf, false); }  // from lane (q+1)&3
+__device__ __forceinline__ i32 quad_rot2(i32 v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }  // (q+2)&3
+__device__ __forceinline__ i32 quad_rot3(i32 v) { return __builtin_amdgcn_update_dpp(0, v, 0x93, 0xf, 0xf, false); }  // (q+3)&3
+__device__ __forceinline__ i32 quad_xor1(i32 v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ i64 add_u32v(i64 c, uint32_t k, int alt) {  // c + k, k a per-lane unsigned word
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 r;
+    BX_MAD_ASM("v_mad_u64_u32", "%1, 1, %2", "v"(k), "v"(c));
+    return r;
+#else
+    (void)alt;
+    return c + (i64)k;
+#endif
+}
+struct QuadCoef {
+    i32 c0, c1, c3;  // this lane's row of M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]], rotated to start at its own column (c2 = 1)
+};
+__device__ __forceinline__ void m_ext_quad(const i32* s, i64* y, const QuadCoef& m) {
+    i64 t = 0;
+#pragma unroll
+    for (int k = 0; k < QS; ++k) {
+        const i32 x1 = quad_rot1(s[k]), x2 = quad_rot2(s[k]), x3 = quad_rot3(s[k]);
+        i64 w = smul(s[k], m.c0, k);
+        w = smad(x1, m.c1, w, k + 1);
+        w = smadc<1>(x2, w, k + 2);
+        w = smad(x3, m.c3, w, k + 3);
+        y[k] = w;
+        t += w;
+    }
+#pragma unroll
+    for (int k = 0; k < QS; ++k) y[k] += t;
+}
+__device__ __forceinline__ void redc_quad(const i64* y, const uint32_t* __restrict__ rc /* LDS, this lane's entries 4k apart */, i32* s) {
+    i64 acc[QS];
+#pragma unroll
+    for (int k = 0; k < QS; ++k) acc[k] = add_u32v(y[k], rc[4 * k], k);
+    sredc_n<QS>(acc, s);
+}
+template <uint32_t K1, uint32_t K2>
+__device__ __forceinline__ void redk_quad(const i64* y, uint32_t add0 /* this lane's addend for slot 0 (0 = none) */, i32* s) {
+    i64 acc[QS];
+#pragma unroll
+    for (int k = 0; k < QS; ++k) acc[k] = umul_k((uint32_t)y[k], K1, k);
+    acc[0] = add_u32v(acc[0], add0, 0);
+#pragma unroll
+    for (int k = 0; k < QS; ++k) acc[k] = smad_k((i32)(y[k] >> 32), K2, acc[k], k + 1);
+    sredc_n<QS>(acc, s);
+}
+template <bool RC_ALL>
+__device__ __forceinline__ void internal_round_quad(i32* s, const i32* diag, uint32_t rc0 /* lane 0: the round's constant, else 0 */,
+                                                    const uint32_t* __restrict__ rc_all, uint32_t keep_mask) {
+    const i32 sb = sbox7s(s[0]);
+    s[0] = (i32)(((uint32_t)sb & keep_mask) | ((uint32_t)s[0] & ~keep_mask));  // only cell 0 has an S-box in these rounds
+    i64 pa = smulc<1>(s[0], 0);
+#pragma unroll
+    for (int k = 1; k < QS; ++k) pa = smadc<1>(s[k], pa, k);
+    {  // all-reduce over the quad
+        i64 o = (i64)(((uint64_t)(uint32_t)quad_xor1((i32)(pa >> 32)) << 32) | (uint32_t)quad_xor1((i32)(uint32_t)pa));
+        pa += o;
+        o = (i64)(((uint64_t)(uint32_t)quad_rot2((i32)(pa >> 32)) << 32) | (uint32_t)quad_rot2((i32)(uint32_t)pa));
+        pa += o;
+    }
+    const i64 c = smulc<1>(internal_sum_rs(pa), 1);
+    i64 tt[QS];
+#pragma unroll
+    for (int k = 0; k < QS; ++k) {
+        if (RC_ALL) tt[k] = smad(s[k], diag[k], add_u32v(c, rc_all[4 * k], 2 * k), 2 * k + 1);
+        else if (k == 0) tt[k] = smad(s[k], diag[k], add_u32v(c, rc0, 0), 1);
+        else tt[k] = smad(s[k], diag[k], c, k + 1);
+    }
+    sredc_n<QS>(tt, s);
+}
+// in: this lane's cells (canonical); out: this lane's cells (canonical).  shp = the parameter table in LDS.
+__device__ __forceinline__ void poseidon2_mix_quad(uint32_t* io, const uint32_t* __restrict__ shp, uint32_t q) {
+    i32 s[QS];
+    i64 y[QS];
+    const bool odd = q & 1;
+    const QuadCoef m{odd ? 6 : 5, odd ? 1 : 7, odd ? 4 : 3};
+    const uint32_t keep = q == 0 ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int k = 0; k < QS; ++k) s[k] = (i32)io[k];
+    m_ext_quad(s, y, m);
+    redc_quad(y, shp + q, s);
+#pragma unroll 1
+    for (int r = 0; r < RF_HALF; ++r) {
+        sbox7s_n<QS>(s);
+        m_ext_quad(s, y, m);
+        if (r < RF_HALF - 1) redc_quad(y, shp + (r + 1) * CELLS + q, s);
+        else redk_quad<K1_MID, K2_MID>(y, shp[96] & keep, s);
+    }
+    i32 diag[QS];
+#pragma unroll
+    for (int k = 0; k < QS; ++k) diag[k] = (i32)shp[DIAG_OFF + 4 * k + q];
+#pragma unroll 1
+    for (int r = 0; r < RP - 1; ++r) internal_round_quad<false>(s, diag, shp[97 + r] & keep, nullptr, keep);
+    internal_round_quad<true>(s, diag, 0u, shp + 117 + q, keep);
+#pragma unroll 1
+    for (int r = 0; r < RF_HALF; ++r) {
+        sbox7s_n<QS>(s);
+        m_ext_quad(s, y, m);
+        if (r < RF_HALF - 1) redc_quad(y, shp + 117 + (r + 1) * CELLS + q, s);
+        else redk_quad<K1_END, K2_END>(y, 0u, s);
+    }
+#pragma unroll
+    for (int k = 0; k < QS; ++k) io[k] = canon(s[k]);
+}
+
+// Small Merkle layers, four lanes per node: a workgroup owns `per_wg` (<= 512) consecutive input digests and folds them
+// `levels` levels deep through LDS, writing every intermediate layer (as hash_fold_multi_kernel does with one lane per node).
+__global__ __launch_bounds__(1024) void hash_fold_quad_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm, uint32_t input_size,
+                                                              uint32_t per_wg, int levels) {
+    __shared__ uint32_t sh[256 * 8];
+    __shared__ uint32_t shp[DIAG_OFF + 24];
+    const uint32_t tid = threadIdx.x, q = tid & 3, node = tid >> 2;
+    for (uint32_t i = tid; i < DIAG_OFF + 24; i += blockDim.x) shp[i] = prm[i];
+    uint32_t width = per_wg >> 1;  // nodes this workgroup produces at the current level
+    uint32_t out_size = input_size >> 1;
+    for (int lvl = 0; lvl < levels; ++lvl) {
+        const bool active = node < width;
+        uint32_t s[QS];
+        if (active) {
+            if (lvl == 0) {
+                const uint32_t* src = io + ((size_t)input_size + 2 * ((size_t)blockIdx.x * width + node)) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = src[4 * k + q];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = sh[node * 16 + 4 * k + q];
+            }
+            s[4] = 0u;
+            s[5] = 0u;
+        }
+        __syncthreads();  // the level's inputs are in registers (and, at level 0, the parameter table is in LDS)
+        if (active) {
+            poseidon2_mix_quad(s, shp, q);
+            uint32_t* o = io + ((size_t)out_size + (size_t)blockIdx.x * width + node) * 8;
+            o[q] = s[0];
+            o[4 + q] = s[1];
+            sh[node * 8 + q] = s[0];
+            sh[node * 8 + 4 + q] = s[1];
+        }
+        __syncthreads();
+        width >>= 1;
+        out_size >>= 1;
+    }
+}
+
 const char* poseidon2_upload_params(bx_ctx* c) {
     uint32_t h[DIAG_OFF + 24] = {0};
     // round constants ride in REDC accumulators, pre-scaled to the representation of the round they are added in
@@ -294,10 +453,15 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
     const size_t fuse_below = (size_t)c->fold_fuse_below;
     while (size > 1) {
         if (size <= fuse_below) {
-            size_t per_wg = size < 512 ? size : 512;
+            const size_t cap = c->fold_quad ? (size_t)c->fold_quad_wg : 512;
+            size_t per_wg = size < cap ? size : cap;
             int levels = ilog2(per_wg);
-            hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / per_wg)), dim3(256), 0, c->stream, n, c->d_p2,
-                               (uint32_t)size, (uint32_t)per_wg, levels);
+            if (c->fold_quad)
+                hipLaunchKernelGGL(hash_fold_quad_kernel, dim3((unsigned)(size / per_wg)), dim3((unsigned)(2 * per_wg)), 0, c->stream, n,
+                                   c->d_p2, (uint32_t)size, (uint32_t)per_wg, levels);
+            else
+                hipLaunchKernelGGL(hash_fold_multi_kernel, dim3((unsigned)(size / per_wg)), dim3(256), 0, c->stream, n, c->d_p2,
+                                   (uint32_t)size, (uint32_t)per_wg, levels);
             BX_LAUNCH_CHECK(c);
             size >>= levels;
         } else {

@@ -264,8 +264,16 @@ def test_hash_rows_extreme_values(hal, oracle):
     assert np.array_equal(io.view()[8:16], want)
 
 
-@pytest.mark.parametrize("rows", [2, 8, 256, 512, 1024, 4096, 1 << 15])
-def test_merkle_build_vs_oracle(hal, oracle, rows):
+@pytest.fixture(params=[1, 0], ids=["quad", "lane"])
+def fold_path(hal, request):
+    """Small Merkle layers on both kernels: four lanes per node (default) and one lane per node."""
+    hal.set_tunable("fold_quad", request.param)
+    yield request.param
+    hal.set_tunable("fold_quad", 1)
+
+
+@pytest.mark.parametrize("rows", [2, 4, 8, 256, 512, 1024, 4096, 1 << 15, 1 << 17, 1 << 19])
+def test_merkle_build_vs_oracle(hal, oracle, fold_path, rows):
     cols = 20
     x = rnd(rows, rows * cols)
     nodes = hal.alloc_digest(2 * rows)
