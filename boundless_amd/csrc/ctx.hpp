@@ -65,6 +65,10 @@ struct bx_ctx {
     // points (bx_d2h, bx_sync) copy it to the pinned *h_flag with their own synchronisation and report it
     uint32_t* d_flag = nullptr;
     uint32_t* h_flag = nullptr;
+    // pinned landing area of bx_d2h: a device-to-host copy into pageable memory is staged (and serialised) by the runtime;
+    // copies up to this size land here at pinned-memory latency and are handed to the caller with one memcpy
+    uint32_t* h_stage = nullptr;
+    static constexpr size_t STAGE_WORDS = (size_t)1 << 20;  // 4 MiB: every read-back of a proof (tops, taps, queries) fits
 
     // scratch (grown on demand)
     uint32_t* d_scratch = nullptr;

@@ -151,6 +151,10 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
         return "bx_init: allocating the device error flag failed";
     }
     *c->h_flag = 0;
+    if (hipHostMalloc((void**)&c->h_stage, bx_ctx::STAGE_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
+        bx_free(c);
+        return "bx_init: allocating the pinned read-back buffer failed";
+    }
     // constants sanity (fp.hpp literals vs. computed)
     if (fp_encode(1u) != MONT_ONE || fp_encode(P - 11u) != MONT_NBETA || fp_encode(11u) != MONT_BETA ||
         fp_encode(3u) != MONT_THREE) {
@@ -199,6 +203,7 @@ extern "C" const char* bx_free(bx_ctx* c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -258,6 +263,13 @@ extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words
     if (!c) return "bx_d2h: null ctx";
     BX_REQUIRE(c, words <= src.len, "bx_d2h: copy larger than the buffer");
     BX_HIP(c, hipSetDevice(c->device));
+    if (words == 0) return sync_and_check_flag(c);
+    if (words <= bx_ctx::STAGE_WORDS) {
+        BX_HIP(c, hipMemcpyAsync(c->h_stage, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
+        BX_TRY(sync_and_check_flag(c));
+        memcpy(dst, c->h_stage, words * 4);
+        return nullptr;
+    }
     BX_HIP(c, hipMemcpyAsync(dst, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
     return sync_and_check_flag(c);
 }
