@@ -25,25 +25,24 @@ struct HostPoseidon2 {
         return fp_mul(x3, x4);
     }
     static void m_ext(uint32_t* s) {
-        // y_k = M4 (x_k + S), S = sum of the six 4-chunks  (circ(2*M4, M4, ..., M4))
-        uint32_t S[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 24; ++i) S[i & 3] = fp_add(S[i & 3], s[i]);
+        // y_k = M4 x_k + T,  T = sum_k M4 x_k  (circ(2*M4, M4, ..., M4)); M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] by the
+        // Poseidon2 addition chain, unreduced in 64 bits (rows of the whole layer sum to <= 112: < 2^38), one reduction per cell
+        uint64_t y[24], t[4] = {0, 0, 0, 0};
         for (int k = 0; k < 24; k += 4) {
-            uint32_t z[4];
-            for (int j = 0; j < 4; ++j) z[j] = fp_add(s[k + j], S[j]);
-            // M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] by repeated addition
-            const int M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
-            for (int r = 0; r < 4; ++r) {
-                uint32_t acc = 0;
-                for (int c = 0; c < 4; ++c)
-                    for (int m = 0; m < M4[r][c]; ++m) acc = fp_add(acc, z[c]);
-                s[k + r] = acc;
-            }
+            const uint64_t a = s[k], b = s[k + 1], c = s[k + 2], d = s[k + 3];
+            const uint64_t t0 = a + b, t1 = c + d, t2 = 2 * b + t1, t3 = 2 * d + t0, t4 = 4 * t1 + t3, t5 = 4 * t0 + t2;
+            y[k] = t3 + t5;
+            y[k + 1] = t5;
+            y[k + 2] = t2 + t4;
+            y[k + 3] = t4;
+            for (int j = 0; j < 4; ++j) t[j] += y[k + j];
         }
+        for (int i = 0; i < 24; ++i) s[i] = (uint32_t)((y[i] + t[i & 3]) % P);
     }
     void m_int(uint32_t* s) const {
-        uint32_t sum = 0;
-        for (int i = 0; i < 24; ++i) sum = fp_add(sum, s[i]);
+        uint64_t acc = 0;
+        for (int i = 0; i < 24; ++i) acc += s[i];
+        const uint32_t sum = (uint32_t)(acc % P);
         for (int i = 0; i < 24; ++i) s[i] = fp_add(sum, fp_mul(diag[i], s[i]));
     }
     void mix(uint32_t* s) const {
