@@ -61,9 +61,9 @@ struct bx_ctx {
     uint32_t* d_p2 = nullptr;
     int live_provers = 0;  // bx_prover objects created on this ctx and not yet destroyed
 
-    // deferred device-side errors (e.g. a scatter offset out of range): kernels OR bits into *d_flag, the blocking entry
-    // points (bx_d2h, bx_sync) copy it to the pinned *h_flag with their own synchronisation and report it
-    uint32_t* d_flag = nullptr;
+    // deferred device-side errors (e.g. a scatter offset out of range): h_flag is pinned, host-coherent memory the kernels
+    // write straight into (one word per kind of error, so plain stores suffice); the blocking entry points (bx_d2h, bx_sync)
+    // read it after their own stream synchronisation — no copy, no extra launch
     uint32_t* h_flag = nullptr;
     // pinned landing area of bx_d2h: a device-to-host copy into pageable memory is staged (and serialised) by the runtime;
     // copies up to this size land here at pinned-memory latency and are handed to the caller with one memcpy
@@ -180,8 +180,9 @@ struct OpScope {
 
 // internal launchers shared between translation units (each returns NULL or an error string)
 const char* ensure_scratch(bx_ctx* c, size_t words);
-constexpr uint32_t FLAG_SCATTER_RANGE = 1u;  // bits of bx_ctx::d_flag
-constexpr uint32_t FLAG_SCATTER_INDEX = 2u;
+constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
+constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;
+constexpr uint32_t FLAG_SLOTS = 4u;
 const char* sync_and_check_flag(bx_ctx* c);  // hipStreamSynchronize + deferred device errors
 const char* ntt_init_tables(bx_ctx* c);
 void ntt_free_tables(bx_ctx* c);

@@ -145,12 +145,11 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
         delete c;
         return "bx_init: hipEventCreate failed";
     }
-    if (hipMalloc(&c->d_flag, 4) != hipSuccess || hipMemset(c->d_flag, 0, 4) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_flag, 4, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&c->h_flag, FLAG_SLOTS * 4, hipHostMallocDefault) != hipSuccess) {
         bx_free(c);
-        return "bx_init: allocating the device error flag failed";
+        return "bx_init: allocating the deferred error flags failed";
     }
-    *c->h_flag = 0;
+    for (uint32_t i = 0; i < FLAG_SLOTS; ++i) c->h_flag[i] = 0;
     if (hipHostMalloc((void**)&c->h_stage, bx_ctx::STAGE_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
         bx_free(c);
         return "bx_init: allocating the pinned read-back buffer failed";
@@ -179,15 +178,13 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
 
 namespace bx {
 const char* sync_and_check_flag(bx_ctx* c) {
-    BX_HIP(c, hipMemcpyAsync(c->h_flag, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
     BX_HIP(c, hipStreamSynchronize(c->stream));
-    const uint32_t f = *c->h_flag;
-    if (f) {
-        BX_HIP(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));
-        *c->h_flag = 0;
-        if (f & FLAG_SCATTER_RANGE) return set_msg(c, "scatter: an offset is outside the destination buffer");
-        if (f & FLAG_SCATTER_INDEX) return set_msg(c, "scatter: index range exceeds offsets/values");
-        return set_msg(c, "deferred device error");
+    volatile uint32_t* f = c->h_flag;
+    const bool range = f[FLAG_SLOT_SCATTER_RANGE] != 0, index = f[FLAG_SLOT_SCATTER_INDEX] != 0;
+    if (range || index) {
+        for (uint32_t i = 0; i < FLAG_SLOTS; ++i) f[i] = 0;  // the stream is idle: nothing races with the reset
+        if (range) return set_msg(c, "scatter: an offset is outside the destination buffer");
+        return set_msg(c, "scatter: index range exceeds offsets/values");
     }
     return nullptr;
 }
@@ -201,7 +198,6 @@ extern "C" const char* bx_free(bx_ctx* c) {
     ntt_free_tables(c);
     if (c->d_p2) (void)hipFree(c->d_p2);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
-    if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

@@ -424,14 +424,14 @@ __global__ void pp_apply_kernel(uint32_t* __restrict__ io, size_t n, const uint3
 }
 // entries [index[0], index[last]) are written.  The per-cycle grouping of upstream's scatter only orders writes that hit
 // the same offset, which its circuits never produce, so one pass over the range is equivalent.  Nothing is read back by
-// the host: a bad offset or index range raises a bit of the ctx's deferred error flag (reported by the next bx_d2h / bx_sync).
+// the host: a bad offset or index range raises a word of the ctx's deferred error flags (reported by the next bx_d2h / bx_sync).
 __global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __restrict__ index, size_t index_len,
                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ values, size_t entries, size_t into_len,
                                uint32_t* __restrict__ flag) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lo = index[0], hi = index[index_len - 1];  // wave-uniform
     if (lo > hi || hi > entries) {
-        if (e == 0) atomicOr(flag, FLAG_SCATTER_INDEX);
+        if (e == 0) *(volatile uint32_t*)(flag + FLAG_SLOT_SCATTER_INDEX) = 1u;
         return;
     }
     if (e < lo || e >= hi) return;
@@ -439,7 +439,7 @@ __global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __re
     if (o < into_len) {
         into[o] = values[e];
     } else {
-        atomicOr(flag, FLAG_SCATTER_RANGE);
+        *(volatile uint32_t*)(flag + FLAG_SLOT_SCATTER_RANGE) = 1u;
     }
 }
 
@@ -695,7 +695,7 @@ extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf o
     OpScope op(c, "scatter", 12.0 * (double)offsets.len);
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((offsets.len + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)into.dptr,
                        (const uint32_t*)index.dptr, index.len, (const uint32_t*)offsets.dptr, (const uint32_t*)values.dptr, offsets.len,
-                       into.len, c->d_flag);
+                       into.len, c->h_flag);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
