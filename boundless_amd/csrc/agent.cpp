@@ -1023,7 +1023,13 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
         if (!a->cfg.redis_ttl) a->cfg.redis_ttl = 8 * 60 * 60;
         if (!(a->cfg.poll_time > 0)) a->cfg.poll_time = 1.0;
         if (!a->cfg.po2_min) a->cfg.po2_min = 9;
+        // the prover takes po2 up to 24, but a lane's buffers grow with the size (8.5 GB at 2^20, 34 GB at 2^22, 135 GB at 2^24 for
+        // 16/256/64): the default keeps `inflight` x 2 cached shapes inside one 288 GB GPU; raise po2_max with fewer lanes
         if (!a->cfg.po2_max) a->cfg.po2_max = 22;
+        if (a->cfg.po2_min < 9 || a->cfg.po2_max > 24 || a->cfg.po2_min > a->cfg.po2_max) {
+            delete a;
+            return "bx_agent_create: po2_min / po2_max must satisfy 9 <= po2_min <= po2_max <= 24";
+        }
         if (!a->cfg.max_shapes) a->cfg.max_shapes = 2;
         if (a->cfg.n_devices == 0) {
             a->cfg.n_devices = 1;

@@ -208,7 +208,7 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
     if (!circuit) circuit = bx_synthetic_circuit();
     BX_REQUIRE(c, circuit->taps && circuit->witgen && circuit->accumulate && circuit->eval_check, "bx_prover_create: circuit table incomplete");
-    BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 22, "bx_prover_create: po2 must be in [9, 22]");
+    BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 24, "bx_prover_create: po2 must be in [9, 24]");
     BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
     BX_REQUIRE(c, shape->w_code < 65536 && shape->w_data < 65536 && shape->w_accum < 65536, "bx_prover_create: group width out of range");
 

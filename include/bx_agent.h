@@ -174,7 +174,7 @@ typedef struct bx_agent_config {
     int32_t synthetic;       /* 1 = accept the synthetic wire format and write synthetic_receipts (see above); without it an
                               * agent whose prover table has no prove_blob refuses to start */
     uint32_t cons_terms, cons_degree; /* the synthetic circuit's knobs for the built-in prover (0 = defaults) */
-    uint32_t po2_min, po2_max;        /* segment sizes the built-in prover accepts; 0 = 9 / 22.  Others fail the task */
+    uint32_t po2_min, po2_max;        /* segment sizes the built-in prover accepts (within 9..24); 0 = 9 / 22.  Others fail the task.  A lane's buffers are 8.5 GB at 2^20, 34 GB at 2^22, 135 GB at 2^24 (16/256/64): size po2_max x inflight for the GPU */
     uint32_t max_shapes;     /* buffer sets (one per segment size, several GB at po2 20) cached per lane, least recently used
                               * evicted; 0 = 2 */
 } bx_agent_config;

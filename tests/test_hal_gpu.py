@@ -123,9 +123,10 @@ def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, fast, block_log, til
         hal.set_tunable("ntt_tile_b_log", 13)
 
 
-@pytest.mark.parametrize("bits", [21, 22])
+@pytest.mark.parametrize("bits", [21, 22, 23, 24])
 def test_ntt_largest_segment_sizes(hal, oracle, bits):
-    """po2 21/22 segments: 2^23 / 2^24-point LDEs (pass B with 2^11 / 2^12 rows), one column, vs the oracle."""
+    """po2 21-24 segments: 2^23 ... 2^26-point LDEs (pass B with 2^11 ... 2^13 rows, pass A with 2^13 at the top), one column, vs
+    the oracle."""
     n = 1 << bits
     x = rnd(bits, n)
     ref = x.copy()

@@ -44,7 +44,8 @@ def test_seal_bit_exact_vs_oracle(po2, widths, seed):
     (10, (2, 2, 4), (0, 0), 5),        # one free and one derived data column: the pool wraps around the free columns
     (9, (3, 3, 8), (7, 3), 6),         # more accumulators than free columns allow pairs for
     (10, (40, 6, 16), (0, 0), 7),      # wide code group, narrow data group
-    (22, (2, 6, 4), (0, 0), 22),       # the largest segment the prover accepts: 2^24-point LDEs
+    (22, (2, 6, 4), (0, 0), 22),       # 2^24-point LDEs
+    (23, (2, 6, 4), (0, 0), 23),       # 2^25-point LDEs: pass B of the NTT at 2^13 rows (the oracle needs about a minute here)
 ])
 def test_seal_bit_exact_vs_oracle_other_sizes_and_circuit_knobs(po2, widths, knobs, seed):
     from boundless_amd.prover import HipProverServer, Segment
@@ -87,6 +88,39 @@ def test_seal_bit_exact_vs_oracle_on_random_shapes(po2, widths, knobs, seed):
     bad = np.nonzero(receipt.seal != seal)[0] if receipt.seal.size == seal.size else [-1]
     assert len(bad) == 0, f"seal differs from the oracle's at {bad[:5]} for po2={po2} widths={widths} knobs={knobs}"
     receipt.verify_integrity()
+
+
+def test_the_largest_segment_at_full_width_is_one_proof_on_one_gpu():
+    """po2 = 24 — risc0's largest segment, 16 M cycles — at the BASELINE widths 16/256/64: 135 GB of buffers, which is what
+    288 GB of HBM is for (the reference's CUDA targets top out at 24-80 GB and split such work into smaller segments).  The CPU
+    oracle would need ten minutes and as much host memory, so here the checks are the size-independent ones: the proof is
+    deterministic, the CPU verifier accepts it (every Merkle opening, the constraint identity, the DEEP quotients and the FRI
+    chain of a 2^26-row domain: any 32-bit index overflow in a kernel would break one of them) and rejects a flipped word."""
+    import torch
+
+    from boundless_amd.hal import HalError
+    from boundless_amd.prover import HipProverServer, Segment, verify_seal
+
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 150 * 2**30:
+        pytest.skip("needs 135 GB of free HBM")
+    srv = HipProverServer(0, po2=24)
+    try:
+        a = srv.prove_segment(Segment.synthetic(0, po2=24)).seal
+        b = srv.prove_segment(Segment.synthetic(0, po2=24)).seal
+        c = srv.prove_segment(Segment.synthetic(1, po2=24)).seal
+    finally:
+        srv.close()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a[:6].tolist() == [24, 16, 256, 64, 64, 4]
+    verify_seal(a)
+    verify_seal(c)
+    bad = a.copy()
+    bad[a.size // 2] ^= 4
+    with pytest.raises(HalError):
+        verify_seal(bad)
+    with pytest.raises(HalError, match=r"po2 must be in \[9, 24\]"):
+        HipProverServer(0, po2=25, widths=(2, 2, 2))
 
 
 def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
