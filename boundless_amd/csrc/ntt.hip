@@ -259,6 +259,9 @@ static Split choose_split(bx_ctx* c, int m) {
     Split sp;
     int blk = (int)c->ntt_block_log;
     if (blk > TW_LOG) blk = TW_LOG;
+    // sizes beyond 2^24 (segments of po2 23 / 24): a taller contiguous pass keeps the strided pass at <= 2^12 rows where it can,
+    // i.e. its LDS tile (<= 2^14 elements) at least four positions wide (measured: po2 23 proof 0.44 -> 0.38 s)
+    if (m - blk > 12 && blk < TW_LOG) blk = m - 12 < TW_LOG ? m - 12 : TW_LOG;
     if (m <= blk) {
         sp.m_hi = m;
         sp.m_lo = 0;
@@ -359,7 +362,8 @@ static const char* fast_pass_b(bx_ctx* c, bool inv, uint32_t* io, size_t count, 
     int tile = (int)c->ntt_tile_b_log;
     // keep every row access at least 64 bytes wide: tall passes (>= 2^10 rows) take the 2^14-element tile (1024 threads);
     // measured on the 2^22 LDE: -6 % time and 1.5x fewer HBM write bytes than 32-byte rows
-    if (c->ntt_tile_b_wide && m_lo + 4 > tile && m_lo + 4 <= 14) tile = m_lo + 4;
+    // ... and the tallest ones (2^11 .. 2^13 rows) the same 2^14-element tile, as wide as it still allows (po2 24 proof 1.22 -> 0.86 s)
+    if (c->ntt_tile_b_wide && m_lo + 4 > tile) tile = m_lo + 4 <= 14 ? m_lo + 4 : 14;
     if (tile < m_lo) tile = m_lo;
     int lt = tile - m_lo;
     if (lt > m_hi) lt = m_hi;
