@@ -325,6 +325,11 @@ static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
     if (PASS_A && a.lr == 12 && a.lt == 0) return launch_r16_geom<INV, PASS_A, SKIP, 12, 0>(c, a, count);
     if (!PASS_A && a.lr == 10 && a.lt == 3) return launch_r16_geom<INV, PASS_A, SKIP, 10, 3>(c, a, count);
     if (!PASS_A && a.lr == 10 && a.lt == 4) return launch_r16_geom<INV, PASS_A, SKIP, 10, 4, 1024>(c, a, count);  // 64-byte rows
+    // po2 21 .. 24 segments (compose.yml:67 runs 21): strided passes of 2^11 .. 2^13 rows on the 2^14-element tile, 2^13 contiguous pass
+    if (!PASS_A && a.lr == 11 && a.lt == 3) return launch_r16_geom<INV, PASS_A, SKIP, 11, 3, 1024>(c, a, count);
+    if (!PASS_A && a.lr == 12 && a.lt == 2) return launch_r16_geom<INV, PASS_A, SKIP, 12, 2, 1024>(c, a, count);
+    if (!PASS_A && a.lr == 13 && a.lt == 1) return launch_r16_geom<INV, PASS_A, SKIP, 13, 1, 1024>(c, a, count);
+    if (PASS_A && a.lr == 13 && a.lt == 0 && a.lrows == 13) return launch_r16_geom<INV, PASS_A, SKIP, 13, 0>(c, a, count);
     if (!PASS_A && a.lrows + a.lt > 13) return launch_r16_geom<INV, PASS_A, SKIP, 0, 0, 1024>(c, a, count);
     if (!PASS_A && a.lr == 8 && a.lt == 5) return launch_r16_geom<INV, PASS_A, SKIP, 8, 5>(c, a, count);
     return launch_r16_geom<INV, PASS_A, SKIP, 0, 0>(c, a, count);
