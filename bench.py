@@ -78,9 +78,17 @@ def cpu_baseline(po2_sample, widths, po2_full):
     L = ol.lib(path) if path else ol.lib()
     ol.prove_segment(10, 2, 4, 2, 1, L)  # warm
     ncpu = os.cpu_count() or 1
+    quota = None  # the container's CPU quota (cgroup v2 cpu.max = "<max> <period>"): threads beyond it only get throttled
+    try:
+        mx, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if mx != "max":
+            quota = max(1, int(mx) // int(period))
+    except (OSError, ValueError):
+        quota = None
+    usable = min(ncpu, quota) if quota else ncpu
     probe_po2 = min(14, po2_sample)
     best = None
-    for threads in sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for threads in sorted({min(usable, 64), min(usable, 32), min(usable, 16)}, reverse=True):
         L.bxo_set_threads(threads)
         t0 = time.time()
         ol.prove_segment(probe_po2, *widths, 0xB0D1E550000, L)
@@ -100,7 +108,9 @@ def cpu_baseline(po2_sample, widths, po2_full):
         "cores": cores,
         "kind": "port",
         "sample": f"one 2^{po2_sample}-cycle synthetic segment (widths {'/'.join(map(str, widths))}, default circuit) proved by oracle/ "
-                  f"(C, OpenMP, {cores} threads chosen on a 2^{probe_po2} probe, of {ncpu} hardware threads) in {dt:.2f}s; {how}",
+                  f"(C, OpenMP, {cores} threads chosen on a 2^{probe_po2} probe; the box has {ncpu} hardware threads"
+                  f"{f' and this container a CPU quota of {quota} (cgroup cpu.max)' if quota else ''}) in {dt:.2f}s; {how}",
+        "cpu_quota": quota,
         "sample_seconds": round(dt, 3),
     }
 
