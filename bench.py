@@ -17,7 +17,7 @@ max-over-ranks.  Inputs are generated on the device (no host buffers cross PCIe 
 Fiat-Shamir digests, exactly as in the reference's prover).
 
 By default three segments are in flight per GPU (one prover, stream and host thread each): the others fill the
-latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +20 % throughput; a step is then one
+latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +15 % throughput; a step is then one
 batch of `--inflight` segments per GPU and `value` counts segments.
 
 The JSON line also carries
@@ -27,7 +27,8 @@ The JSON line also carries
                 in-region durations; `roofline_in_region` is the concurrent figure;
   kernels       the same for every HAL entry point in the timed region;
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
-                box's host cores: one proof of the metric's own size (2^20, ~40 s), thread count chosen on a small probe.
+                box's host cores: one proof of the metric's own size (2^20, ~35 s), thread count chosen on a small probe within the
+                container's CPU quota (16 on the GPU boxes).
 """
 import argparse
 import json
