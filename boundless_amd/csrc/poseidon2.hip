@@ -11,6 +11,7 @@
 // across the 64 lanes of a wave (lane r reads matrix[c*rows + r]).
 #include "ctx.hpp"
 #include "poseidon2_arith.hpp"
+#include "../../include/bx_image.h"
 
 namespace bx {
 
@@ -155,6 +156,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int k = 16; k < CELLS; ++k) s[k] = 0u;
     poseidon2_mix(s, prm);
     uint4* o = reinterpret_cast<uint4*>(io + ((size_t)output_size + i) * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// hash_fold with an indirection: out[j] = H(in[sel[2j]] || in[sel[2j+1]]).  The levels of a SPARSE Merkle tree (the zkVM
+// memory image, bx_image.h: 2^22 leaves of which a few hundred exist) are folded with it: the host lists, per level, which
+// two digests of the level below (or that level's all-zero digest) feed each surviving parent.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_indexed_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+                                                                const uint32_t* __restrict__ sel, const uint32_t* __restrict__ prm,
+                                                                uint32_t count) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint2 pr = reinterpret_cast<const uint2*>(sel)[j];
+    const uint4* a = reinterpret_cast<const uint4*>(in + (size_t)pr.x * 8);
+    const uint4* b = reinterpret_cast<const uint4*>(in + (size_t)pr.y * 8);
+    uint32_t s[CELLS];
+    uint4 v0 = a[0], v1 = a[1], v2 = b[0], v3 = b[1];
+    s[0] = v0.x; s[1] = v0.y; s[2] = v0.z; s[3] = v0.w;
+    s[4] = v1.x; s[5] = v1.y; s[6] = v1.z; s[7] = v1.w;
+    s[8] = v2.x; s[9] = v2.y; s[10] = v2.z; s[11] = v2.w;
+    s[12] = v3.x; s[13] = v3.y; s[14] = v3.z; s[15] = v3.w;
+#pragma unroll
+    for (int k = 16; k < CELLS; ++k) s[k] = 0u;
+    poseidon2_mix(s, prm);
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)j * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
@@ -433,6 +459,20 @@ extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, siz
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "hash_fold", 96.0 * (double)output_size);
     return launch_hash_fold(c, (uint32_t*)io.dptr, input_size, output_size);
+}
+
+extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx_buf sel, size_t count) {
+    if (!c) return "bx_hash_fold_indexed: null ctx";
+    BX_REQUIRE(c, out.len >= 8 * count && sel.len >= 2 * count, "hash_fold_indexed: out or sel too small");
+    BX_REQUIRE(c, count <= 0xffffffffu && in.len / 8 <= 0xffffffffu, "hash_fold_indexed: too many digests");
+    if (count == 0) return nullptr;
+    BX_REQUIRE(c, out.dptr && in.dptr && sel.dptr, "hash_fold_indexed: null buffer");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "hash_fold_indexed", 104.0 * (double)count);
+    hipLaunchKernelGGL(hash_fold_indexed_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
+                       (const uint32_t*)in.dptr, (const uint32_t*)sel.dptr, c->d_p2, (uint32_t)count);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
 }
 
 extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) {

@@ -103,6 +103,12 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
 void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
 void bxo_free(void* p);
 
+/* ---- program image (bx_oracle_image.c): risc0_zkvm::compute_image_id of an "R0BF" program binary.  PINNED by the
+ * reference's own vector (crates/povw/src/log_updater.rs:383-388).  Returns 0 or a negative error code;
+ * root_canonical (may be NULL) receives the Poseidon2 Merkle root of the memory image as canonical words. ---- */
+int bxo_compute_image_id(const uint8_t* blob, size_t len, uint8_t id_out[32], uint32_t root_canonical[8]);
+void bxo_sha256(uint8_t out[32], const uint8_t* msg, size_t len);
+
 #ifdef __cplusplus
 }
 #endif

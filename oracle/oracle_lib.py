@@ -14,7 +14,7 @@ u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 def build(force=False, native=False, out=None):
     """Compile the C oracle.  native=True builds a -march=native copy (for the cpu_baseline timing leg)."""
     out = out or os.path.join(_HERE, "libbx_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("bx_oracle.c", "bx_oracle_prover.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("bx_oracle.c", "bx_oracle_prover.c", "bx_oracle_image.c")]
     deps = srcs + [os.path.join(_HERE, "bx_oracle.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
@@ -75,6 +75,8 @@ def lib(path=None):
         "bxo_prove_segment_ex": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
         "bxo_free": ([C.c_void_p], None),
+        "bxo_compute_image_id": ([C.c_char_p, sz, C.c_char_p, u32p], C.c_int),
+        "bxo_sha256": ([C.c_char_p, C.c_char_p, sz], None),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -123,3 +125,14 @@ def prove_segment(po2, w_code, w_data, w_accum, seed, L=None, terms=0, degree=0)
     seal = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
     L.bxo_free(ptr)
     return seal, roots.reshape(4, 8)
+
+
+def compute_image_id(blob, L=None):
+    """risc0_zkvm::compute_image_id of an R0BF program binary -> (32-byte id, canonical Merkle root words)."""
+    L = L or lib()
+    out = C.create_string_buffer(32)
+    root = np.zeros(8, np.uint32)
+    rc = L.bxo_compute_image_id(bytes(blob), len(blob), out, root)
+    if rc != 0:
+        raise ValueError(f"oracle compute_image_id: malformed program binary (code {rc})")
+    return out.raw, root
