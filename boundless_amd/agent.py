@@ -279,7 +279,7 @@ class Agent:
                     out_len[0] = len(rec)
                     return None
                 except Exception as e:  # noqa: BLE001
-                    self._errs[lane] = C.create_string_buffer(f"{e}".encode())
+                    self._errs[lane] = C.create_string_buffer(f"{e}".encode("utf-8", "surrogateescape"))
                     return C.cast(self._errs[lane], C.c_void_p).value
 
             def free_blob(_user, _ptr):
@@ -301,7 +301,7 @@ class Agent:
                     words[0] = seal.size
                     return None
                 except Exception as e:  # noqa: BLE001 - the error crosses the ABI as a string, like the HIP prover's
-                    self._errs[lane] = C.create_string_buffer(f"{e}".encode())
+                    self._errs[lane] = C.create_string_buffer(f"{e}".encode("utf-8", "surrogateescape"))
                     return C.cast(self._errs[lane], C.c_void_p).value
 
             self._ops = _ProverOps(None, _SEAL_WORDS_FN(seal_words), _PROVE_FN(prove), _PROVE_BLOB_FN(), _FREE_BLOB_FN())

@@ -11,6 +11,9 @@ from .hal import BxBuf, load_library
 from .prover import SegmentParams
 
 
+MAX_TAPS = 8  # BX_MAX_TAPS (include/bx_circuit.h)
+
+
 class TapReader(C.Structure):
     pass
 
@@ -64,7 +67,10 @@ class CircuitOps(C.Structure):
             return n_glob["n"]
 
         def witgen(_u, _s, ctx, code, data, seed, globals_out):
-            g = obj.witgen(ctx, code, data, seed) or []
+            g = list(obj.witgen(ctx, code, data, seed) or [])
+            # the C side hands over an array of n_globals words: more would be written past it before any check could run
+            if len(g) > n_glob.get("n", 0):
+                raise ValueError(f"witgen returned {len(g)} public words, the circuit declared {n_glob.get('n', 0)}")
             for i, v in enumerate(g):
                 globals_out[i] = int(v)
 
@@ -85,7 +91,9 @@ class CircuitOps(C.Structure):
 
         def taps(_u, shape, g, c, out):
             backs = list(obj.taps(shape.contents, g, c))  # e.g. [0] or [0, 1, 3]: the rows back the column is opened at
-            for i, b in enumerate(backs):
+            # `out` is a BX_MAX_TAPS-word array on the caller's stack: report an oversized set by its length (the C side refuses
+            # k > BX_MAX_TAPS) without writing past the array
+            for i, b in enumerate(backs[:MAX_TAPS]):
                 out[i] = int(b)
             return len(backs)
 

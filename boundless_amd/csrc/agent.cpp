@@ -765,6 +765,13 @@ struct bx_agent {
     }
 
     // the error arm of poll_work (lib.rs:381-436); returns "" or a fatal task-db error
+    // cut at a character boundary: a multi-byte UTF-8 sequence split in half makes the failure report itself invalid JSON
+    static void truncate_utf8(std::string& s, size_t cap) {
+        if (s.size() <= cap) return;
+        size_t n = cap;
+        while (n > 0 && ((unsigned char)s[n] & 0xC0) == 0x80) --n;  // s[n] is a continuation byte: back up to its lead byte
+        s.resize(n);
+    }
     std::string handle_failure(const bx_ready_task& task, std::string err) {
         char eb[256] = {0};
         const std::string type = task_type_label(task);
@@ -774,7 +781,7 @@ struct bx_agent {
             if (found < 0) return std::string("[BENTO-WF-109] Failed to read current retries: ") + eb;
             if (found == 1 && cur + 1 > task.max_retries) {
                 metrics.record_task_max_retries_exhausted(type);
-                if (err.size() > 1024) err.resize(1024);
+                truncate_utf8(err, 1024);
                 std::string final_err = err.empty() ? "retry max hit" : "retry max hit: " + err;
                 if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, final_err.c_str(), eb, sizeof eb) < 0)
                     return std::string("[BENTO-WF-110] Failed to report task failure: ") + eb;
@@ -787,7 +794,7 @@ struct bx_agent {
             else metrics.record_task_max_retries_exhausted(type);
         } else {
             metrics.record_task_max_retries_exhausted(type);
-            if (err.size() > 1024) err.resize(1024);
+            truncate_utf8(err, 1024);
             if (taskdb.update_task_failed(taskdb.user, task.job_id, task.task_id, err.c_str(), eb, sizeof eb) < 0)
                 return std::string("[BENTO-WF-112] Failed to report task failure: ") + eb;
         }

@@ -34,8 +34,9 @@ struct Circuit {
         F = (wd + 1) / 2;  // free data columns [0, F); derived [F, wd)
         J = wd - F;
         E = wa / 4;  // ext accumulators; accum columns [4E, wa) are noise
-        pairs = 0;
-        while (2 * pairs + 1 < E && 4 * pairs + 3 < F) ++pairs;
+        // the largest count with 2(pairs-1)+1 < E and 4(pairs-1)+3 < F, in closed form (this constructor runs once per column in
+        // the verifier's tap loop: a loop here let a hostile header buy seconds of CPU before the seal length was looked at)
+        pairs = (E >= 2 && F >= 4) ? (((E - 2) / 2 + 1 < (F - 4) / 4 + 1) ? (E - 2) / 2 + 1 : (F - 4) / 4 + 1) : 0;
         if (wc < 2) pairs = 0;  // the closing constraint needs the `last` selector (code column 1)
     }
     // public words of the statement: the first cell of data column 0 ("where the segment starts") and, with a `last` selector,

@@ -22,6 +22,7 @@
 #include "poseidon2_arith.hpp"
 
 namespace bx {
+inline namespace BX_MAD_FLAVOUR {
 
 // canonical [0, P) -> the representative in [-P/2, P/2]
 BX_HD i32 fp_centre(uint32_t v) { return (i32)v - (v > P / 2 ? (i32)P : 0); }
@@ -81,4 +82,5 @@ BX_HD uint32_t cons_sum(const uint32_t (&pool_u)[Circuit::POOL], uint32_t T, uin
     }
 }
 
+}  // inline namespace BX_MAD_FLAVOUR
 }  // namespace bx

@@ -18,6 +18,7 @@
 #include "poseidon2_arith.hpp"
 
 namespace bx {
+inline namespace BX_MAD_FLAVOUR {
 
 BX_HD i32 fp_centre_w(uint32_t v) { return (i32)v - (v > P / 2 ? (i32)P : 0); }  // canonical -> [-P/2, P/2]
 
@@ -57,4 +58,5 @@ struct LazyExtAcc {
     }
 };
 
+}  // inline namespace BX_MAD_FLAVOUR
 }  // namespace bx

@@ -21,7 +21,16 @@
 #define BX_ASSERT_BOUND(cond, what) ((void)0)
 #endif
 
+// The multiply-add helpers below have two bodies (pinned instructions / plain C, chosen per translation unit by BX_PLAIN_MAD).
+// Each flavour lives in its own inline namespace, so the two never share a mangled name: one definition per entity even if the
+// build is ever linked with -fgpu-rdc.
+#if defined(BX_PLAIN_MAD)
+#define BX_MAD_FLAVOUR mad_plain
+#else
+#define BX_MAD_FLAVOUR mad_pinned
+#endif
 namespace bx {
+inline namespace BX_MAD_FLAVOUR {
 
 constexpr int P2_CELLS = 24;
 
@@ -468,4 +477,5 @@ BX_HD void poseidon2_mix_bounded(uint32_t* io, const uint32_t* prm) {
     }
 }
 
+}  // inline namespace BX_MAD_FLAVOUR
 }  // namespace bx

@@ -68,8 +68,22 @@ std::string json_escape(const char* s) {
                     char b[8];
                     snprintf(b, sizeof b, "\\u%04x", *p);
                     o += b;
-                } else {
+                } else if (*p < 0x80) {
                     o += (char)*p;
+                } else {
+                    // error texts come from the hot store, the prover and the OS: arbitrary bytes.  Pass well-formed UTF-8
+                    // sequences through, replace anything else by U+FFFD so that the body is always valid JSON
+                    int len = (*p >= 0xC2 && *p <= 0xDF) ? 2 : (*p >= 0xE0 && *p <= 0xEF) ? 3 : (*p >= 0xF0 && *p <= 0xF4) ? 4 : 0;
+                    bool ok = len != 0;
+                    for (int k = 1; ok && k < len; ++k) ok = (p[k] & 0xC0) == 0x80;  // p[k] == 0 ends the string and fails here
+                    if (ok && len == 3) ok = !(p[0] == 0xE0 && p[1] < 0xA0) && !(p[0] == 0xED && p[1] >= 0xA0);  // overlong, surrogates
+                    if (ok && len == 4) ok = !(p[0] == 0xF0 && p[1] < 0x90) && !(p[0] == 0xF4 && p[1] >= 0x90);
+                    if (ok) {
+                        o.append((const char*)p, (size_t)len);
+                        p += len - 1;
+                    } else {
+                        o += "\\ufffd";
+                    }
                 }
         }
     }

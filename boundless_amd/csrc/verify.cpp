@@ -131,7 +131,10 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     bx_segment_params shape{po2, widths[0], widths[1], widths[2], hdr[4], hdr[5]};
     {
         bx_segment_params norm = shape;
-        VCHECK(hdr[4] != 0 && hdr[5] != 0, "header: bad circuit knobs");
+        // a zero knob is "use the default" on the proving side and never reaches a seal of the built-in circuit; a plug-in
+        // circuit may leave the two words unused (bx_circuit.h: they are the circuit's to interpret), so only its own
+        // normalisation decides
+        if (circ == bx_synthetic_circuit()) VCHECK(hdr[4] != 0 && hdr[5] != 0, "header: bad circuit knobs");
         if (circ->normalize) VCHECK(circ->normalize(circ->user, &norm) == nullptr, "header: bad circuit knobs");
         VCHECK(norm.cons_terms == shape.cons_terms && norm.cons_degree == shape.cons_degree, "header: bad circuit knobs");
     }
@@ -161,6 +164,9 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     trees[3].read_and_commit(rd, T, h, D, widths[3]);
     const Fp4 Z = T.random_ext();
     // ---- taps ----
+    // every column contributes at least one ext tap value to coeff_u: refuse a header whose widths the seal cannot back before
+    // spending any per-column work on it (an 8 KB seal claiming three 65535-column groups used to cost seconds here)
+    VCHECK(rd.n - rd.pos >= 4 * ((size_t)widths[0] + widths[1] + widths[2] + widths[3]), "seal truncated");
     // tap set of every column (the rows back it is opened at) and the combo it belongs to: columns with the same set share
     // a DEEP combination polynomial, combos in order of first appearance, the check group's last (as in prover.hip)
     std::vector<std::vector<std::vector<uint32_t>>> backs(4);

@@ -156,3 +156,30 @@ def test_long_poll_claim_and_invalid_stream(server):
         bad.poll_work(max_idle_polls=1)
     bad.close()
     w.close()
+
+
+def test_a_long_non_ascii_error_still_reaches_the_server_as_valid_json(server):
+    """The 1024-byte truncation (lib.rs:424) must not cut a multi-byte UTF-8 sequence in half, and bytes that are not UTF-8 at
+    all must not make the failure report itself fail (the lane used to stop with [BENTO-WF-112])."""
+    st = server.state
+    for k, (task, text) in enumerate((("t-utf8", "é" * 2000), ("t-bytes", None))):
+        st.hot[f"job:{JOB}:segments:{k}"] = (ag.serialize_segment(Segment.synthetic(k, po2=10)), None)
+        st.create_task("prove", JOB, task, {"Prove": {"index": k}}, max_retries=0)
+
+    class Noisy:
+        def prove_segment(self, seg):
+            if seg.index == 0:
+                raise RuntimeError("é" * 2000)
+            raise RuntimeError(b"bad \xff\xfe bytes \xc3".decode("latin-1").encode("latin-1").decode("utf-8", "surrogateescape"))
+
+    w = ag.RestWorker(server.url)
+    a = ag.Agent(prover=Noisy(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    try:
+        assert a.poll_work(max_idle_polls=1) == 0
+    finally:
+        a.close()
+    by = {t["task_id"]: t for t in st.tasks}
+    assert by["t-utf8"]["state"] == "failed" and by["t-bytes"]["state"] == "failed"
+    e = by["t-utf8"]["error"]
+    assert e.startswith("[BENTO-WF-115] Prove failed: é") and e.endswith("é") and len(e.encode()) in (1023, 1024)
+    w.close()

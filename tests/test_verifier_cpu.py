@@ -185,3 +185,17 @@ def test_seal_of_another_segment_shape_is_rejected():
     mixed[-500:] = b[-500:]
     with pytest.raises(HalError):
         verify_seal(mixed)
+
+
+def test_a_short_seal_claiming_huge_widths_is_refused_before_any_per_column_work():
+    """An ~8 KB seal whose header claims three 65535-column groups used to cost ~1.7 s of tap-set construction before it was
+    rejected as truncated (the agent verifies every seal it is handed): the widths are now checked against the words left."""
+    import time
+
+    seal, _ = ol.prove_segment(9, 1, 1, 1, 3)
+    bad = seal[:2048].copy()
+    bad[1] = bad[2] = bad[3] = 65535
+    t0 = time.perf_counter()
+    with pytest.raises(HalError):
+        verify_seal(bad)
+    assert time.perf_counter() - t0 < 0.25
