@@ -40,24 +40,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r02"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
+PROFILE_ROUND = "r03"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GOPS = 39321.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz non-packed VALU lane-ops (measured ~37k, profiles/r01_microbench_valu.jsonl)
 
 
+_replayed = {}  # profile file -> csrc hash it was collected on (None when the file predates the stamps)
+
+
 def _profile(name):
-    """profiles/<PROFILE_ROUND>_<name>, or round 1's file while this round's has not been collected yet"""
-    for rnd in (PROFILE_ROUND, "r01"):
+    """profiles/<PROFILE_ROUND>_<name>, or an earlier round's file while this round's has not been collected yet"""
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(p):
             return p
     raise FileNotFoundError(name)
 
 
+def _load_profile(name):
+    """A committed PMC summary this line replays; remembers which sources it was collected on (boundless_amd.build.csrc_hash)."""
+    path = _profile(name)
+    j = json.load(open(path))
+    _replayed[os.path.basename(path)] = j.get("csrc_sha") if isinstance(j, dict) else None
+    return j
+
+
+def replayed_profiles():
+    """Which figures of this line were not measured in this run, and whether the library that ran is the one they describe."""
+    from boundless_amd.build import csrc_hash
+
+    cur = csrc_hash()
+    return {"csrc_sha": cur, "files": dict(_replayed),
+            "profile_stale": any(v != cur for v in _replayed.values()) if _replayed else False,
+            "note": "roofline.traffic, valu_view and roofline_job replay rocprofv3 --pmc passes committed under profiles/ (counters cannot be "
+                    "collected inside a timed run); profile_stale = at least one of them was collected on other kernel sources than the ones that just ran"}
+
+
 def _valu_per_wave():
     """VALU instructions per wave, per kernel name: this round's job-level PMC pass, else round 1's opbench pass"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_job_valu_insts.json")))["valu_insts_per_wave"]
+        return _load_profile("job_valu_insts.json")["valu_insts_per_wave"]
     except Exception:
         k = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_valu_counts.json")))["kernels"]
         return {name: v["valu_insts_per_wave"] for name, v in k.items() if "valu_insts_per_wave" in v}
@@ -120,7 +142,7 @@ def job_valu_view(segments_per_s_per_gpu):
     """Whole-job VALU issue rate: wave-level VALU instructions per segment (PMC, profiles/r02_job_valu_insts.json, all
     kernels of the default workload) x the measured segment rate of one GPU, against the multiply-class issue peak."""
     try:
-        j = json.load(open(_profile("job_valu_insts.json")))
+        j = _load_profile("job_valu_insts.json")
         rate = j["per_segment"] * segments_per_s_per_gpu
         return {"valu_wave_insts_per_segment": j["per_segment"], "wave_insts_per_s_per_gpu": rate,
                 "issue_peak_mul": 1024 * 2.4e9 / 4, "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3),
@@ -133,34 +155,86 @@ def job_valu_view(segments_per_s_per_gpu):
 
 def agent_mode(args, widths, device, lanes):
     """Segments/s through the native prove agent (include/bx_agent.h) over the in-memory hot store and task db."""
+    out = {}
+    n = max(2, args.steps) * lanes
+    for verify in (True, False):
+        out["verify_on" if verify else "verify_off"] = _agent_run(args, widths, [device], lanes, verify, n)
+    out["lanes"] = lanes
+    out["note"] = ("untimed extra: tasks claimed from the in-memory task db by bx_agent_poll_work; verify_on includes the CPU "
+                   "seal verification the reference runs after every prove (prove.rs:53-55); host_cpu_s_per_proof = process CPU time / proofs")
+    return out
+
+
+def _agent_run(args, widths, devices, lanes, verify, segments):
+    """`segments` synthetic segments through bx_agent_poll_work on `devices` x `lanes` lanes; returns the measurement."""
+    import resource
+
     from boundless_amd import agent as ag
     from boundless_amd.prover import Segment
 
-    out = {}
-    for verify in (True, False):
-        a = ag.Agent(prover=None, device=device, inflight=lanes, widths=widths, poll_time=0.001, verify=verify)
-        try:
-            def enqueue(job, n):
-                for i in range(n):
-                    a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
-                    a.taskdb.create_task(job, f"prove-{i}", {"Prove": {"index": i}})
+    a = ag.Agent(prover=None, device=devices[0], devices=devices if len(devices) > 1 else None, inflight=lanes, widths=widths,
+                 poll_time=0.001, verify=verify, terms=args.terms, degree=args.degree)
+    try:
+        def enqueue(job, n):
+            for i in range(n):
+                a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
+                a.taskdb.create_task(job, f"prove-{i}", {"Prove": {"index": i}})
 
-            enqueue("warm", lanes)
-            a.poll_work(max_idle_polls=1)
-            n = max(2, args.steps) * lanes
-            enqueue("timed", n)
-            t0 = time.perf_counter()
-            done = a.poll_work(max_idle_polls=1)
-            dt = time.perf_counter() - t0
-            if done != n:
-                raise RuntimeError(f"agent completed {done} of {n} tasks")
-            out["verify_on" if verify else "verify_off"] = {"segment_proofs_per_s": n / dt, "segments": n, "seconds": dt}
-        finally:
-            a.close()
-    out["lanes"] = lanes
-    out["note"] = ("untimed extra: tasks claimed from the in-memory task db by bx_agent_poll_work; verify_on includes the CPU "
-                   "seal verification the reference runs after every prove (prove.rs:53-55)")
-    return out
+        enqueue("warm", max(1, args.warmup) * lanes * len(devices))
+        a.poll_work(max_idle_polls=1)
+        base = {d: 0 for d in devices}
+        for d, n in a.lane_stats():
+            base[d] = base.get(d, 0) + n
+        enqueue("timed", segments)
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.perf_counter()
+        done = a.poll_work(max_idle_polls=1)
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        if done != segments:
+            raise RuntimeError(f"agent completed {done} of {segments} tasks")
+        per_dev = {d: -base[d] for d in devices}
+        for d, n in a.lane_stats():
+            per_dev[d] = per_dev.get(d, 0) + n
+        cpu = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        return {"segment_proofs_per_s": segments / dt, "segments": segments, "seconds": dt, "host_cpu_s_per_proof": round(cpu / segments, 5),
+                "cpus_busy_avg": round(cpu / dt, 3), "segments_per_device": {str(d): int(n) for d, n in per_dev.items()}}
+    finally:
+        a.close()
+
+
+def native_agent_main(args, widths):
+    """`--native-agent`: the second multi-GPU design.  ONE process, no torch.distributed: the native agent
+    (include/bx_agent.h, csrc/agent.cpp) runs --inflight prover lanes on each of --gpus devices, every lane claiming from the
+    one task db (the reference's request_work queue is the work-stealing queue), each seal CPU-verified as the reference
+    does after every prove (prove.rs:53-55).  Prints the same JSON line; `value` = segments/s through the whole feed loop.
+    Under torchrun only rank 0 does anything."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--native-agent --gpus {n}: only {torch.cuda.device_count()} device(s) visible")
+    lanes = max(1, args.inflight)
+    devices = list(range(n)) if args.device is None else [args.device] * n
+    segments = args.steps * lanes * n
+    r = _agent_run(args, widths, devices, lanes, True, segments)
+    out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": r["segment_proofs_per_s"], "unit": "segment-proofs/s", "n_gpus": n,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["seconds"] / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
+           "config": {"workload": f"2^{args.po2}-cycle synthetic segments through the native prove agent (claim -> hot-store GET -> prove on the GPU -> "
+                                  f"CPU verify -> SETEX -> UNLINK -> done), trace widths {'/'.join(map(str, widths))}", "po2": args.po2,
+                      "segments_proved": segments, "segments_in_flight_per_gpu": lanes,
+                      "queue": "one in-memory task db shared by every lane of every device (claim-when-idle)",
+                      "parallelism": f"one process, {n} device(s) x {lanes} lanes, no collective, no torch.distributed"},
+           "host_cpu_s_per_proof": r["host_cpu_s_per_proof"],
+           "host": {"cpus_busy_avg": r["cpus_busy_avg"], "wait_policy": os.environ.get("BX_WAIT", "block (library default)"),
+                    "cpus_allowed": len(os.sched_getaffinity(0)), "includes": "lane threads, finisher threads (CPU verification of every seal), the in-memory stores"},
+           "segments_per_device": r["segments_per_device"]}
+    print(json.dumps(out))
 
 
 def main():
@@ -176,6 +250,11 @@ def main():
     ap.add_argument("--dist-backend", type=str, default=None, help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 path be exercised on a single-GPU box")
     ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank (under torchrun): exercises the RCCL rendezvous, barrier and all-reduce of the N>1 path on a one-GPU box")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index for every rank (testing only; default LOCAL_RANK)")
+    ap.add_argument("--cpus", type=int, default=0, help="restrict this process (all lane/finisher threads) to the first N allowed CPUs: the host budget of one GPU's share of the box (tools/host_budget.py)")
+    ap.add_argument("--wait", choices=("block", "spin"), default=None, help="how host threads wait for their stream (BX_WAIT; library default: block)")
+    ap.add_argument("--native-agent", action="store_true", help="second N>1 design: ONE process, no torch.distributed; the native agent (include/bx_agent.h) runs "
+                    "--inflight lanes on each of --gpus devices, all claiming from one task db; value = segments/s through the whole feed loop")
+    ap.add_argument("--no-native-agent-extra", action="store_true", help="N>1 under torchrun: skip the untimed native-agent run that rank 0 spawns after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
     ap.add_argument("--cpu-sample-po2", type=int, default=20, help="size of the oracle proof timed for cpu_baseline (default: the metric's 2^20, ~40 s of CPU)")
@@ -184,7 +263,14 @@ def main():
     ap.add_argument("--dump", type=str, default=None, help="directory: every rank writes rank{r}.npz with the segment indices it claimed in the timed region and their seals (parity tests of the N>1 path)")
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
+    if args.wait:
+        os.environ["BX_WAIT"] = args.wait
+    if args.cpus:
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[: args.cpus]))
+    if args.native_agent:
+        return native_agent_main(args, widths)
 
+    import resource
     import threading
 
     import torch
@@ -254,10 +340,13 @@ def main():
     for sv in servers:
         sv.hal.profile_reset()
         sv.hal.profile_enable(True)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     proved, receipt = run(per_rank if not args.batch else total_global, total_global, "timed")
     barrier()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)  # every thread of this rank, user + system
     prof = {}
     for sv in servers:
         sv.hal.profile_enable(False)
@@ -287,20 +376,20 @@ def main():
             ms = r["ms"] / max(r["calls"], 1)
             gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             kernels[name] = {"calls_per_step": r["calls"] / max(proved, 1), "avg_ms": round(ms, 4),
-                             "ms_per_step": round(r["ms"] / max(proved, 1), 3), "alg_GBps": round(gbps, 1),
+                             "ms_per_segment": round(r["ms"] / max(proved, 1), 3), "alg_GBps": round(gbps, 1),
                              "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
         ntt = kernels.get("batch_expand_into_evaluate_ntt", {})
         iso_k = {}
         for name, r in iso.items():
             ms = r["ms"] / max(r["calls"], 1)
             gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            iso_k[name] = {"avg_ms": round(ms, 4), "ms_per_step": round(r["ms"], 3), "alg_GBps": round(gbps, 1),
+            iso_k[name] = {"avg_ms": round(ms, 4), "ms_per_segment": round(r["ms"], 3), "alg_GBps": round(gbps, 1),
                            "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
         # HBM traffic of the LDE's two kernels from the committed PMC passes of this same command (separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/pmc_traffic.py); None when the file is absent
         traffic = None
         try:
-            pmc = json.load(open(_profile("bench_pmc_traffic.json")))["kernels"]
+            pmc = _load_profile("bench_pmc_traffic.json")["kernels"]
             sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k or "ntt_passA_fwd12_multi_kernel" in k]
             if sel:
                 launches = max(v["launches"] for v in sel)
@@ -342,7 +431,7 @@ def main():
         roofline = ntt_valu_view(ntt_roofline(iso_k, "isolated probe: one extra segment proved alone after the timed region")) if iso_k else roofline_in_region
         # dominance is judged on the isolated durations (in-region ones are stretched by stream sharing)
         dom_src = iso_k if iso_k else kernels
-        dom_name = max(dom_src, key=lambda k: dom_src[k]["ms_per_step"]) if dom_src else None
+        dom_name = max(dom_src, key=lambda k: dom_src[k]["ms_per_segment"]) if dom_src else None
         # The dominant entry point (hash_rows: Poseidon2 leaf hashing) is VALU-issue-bound: report its instruction rate
         # from the committed PMC count of VALU instructions per permutation against the chip's issue peaks
         # (1024 SIMDs x 2.4 GHz / 2 cycles for the cheap class, / 4 cycles for multiplies, profiles/r01_microbench2_instr_cost.jsonl).
@@ -355,8 +444,8 @@ def main():
             rows4 = 4 << args.po2
             perms = rows4 * sum((w + 15) // 16 for w in list(widths) + [16])
             hr = src_k.get("hash_rows", {})
-            if dom_name == "hash_rows" and hr.get("ms_per_step"):
-                trees_ms = hr["ms_per_step"] * (1.0 if iso_k else 1.0)
+            if dom_name == "hash_rows" and hr.get("ms_per_segment"):
+                trees_ms = hr["ms_per_segment"]
                 # hash_rows calls per segment also include the FRI rounds (64 columns, rows/16): add them
                 s_ = 1 << args.po2
                 while s_ > 256:
@@ -367,6 +456,9 @@ def main():
                 dominant.update({"valu_insts_per_permutation": round(per_perm), "permutations_per_s": perm_rate,
                                  "wave_insts_per_s": wave_insts, "issue_peak_cheap": 1024 * 2.4e9 / 2, "issue_peak_mul": 1024 * 2.4e9 / 4,
                                  "frac_of_mul_class_peak": round(wave_insts / (1024 * 2.4e9 / 4), 3),
+                                 # the same rate counting only the permutation's ALGORITHMIC multiplies (1356 modmul x 3
+                                 # multiply-class instructions each): what a reader should hold against "91 % of peak"
+                                 "frac_algorithmic": round(perm_rate * 1356 * 3 / 64.0 / (1024 * 2.4e9 / 4), 3),
                                  "measured": "isolated probe" if iso_k else "timed region"})
         except Exception:
             pass
@@ -375,15 +467,15 @@ def main():
         # not comparable to upstream's effective kHz.  `share_of_gpu_time` is the circuit stages' part of one proof's GPU time.
         src_c = iso_k if iso_k else kernels
         circ_ops = ("witgen_fill", "scatter", "witgen_derive", "accum_gather", "accum_build", "prefix_products", "accum_store", "eval_check")
-        circ_ms = sum(src_c[k]["ms_per_step"] for k in circ_ops if k in src_c)
-        all_ms = sum(v["ms_per_step"] for v in src_c.values())
+        circ_ms = sum(src_c[k]["ms_per_segment"] for k in circ_ops if k in src_c)
+        all_ms = sum(v["ms_per_segment"] for v in src_c.values())
         circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: public words bound to the trace, but no image id and no ZK blinding; lift is not included",
                         "included": ["witness generation (synthetic)", "accumulate (prefix_products)", "eval_check (synthetic constraints / vanishing polynomial)",
                                      "3 trace commits + check commit", "DEEP", "FRI", "50 queries"],
                         "excluded": ["rv32im preflight/witgen/eval_check (generated code, not in the reference tree)", "lift (recursion circuit)",
                                      "ZK blinding rows", "CPU verification of the seal (reported in agent_mode)"],
                         "terms": int(receipt.seal[4]), "degree": int(receipt.seal[5]),
-                        "stages_ms_per_segment": {k: src_c[k]["ms_per_step"] for k in circ_ops if k in src_c},
+                        "stages_ms_per_segment": {k: src_c[k]["ms_per_segment"] for k in circ_ops if k in src_c},
                         "share_of_gpu_time": round(circ_ms / all_ms, 3) if all_ms else None}
         out = {
             "metric": "segment-proofs/sec @ 2^20 cycles",
@@ -401,17 +493,25 @@ def main():
             "config": {"workload": f"single 2^{args.po2}-cycle synthetic segment per GPU via the HIP HAL (witgen+accum+eval_check+NTT+Poseidon2+FRI), "
                                    f"trace widths code/data/accum = {'/'.join(map(str, widths))}, check 16, 50 queries",
                        "po2": args.po2, "segments_proved": proved_total, "segments_in_flight_per_gpu": len(servers),
-                       "queue": ("claim-when-idle ticket queue (c10d store)" if args.steal else "static rank split"),
+                       "queue": ("claim-when-idle ticket queue (c10d store)" if args.steal else
+                                 ("static rank split" if world > 1 else "one rank: its lanes take consecutive segment indices")),
                        "parallelism": f"segments sharded over {world} GPU(s), no collective",
                        "rendezvous": (None if dist is None else f"torch.distributed/{dist.get_backend()}"),
                        "circuit": circuit_view},
             "seal_words": int(receipt.seal.size),
+            "host_cpu_s_per_proof": round(host_cpu_s / max(proved, 1), 5),
+            "host": {"cpu_s_per_proof": round(host_cpu_s / max(proved, 1), 5), "cpu_s_in_timed_region": round(host_cpu_s, 3),
+                     "cpus_busy_avg": round(host_cpu_s / elapsed, 3), "wait_policy": os.environ.get("BX_WAIT", "block (library default)"),
+                     "cpus_allowed": len(os.sched_getaffinity(0)),
+                     "note": "getrusage(RUSAGE_SELF) user+system over the timed region of rank 0 (all lane threads) / proofs; "
+                             "the GPU boxes give a container 16 CPUs for 8 GPUs, i.e. 2 per GPU (profiles/r03_host_budget.json)"},
             "roofline": roofline,
             "roofline_in_region": roofline_in_region,
             "roofline_dominant": dominant,
             "roofline_job": job_valu_view(proved_total / elapsed / max(world, 1)),
             "kernels": kernels,
             "kernels_isolated": iso_k,
+            "replayed_profiles": replayed_profiles(),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -420,6 +520,25 @@ def main():
                 out["cpu_baseline"] = {"error": str(e)}
     for sv in servers:
         sv.close()
+    if world > 1 and not args.no_native_agent_extra:
+        # Untimed extra at N > 1: the other multi-GPU design measured by the same command.  Every rank has released its
+        # provers; rank 0 runs `bench.py --native-agent` over all N devices in a CHILD process under a timeout (a failure or a
+        # hang there cannot take the primary line with it), the other ranks wait at the barrier.
+        if rank == 0:
+            import subprocess
+
+            cmd = [sys.executable, os.path.abspath(__file__), "--native-agent", "--gpus", str(world), "--steps", str(max(2, args.steps // 2)),
+                   "--warmup", "1", "--po2", str(args.po2), "--widths", args.widths, "--inflight", str(args.inflight)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                     "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out["native_agent"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+            except Exception as e:  # reported, never required for the primary number
+                out["native_agent"] = {"error": f"{type(e).__name__}: {e}"}
+        if dist is not None:
+            dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_agent_mode:
             # Untimed extra (never `value`): the same workload claimed through the native feed loop (bx_agent_poll_work:

@@ -20,6 +20,22 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
 
 
+def csrc_hash():
+    """SHA-256 (first 16 hex digits) over the kernel and host sources of the library, in name order.  Profile summaries under
+    profiles/ are stamped with it by the tools that write them, and bench.py reports `profile_stale` when the library it runs
+    was built from different sources than the ones a replayed PMC figure was collected on.  (A content hash rather than a git
+    tree hash: the GPU box receives a snapshot without .git.)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in (CSRC, INC):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".cpp", ".hpp", ".h")):
+                h.update(f.encode() + b"\0")
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 

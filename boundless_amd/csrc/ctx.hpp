@@ -87,6 +87,14 @@ struct bx_ctx {
     long fold_quad = 1;              // small Merkle layers: four lanes per node (hash_fold_quad_kernel) instead of one
     long fold_quad_wg = 512;         // ... input digests per workgroup of that kernel (a power of two, 16..512)
     long fold_fuse_below = 1 << 17;  // Merkle layers with at most this many inputs are folded 9 levels per launch
+    // How a host thread waits for its stream (bx_d2h, bx_sync, bx_h2d ...).  1 = blocking: record an event created with
+    // hipEventBlockingSync and sleep on it (the thread is descheduled until the GPU's interrupt; costs a wake-up latency of a
+    // few microseconds per wait); 0 = hipStreamSynchronize under the runtime's default schedule, which busy-polls.  With one
+    // lane thread per segment in flight and 3 lanes x 8 GPUs against the 16-CPU quota of a GPU box, busy-polling threads would
+    // take CPUs from each other and from the seal verifiers, so blocking is the default (BX_WAIT=spin|block overrides it at
+    // bx_init; measured in profiles/r03_host_budget.json).
+    long wait_blocking = 1;
+    hipEvent_t wait_ev = nullptr;
     long deep_bitrev = 1;            // segment prover: keep trace coefficients bit-reversed through the DEEP phase (read at bx_prover_create)
 
     // timing
@@ -183,7 +191,8 @@ const char* ensure_scratch(bx_ctx* c, size_t words);
 constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
 constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;
 constexpr uint32_t FLAG_SLOTS = 4u;
-const char* sync_and_check_flag(bx_ctx* c);  // hipStreamSynchronize + deferred device errors
+hipError_t stream_wait(bx_ctx* c);           // wait for the ctx's stream under the ctx's wait policy (bx_ctx::wait_blocking)
+const char* sync_and_check_flag(bx_ctx* c);  // stream_wait + deferred device errors
 const char* ntt_init_tables(bx_ctx* c);
 void ntt_free_tables(bx_ctx* c);
 const char* poseidon2_upload_params(bx_ctx* c);

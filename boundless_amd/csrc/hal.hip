@@ -141,9 +141,18 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
         return "bx_init: hipStreamCreate failed";
     }
     c->stream = c->own_stream;
-    if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+    if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->wait_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
         delete c;
         return "bx_init: hipEventCreate failed";
+    }
+    if (const char* w = getenv("BX_WAIT")) {  // BX_WAIT=spin|block: how host threads wait for their stream (ctx.hpp)
+        if (!strcmp(w, "spin")) c->wait_blocking = 0;
+        else if (!strcmp(w, "block")) c->wait_blocking = 1;
+        else {
+            delete c;
+            return "bx_init: BX_WAIT must be 'spin' or 'block'";
+        }
     }
     if (hipHostMalloc((void**)&c->h_flag, FLAG_SLOTS * 4, hipHostMallocDefault) != hipSuccess) {
         bx_free(c);
@@ -177,8 +186,13 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
 }
 
 namespace bx {
+hipError_t stream_wait(bx_ctx* c) {
+    if (!c->wait_blocking || !c->wait_ev) return hipStreamSynchronize(c->stream);
+    hipError_t e = hipEventRecord(c->wait_ev, c->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(c->wait_ev);
+}
 const char* sync_and_check_flag(bx_ctx* c) {
-    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_HIP(c, stream_wait(c));
     volatile uint32_t* f = c->h_flag;
     const bool range = f[FLAG_SLOT_SCATTER_RANGE] != 0, index = f[FLAG_SLOT_SCATTER_INDEX] != 0;
     if (range || index) {
@@ -203,6 +217,7 @@ extern "C" const char* bx_free(bx_ctx* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return nullptr;
@@ -252,7 +267,7 @@ extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t
     BX_REQUIRE(c, words <= dst.len, "bx_h2d: copy larger than the buffer");
     BX_HIP(c, hipSetDevice(c->device));
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src, words * 4, hipMemcpyHostToDevice, c->stream));
-    BX_HIP(c, hipStreamSynchronize(c->stream));  // src may be pageable and freed by the caller right after
+    BX_HIP(c, stream_wait(c));  // src may be pageable and freed by the caller right after
     return nullptr;
 }
 extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words) {
@@ -361,6 +376,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
     } else if (!strcmp(name, "fold_quad_wg")) {
         BX_REQUIRE(c, value >= 16 && value <= 512 && (value & (value - 1)) == 0, "fold_quad_wg must be a power of two in [16, 512]");
         c->fold_quad_wg = value;
+    } else if (!strcmp(name, "wait_blocking")) {
+        BX_REQUIRE(c, value == 0 || value == 1, "wait_blocking must be 0 (busy-poll) or 1 (sleep on a blocking event)");
+        c->wait_blocking = value;
     } else if (!strcmp(name, "fold_fuse_below")) {
         BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
         c->fold_fuse_below = value;
