@@ -231,7 +231,7 @@ def native_agent_main(args, widths):
                       "queue": "one in-memory task db shared by every lane of every device (claim-when-idle)",
                       "parallelism": f"one process, {n} device(s) x {lanes} lanes, no collective, no torch.distributed"},
            "host_cpu_s_per_proof": r["host_cpu_s_per_proof"],
-           "host": {"cpus_busy_avg": r["cpus_busy_avg"], "wait_policy": os.environ.get("BX_WAIT", "block (library default)"),
+           "host": {"cpus_busy_avg": r["cpus_busy_avg"], "wait_policy": os.environ.get("BX_WAIT", "poll (library default)"),
                     "cpus_allowed": len(os.sched_getaffinity(0)), "includes": "lane threads, finisher threads (CPU verification of every seal), the in-memory stores"},
            "segments_per_device": r["segments_per_device"]}
     print(json.dumps(out))
@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank (under torchrun): exercises the RCCL rendezvous, barrier and all-reduce of the N>1 path on a one-GPU box")
     ap.add_argument("--device", type=int, default=None, help="force the HIP device index for every rank (testing only; default LOCAL_RANK)")
     ap.add_argument("--cpus", type=int, default=0, help="restrict this process (all lane/finisher threads) to the first N allowed CPUs: the host budget of one GPU's share of the box (tools/host_budget.py)")
-    ap.add_argument("--wait", choices=("block", "spin"), default=None, help="how host threads wait for their stream (BX_WAIT; library default: block)")
+    ap.add_argument("--wait", choices=("block", "spin", "poll"), default=None, help="how host threads wait for their stream (BX_WAIT; library default: poll = hipEventQuery + usleep)")
     ap.add_argument("--native-agent", action="store_true", help="second N>1 design: ONE process, no torch.distributed; the native agent (include/bx_agent.h) runs "
                     "--inflight lanes on each of --gpus devices, all claiming from one task db; value = segments/s through the whole feed loop")
     ap.add_argument("--no-native-agent-extra", action="store_true", help="N>1 under torchrun: skip the untimed native-agent run that rank 0 spawns after the timed region")
@@ -501,7 +501,7 @@ def main():
             "seal_words": int(receipt.seal.size),
             "host_cpu_s_per_proof": round(host_cpu_s / max(proved, 1), 5),
             "host": {"cpu_s_per_proof": round(host_cpu_s / max(proved, 1), 5), "cpu_s_in_timed_region": round(host_cpu_s, 3),
-                     "cpus_busy_avg": round(host_cpu_s / elapsed, 3), "wait_policy": os.environ.get("BX_WAIT", "block (library default)"),
+                     "cpus_busy_avg": round(host_cpu_s / elapsed, 3), "wait_policy": os.environ.get("BX_WAIT", "poll (library default)"),
                      "cpus_allowed": len(os.sched_getaffinity(0)),
                      "note": "getrusage(RUSAGE_SELF) user+system over the timed region of rank 0 (all lane threads) / proofs; "
                              "the GPU boxes give a container 16 CPUs for 8 GPUs, i.e. 2 per GPU (profiles/r03_host_budget.json)"},

@@ -87,13 +87,21 @@ struct bx_ctx {
     long fold_quad = 1;              // small Merkle layers: four lanes per node (hash_fold_quad_kernel) instead of one
     long fold_quad_wg = 512;         // ... input digests per workgroup of that kernel (a power of two, 16..512)
     long fold_fuse_below = 1 << 17;  // Merkle layers with at most this many inputs are folded 9 levels per launch
-    // How a host thread waits for its stream (bx_d2h, bx_sync, bx_h2d ...).  1 = blocking: record an event created with
-    // hipEventBlockingSync and sleep on it (the thread is descheduled until the GPU's interrupt; costs a wake-up latency of a
-    // few microseconds per wait); 0 = hipStreamSynchronize under the runtime's default schedule, which busy-polls.  With one
-    // lane thread per segment in flight and 3 lanes x 8 GPUs against the 16-CPU quota of a GPU box, busy-polling threads would
-    // take CPUs from each other and from the seal verifiers, so blocking is the default (BX_WAIT=spin|block overrides it at
-    // bx_init; measured in profiles/r03_host_budget.json).
-    long wait_blocking = 1;
+    // How a host thread waits for its stream (bx_d2h, bx_sync, bx_h2d ...).  Measured on this ROCm (tools/waitbench.hip,
+    // tools/host_budget.py; profiles/r03_waitbench.jsonl, r03_host_budget.json), 3 lanes on one GPU at 2^20:
+    //   0 spin   hipStreamSynchronize under the default device schedule busy-polls (the hipEventBlockingSync event flag is
+    //            ignored): one CPU per lane thread + one runtime thread = 4.0 CPUs busy, 0.162 CPU-s per proof;
+    //   1 block  hipSetDeviceFlags(hipDeviceScheduleBlockingSync) before the stream is created (a stream keeps the mode the
+    //            device had at its creation): waits sleep on the completion interrupt, but the runtime's event thread then
+    //            handles one interrupt per kernel: 0.52 CPUs busy, 0.021 CPU-s per proof (flag is per device and process; if
+    //            the runtime refuses it, falls back to 2);
+    //   2 poll   record an event and hipEventQuery it every wait_poll_us (usleep in between): no interrupts, no spinning:
+    //            0.12 CPUs busy, 0.005 CPU-s per proof, same throughput (<= 50 us added per wait, hidden by the other lanes).
+    // With 3 lanes x 8 GPUs against the 16-CPU quota of a GPU box, spinning lanes would take CPUs from each other and from the
+    // seal verifiers, so 2 is the default; BX_WAIT=spin|block|poll overrides it at bx_init.
+    long wait_blocking = 2;
+    long wait_poll_us = 50;
+    bool wait_poll = false;  // blocking requested but the device flag could not be set: sleep-poll an event instead
     hipEvent_t wait_ev = nullptr;
     long deep_bitrev = 1;            // segment prover: keep trace coefficients bit-reversed through the DEEP phase (read at bx_prover_create)
 
@@ -191,6 +199,7 @@ const char* ensure_scratch(bx_ctx* c, size_t words);
 constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
 constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;
 constexpr uint32_t FLAG_SLOTS = 4u;
+void apply_wait_policy(bx_ctx* c);         // set the device's schedule flag from bx_ctx::wait_blocking
 hipError_t stream_wait(bx_ctx* c);           // wait for the ctx's stream under the ctx's wait policy (bx_ctx::wait_blocking)
 const char* sync_and_check_flag(bx_ctx* c);  // stream_wait + deferred device errors
 const char* ntt_init_tables(bx_ctx* c);

@@ -11,6 +11,8 @@
 #include <mutex>
 #include <string>
 
+#include <unistd.h>
+
 #include "ctx.hpp"
 #include "poseidon2_params.hpp"
 
@@ -136,23 +138,27 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
     c->err[0] = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (const char* w = getenv("BX_WAIT")) {  // BX_WAIT=spin|block: how host threads wait for their stream (ctx.hpp)
+        if (!strcmp(w, "spin")) c->wait_blocking = 0;
+        else if (!strcmp(w, "block")) c->wait_blocking = 1;
+        else if (!strcmp(w, "poll")) c->wait_blocking = 2;
+        else {
+            delete c;
+            return "bx_init: BX_WAIT must be 'spin', 'block' or 'poll'";
+        }
+    }
+    // before the stream exists: a stream keeps the wait mode the device had when it was created (measured: the first ctx of a
+    // process, whose stream predated the flag, kept busy-polling while later ones slept)
+    apply_wait_policy(c);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return "bx_init: hipStreamCreate failed";
     }
     c->stream = c->own_stream;
     if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->wait_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return "bx_init: hipEventCreate failed";
-    }
-    if (const char* w = getenv("BX_WAIT")) {  // BX_WAIT=spin|block: how host threads wait for their stream (ctx.hpp)
-        if (!strcmp(w, "spin")) c->wait_blocking = 0;
-        else if (!strcmp(w, "block")) c->wait_blocking = 1;
-        else {
-            delete c;
-            return "bx_init: BX_WAIT must be 'spin' or 'block'";
-        }
     }
     if (hipHostMalloc((void**)&c->h_flag, FLAG_SLOTS * 4, hipHostMallocDefault) != hipSuccess) {
         bx_free(c);
@@ -187,9 +193,20 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
 
 namespace bx {
 hipError_t stream_wait(bx_ctx* c) {
-    if (!c->wait_blocking || !c->wait_ev) return hipStreamSynchronize(c->stream);
+    if (!((c->wait_blocking == 2 || (c->wait_blocking == 1 && c->wait_poll)) && c->wait_ev))
+        return hipStreamSynchronize(c->stream);  // sleeps on the interrupt or busy-polls, per the device's schedule flag
     hipError_t e = hipEventRecord(c->wait_ev, c->stream);
-    return e != hipSuccess ? e : hipEventSynchronize(c->wait_ev);
+    if (e != hipSuccess) return e;
+    while ((e = hipEventQuery(c->wait_ev)) == hipErrorNotReady) usleep((useconds_t)c->wait_poll_us);
+    return e;
+}
+// Apply bx_ctx::wait_blocking to the device (see ctx.hpp).  The flag is per device and process, not per ctx.
+void apply_wait_policy(bx_ctx* c) {
+    c->wait_poll = false;
+    if (hipSetDeviceFlags(c->wait_blocking == 1 ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin) != hipSuccess) {
+        (void)hipGetLastError();
+        c->wait_poll = c->wait_blocking == 1;
+    }
 }
 const char* sync_and_check_flag(bx_ctx* c) {
     BX_HIP(c, stream_wait(c));
@@ -377,8 +394,13 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         BX_REQUIRE(c, value >= 16 && value <= 512 && (value & (value - 1)) == 0, "fold_quad_wg must be a power of two in [16, 512]");
         c->fold_quad_wg = value;
     } else if (!strcmp(name, "wait_blocking")) {
-        BX_REQUIRE(c, value == 0 || value == 1, "wait_blocking must be 0 (busy-poll) or 1 (sleep on a blocking event)");
+        BX_REQUIRE(c, value >= 0 && value <= 2, "wait_blocking must be 0 (busy-poll), 1 (sleep until the completion interrupt) or 2 (sleep-poll an event)");
         c->wait_blocking = value;
+        BX_HIP(c, hipSetDevice(c->device));
+        apply_wait_policy(c);
+    } else if (!strcmp(name, "wait_poll_us")) {
+        BX_REQUIRE(c, value >= 1 && value <= 10000, "wait_poll_us out of range [1, 10000]");
+        c->wait_poll_us = value;
     } else if (!strcmp(name, "fold_fuse_below")) {
         BX_REQUIRE(c, value >= 0, "fold_fuse_below must be >= 0");
         c->fold_fuse_below = value;

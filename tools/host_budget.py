@@ -39,7 +39,7 @@ if __name__ == "__main__":
     res = {"csrc_sha": csrc_hash(), "what": __doc__.split("\n\n")[0], "command": f"bench.py --steps {STEPS} --warmup 3 --no-cpu-baseline [--cpus 2] --wait block|spin",
            "cpus_allowed": len(os.sched_getaffinity(0)), "runs": {}}
     for cpus in (0, 2, 1):
-        for wait in ("block", "spin"):
+        for wait in ("block", "poll", "spin"):
             key = f"cpus={'all' if not cpus else cpus},wait={wait}"
             res["runs"][key] = run((["--cpus", str(cpus)] if cpus else []) + ["--wait", wait])
             print(key, res["runs"][key], file=sys.stderr)
