@@ -469,11 +469,11 @@ def main():
         circ_ops = ("witgen_fill", "scatter", "witgen_derive", "accum_gather", "accum_build", "prefix_products", "accum_store", "eval_check")
         circ_ms = sum(src_c[k]["ms_per_segment"] for k in circ_ops if k in src_c)
         all_ms = sum(v["ms_per_segment"] for v in src_c.values())
-        circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: public words bound to the trace, but no image id and no ZK blinding; lift is not included",
-                        "included": ["witness generation (synthetic)", "accumulate (prefix_products)", "eval_check (synthetic constraints / vanishing polynomial)",
+        circuit_view = {"kind": "synthetic AIR (include/bx_prover.h), not rv32im: public words bound to the trace, seeded ZK noise rows (last 1994), but no image id / claim; lift is not included",
+                        "included": ["witness generation (synthetic) with ZK noise rows", "accumulate (prefix_products)", "eval_check (synthetic constraints / vanishing polynomial)",
                                      "3 trace commits + check commit", "DEEP", "FRI", "50 queries"],
                         "excluded": ["rv32im preflight/witgen/eval_check (generated code, not in the reference tree)", "lift (recursion circuit)",
-                                     "ZK blinding rows", "CPU verification of the seal (reported in agent_mode)"],
+                                     "CPU verification of the seal (reported in agent_mode)"],
                         "terms": int(receipt.seal[4]), "degree": int(receipt.seal[5]),
                         "stages_ms_per_segment": {k: src_c[k]["ms_per_segment"] for k in circ_ops if k in src_c},
                         "share_of_gpu_time": round(circ_ms / all_ms, 3) if all_ms else None}

@@ -36,7 +36,8 @@ _CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(
 
 class CircuitOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("name", C.c_char_p), ("normalize", _NORMALIZE), ("taps", _TAPS), ("n_globals", _NGLOBALS), ("create", _CREATE),
-                ("destroy", _DESTROY), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL), ("constraints_at", _CONS)]
+                ("destroy", _DESTROY), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL), ("constraints_at", _CONS),
+                ("set_noise_seed", C.c_void_p)]  # optional (include/bx_circuit.h); NULL for circuits written in Python
 
     @staticmethod
     def from_object(obj, name=b"python-circuit"):

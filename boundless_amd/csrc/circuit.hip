@@ -36,28 +36,30 @@ __global__ void witness_code_kernel(uint32_t* __restrict__ code, Circuit cc, uin
     const size_t total = (size_t)n * cc.wc, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const uint32_t c = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
-        code[i] = c == 0 ? (r == 0 ? MONT_ONE : 0u) : c == 1 ? (r == n - 1 ? MONT_ONE : 0u) : synth_word(gseed, c, r);
+        code[i] = c == 0 ? (r == 0 ? MONT_ONE : 0u) : c == 1 ? (r == cc.active_rows() - 1 ? MONT_ONE : 0u) : synth_word(gseed, c, r);
     }
 }
 // ---- witness: free data columns (the permuted copies 4p+3, p < pairs, are placed by Hal::scatter afterwards) ----
-__global__ void witness_free_kernel(uint32_t* __restrict__ data, Circuit cc, uint64_t gseed) {
-    const uint32_t n = 1u << cc.po2;
+// Rows >= active_rows() are the ZK noise rows: drawn from the noise seed, in the permuted copies too.
+__global__ void witness_free_kernel(uint32_t* __restrict__ data, Circuit cc, uint64_t gseed, uint64_t nseed) {
+    const uint32_t n = 1u << cc.po2, act = cc.active_rows();
     const size_t total = (size_t)n * cc.F, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const uint32_t c = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
-        if ((c & 3u) == 3u && (c >> 2) < cc.pairs) continue;
-        data[i] = synth_word(gseed, c, r);
+        if (r < act && (c & 3u) == 3u && (c >> 2) < cc.pairs) continue;
+        data[i] = synth_word(r < act ? gseed : nseed, c, r);
     }
 }
 // offsets of pair p's scatter: entry r of column 4p+2 goes to column 4p+3, row perm_p(r)   (built once per prover)
 __global__ void perm_offsets_kernel(uint32_t* __restrict__ offsets, uint32_t* __restrict__ index, Circuit cc) {
-    const uint32_t n = 1u << cc.po2;
+    const uint32_t n = 1u << cc.po2, act = cc.active_rows();
     const size_t total = (size_t)n * cc.pairs, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const uint32_t p = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
-        offsets[i] = (4 * p + 3) * n + cc.perm_row(p, r);
+        offsets[i] = r < act ? (4 * p + 3) * n + cc.perm_row(p, r) : 0u;
     }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) index[i] = (uint32_t)i;  // one entry per cycle
+    // one entry per active cycle, none for the noise cycles
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) index[i] = (uint32_t)(i < act ? i : act);
 }
 
 // ---- witness: derived data columns, one thread per row, columns in order (column F+j reads F+j-1 .. F+j-4) ----
@@ -254,15 +256,15 @@ const char* circuit_perm_tables(bx_ctx* c, const Circuit& cc, bx_buf offsets, bx
 
 // code + data witness.  `data`/`code` are the groups' column-major N x width buffers; the permuted copies go through
 // Hal::scatter (one call per pair, one entry per cycle), the derived columns through one thread per row.
-const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, bx_buf perm_offsets,
-                            bx_buf perm_index) {
+const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, uint64_t seed_noise,
+                            bx_buf perm_offsets, bx_buf perm_index) {
     const size_t n = (size_t)1 << cc.po2;
     BX_REQUIRE(c, code.len == n * cc.wc && data.len == n * cc.wd, "circuit_witness: group buffer size mismatch");
     {
         OpScope op(c, "witgen_fill", 4.0 * (double)(n * (cc.wc + cc.F)));
         hipLaunchKernelGGL(witness_code_kernel, dim3(grid_for(n * cc.wc)), dim3(256), 0, c->stream, (uint32_t*)code.dptr, cc, seed_code);
         BX_LAUNCH_CHECK(c);
-        hipLaunchKernelGGL(witness_free_kernel, dim3(grid_for(n * cc.F)), dim3(256), 0, c->stream, (uint32_t*)data.dptr, cc, seed_data);
+        hipLaunchKernelGGL(witness_free_kernel, dim3(grid_for(n * cc.F)), dim3(256), 0, c->stream, (uint32_t*)data.dptr, cc, seed_data, seed_noise);
         BX_LAUNCH_CHECK(c);
     }
     for (uint32_t p = 0; p < cc.pairs; ++p) {
@@ -366,6 +368,8 @@ namespace {
 constexpr uint64_t GOLDEN64 = 0x9E3779B97F4A7C15ull;
 struct SynthState {
     Circuit cc;
+    uint64_t noise_seed = 0;
+    bool noise_set = false;  // bx_circuit_ops::set_noise_seed was called for the next witgen
     bx_buf perm_offsets{nullptr, 0}, perm_index{nullptr, 0}, acc_src{nullptr, 0}, acc_run{nullptr, 0}, betas{nullptr, 0}, mixpows{nullptr, 0};
 };
 void synth_destroy(void*, void* state) {
@@ -399,11 +403,14 @@ const char* synth_create(void*, bx_ctx* c, const bx_segment_params* shape, void*
 __global__ void globals_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ data, Circuit cc) {
     const size_t n = (size_t)1 << cc.po2;
     if (threadIdx.x == 0) out[0] = data[0];                                  // data[0][0]
-    if (threadIdx.x == 1) out[1] = data[(size_t)(cc.wd - 1) * n + (n - 1)];  // data[wd-1][N-1]
+    if (threadIdx.x == 1) out[1] = data[(size_t)(cc.wd - 1) * n + (cc.active_rows() - 1)];  // data[wd-1][last active row]
 }
 const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, uint64_t seed, uint32_t* globals_out) {
     auto* st = (SynthState*)state;
-    BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 1, seed + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
+    // the ZK rows' generator: given through set_noise_seed, else a function of the seed (bx_prover.h, "seeds")
+    const uint64_t noise = st->noise_set ? st->noise_seed : splitmix64(seed ^ 0x5A4B4E4F49534521ull);
+    st->noise_set = false;
+    BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 1, seed + GOLDEN64 * 2, noise + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
     BX_TRY(circuit_accum_gather(c, st->cc, st->acc_src, data));  // the prover interpolates `data` in place next
     // the statement's public words come out of the witness (one small copy; the derived cell is only known on the device)
     hipLaunchKernelGGL(globals_kernel, dim3(1), dim3(64), 0, c->stream, (uint32_t*)st->betas.dptr, (const uint32_t*)data.dptr, st->cc);
@@ -412,6 +419,11 @@ const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data
     BX_TRY(bx_d2h(c, g, bx_buf{st->betas.dptr, 2}, 2));  // betas is written by accumulate later: free to borrow here
     for (uint32_t i = 0; i < st->cc.globals(); ++i) globals_out[i] = g[i];
     return nullptr;
+}
+void synth_set_noise_seed(void*, void* state, uint64_t noise_seed) {
+    auto* st = (SynthState*)state;
+    st->noise_seed = noise_seed;
+    st->noise_set = true;
 }
 const char* synth_betas(bx_ctx* c, SynthState* st, const uint32_t mix[4]) {
     if (!st->cc.E) return nullptr;
@@ -460,6 +472,7 @@ extern "C" const bx_circuit_ops* bx_synthetic_circuit(void) {
                                        bx::synth_witgen,
                                        bx::synth_accumulate,
                                        bx::synth_eval_check,
-                                       bx::synthetic_constraints_at};
+                                       bx::synthetic_constraints_at,
+                                       bx::synth_set_noise_seed};
     return &ops;
 }

@@ -66,9 +66,16 @@ struct Circuit {
         if (p < pairs) return (e & 1) ? 4 * p + 3 : 4 * p + 2;
         return e % F;
     }
-    // row permutation of pair p: data[4p+3][perm(r)] = data[4p+2][r]
+    // ZK noise rows: the last zk_rows() rows of the trace hold noise in every free data column (drawn from the segment's
+    // noise seed), the derived columns and the accumulators simply continue over them (their constraints hold on every row), and
+    // `last`, the public word g_1 and the permuted copies refer to the active rows [0, active_rows()) only.
+    // risc0_zkp::ZK_CYCLES = 1994 [EXT]; capped at N/4 for the small sizes the tests use.
+    BX_CIRC_HD uint32_t zk_rows() const { return ((1u << po2) >> 2) < 1994u ? ((1u << po2) >> 2) : 1994u; }
+    BX_CIRC_HD uint32_t active_rows() const { return (1u << po2) - zk_rows(); }
+    // row permutation of pair p over the active rows: data[4p+3][perm(r)] = data[4p+2][r], r < active_rows()
+    // (a bijection: the multiplier is a prime larger than any row count)
     BX_CIRC_HD uint32_t perm_row(uint32_t p, uint32_t r) const {
-        return (uint32_t)(((uint64_t)r * 2654435761ull + 12345u + p) & (((uint64_t)1 << po2) - 1));
+        return (uint32_t)(((uint64_t)r * 2654435761ull + 12345u + p) % active_rows());
     }
     // tap set of column c of group g (0 code, 1 data, 2 accum): the rows back it is opened at; returns their count.
     // data: c % 8 == 0 -> {0,1}, c % 8 == 4 -> {0,1,2}; accumulator columns {0,1}; everything else {0}

@@ -333,8 +333,17 @@ extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_o
     return nullptr;
 }
 
+static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
 extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
     if (!p) return "bx_prove_segment: null prover";
+    return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);  // the circuit derives the noise seed from the seed
+}
+extern "C" const char* bx_prove_segment_zk(bx_prover* p, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
+    if (!p) return "bx_prove_segment_zk: null prover";
+    if (p->circ->set_noise_seed) p->circ->set_noise_seed(p->circ->user, p->circ_state, noise_seed);
+    return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);
+}
+static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
     bx_ctx* c = p->c;
     if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prove_segment: hipSetDevice failed");
     const size_t N = p->N, D = 4 * N;

@@ -27,6 +27,7 @@ class Segment:
     index: int
     po2: int = 20
     seed: int = 0xB0D1E550000
+    noise_seed: int = None  # generator of the ZK noise rows (None = derived from `seed`, include/bx_prover.h)
 
     @staticmethod
     def synthetic(index, po2=20, base_seed=0xB0D1E550000):
@@ -69,6 +70,8 @@ def _declare(lib):
     lib.bx_prover_seal_words.restype = sz
     lib.bx_prove_segment.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, sz, C.POINTER(sz)]
     lib.bx_prove_segment.restype = C.c_char_p
+    lib.bx_prove_segment_zk.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, sz, C.POINTER(sz)]
+    lib.bx_prove_segment_zk.restype = C.c_char_p
     lib.bx_prover_last_roots.argtypes = [C.c_void_p, C.c_void_p]
     lib.bx_prover_last_roots.restype = C.c_char_p
     lib.bx_verify_segment.argtypes = [C.c_void_p, sz]
@@ -120,7 +123,11 @@ class HipProverServer:
         if segment.po2 != self.po2:
             raise HalError(f"segment po2 {segment.po2} does not match the prover's allocation ({self.po2})")
         n = C.c_size_t(0)
-        msg = self.lib.bx_prove_segment(self.handle, segment.seed & (2**64 - 1), self._seal.ctypes.data, self._seal.size, C.byref(n))
+        if segment.noise_seed is None:
+            msg = self.lib.bx_prove_segment(self.handle, segment.seed & (2**64 - 1), self._seal.ctypes.data, self._seal.size, C.byref(n))
+        else:
+            msg = self.lib.bx_prove_segment_zk(self.handle, segment.seed & (2**64 - 1), segment.noise_seed & (2**64 - 1),
+                                               self._seal.ctypes.data, self._seal.size, C.byref(n))
         if msg:
             raise HalError(msg.decode())
         roots = np.zeros(32, np.uint32)

@@ -68,6 +68,11 @@ typedef struct bx_circuit_ops {
      * `poly_ext` called by risc0_zkp::verify. */
     const char* (*constraints_at)(void* user, const bx_segment_params* shape, const bx_tap_reader* taps, const uint32_t poly_mix[4],
                                   const uint32_t mix[4], const uint32_t* globals, uint32_t out[4]);
+    /* ZK blinding: the generator of the noise cells of the NEXT witgen/accumulate (upstream fills them from a thread RNG, which
+     * is why its seals differ from run to run; here every random fill is seeded through the ABI — SURVEY.md section 7, hard part
+     * 3).  Called by bx_prove_segment_zk before witgen.  May be NULL (a circuit without noise cells, or one that derives them
+     * from the seed); tables that predate this member must zero-initialise it. */
+    void (*set_noise_seed)(void* user, void* state, uint64_t noise_seed);
 } bx_circuit_ops;
 
 /* The synthetic circuit of bx_prover.h ("The synthetic circuit"); what bx_prover_create / bx_verify_segment use. */

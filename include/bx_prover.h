@@ -20,17 +20,21 @@
  * stage whose constraints really vanish on the trace domain and are divided by the vanishing polynomial.  The seal is a
  * STARK proof of that circuit: bx_verify_segment accepts it only if the constraint identity holds at the random point Z.
  * It is a deterministic function of (params, seed) and bit-identical to the CPU oracle's seal (oracle/bx_oracle_prover.c).
- * It is NOT a risc0 receipt: no image id, no claim, no ZK blinding rows.
+ * It is NOT a risc0 receipt: no image id and no claim (the ZK blinding rows are there, seeded).
  *
  * The synthetic circuit (normative; N = 2^po2 rows, all row indices cyclic mod N)
  * -------------------------------------------------------------------------------
  *   knobs      T = cons_terms (product terms per derived-column constraint), G = cons_degree (factors per term, <= 5)
  *   seeds      gseed_g = seed + (g+1) * 0x9E3779B97F4A7C15;  word(s,c,r) = splitmix64(s ^ (c << 32 | r)) >> 33, minus P if >= P
- *   code       column 0 = first (1 at row 0, else 0); column 1 = last (1 at row N-1); column c >= 2 = word(gseed_0, c, r).
+ *   zk rows    Z = min(1994, N/4) (risc0_zkp::ZK_CYCLES = 1994 [EXT]); A = N - Z active rows.  Rows >= A of every free data column
+ *              (the permuted copies included) are noise: word(nseed_1, c, r), nseed_g = noise_seed + (g+1) * 0x9E3779B97F4A7C15.
+ *              Derived columns and accumulators are computed on them like on any row (their constraints hold on every row),
+ *              so they are blinded through the free cells; the code group is public and carries no noise.
+ *   code       column 0 = first (1 at row 0, else 0); column 1 = last (1 at row A-1, the last active row); column c >= 2 = word(gseed_0, c, r).
  *              csel(i) = code column 2 + i mod (w_code - 2) when w_code >= 3, else the constant 1.
  *   data       F = ceil(w_data / 2) free columns, J = w_data - F derived columns.
- *              free column c: word(gseed_1, c, r), except the permuted copies: for pair p < pairs,
- *                  data[4p+3][perm_p(r)] = data[4p+2][r],  perm_p(r) = (r * 2654435761 + 12345 + p) mod N
+ *              free column c: word(gseed_1, c, r) on the active rows, except the permuted copies: for pair p < pairs and r < A,
+ *                  data[4p+3][perm_p(r)] = data[4p+2][r],  perm_p(r) = (r * 2654435761 + 12345 + p) mod A
  *              (placed with Hal::scatter).  pairs = the number of p with 2p+1 < E and 4p+3 < F (0 when w_code < 2).
  *              derived column F+j: with the 16-entry pool
  *                  pool_j = [ u = data[j][r],  ub = data[j][r-1] if j % 8 == 0, data[j][r-2] if j % 8 == 4, else u,  data[(j+1) mod F][r],  data[(j+2) mod F][r],
@@ -46,7 +50,7 @@
  *              e < E :  acc_e(r) - (first(r) + (1 - first(r)) * acc_e(r-1)) * (beta_e + data[src(e)][r])        = 0
  *              p < pairs :  last(r) * (acc_{2p+1}(r) - acc_{2p}(r))                                             = 0
  *              first(r) * (data[0][r] - g_0) = 0   and, when w_code >= 2,   last(r) * (data[w_data-1][r] - g_1) = 0
- *   globals    the statement's public words g_0 = data[0][0], g_1 = data[w_data-1][N-1] (Montgomery words): written to the seal
+ *   globals    the statement's public words g_0 = data[0][0], g_1 = data[w_data-1][A-1] (Montgomery words): written to the seal
  *              right after the header and bound into the transcript before the first commitment; the two boundary constraints
  *              above tie them to the trace, so the seal proves "a trace of this circuit that starts at g_0 ends at g_1".
  *   check      check(x) = sum_i poly_mix^i C_i(x) / ((3x)^N - 1), evaluated on the 4N domain x = w_4N^row from the
@@ -89,6 +93,12 @@ size_t bx_prover_seal_words(const bx_prover* prover);
 /* Prove one synthetic segment identified by `seed`; writes the seal (u32 words) and its length. Blocks. */
 const char* bx_prove_segment(bx_prover* prover, uint64_t seed, uint32_t* seal_out, size_t seal_cap,
                              size_t* seal_words);
+/* The same with an explicit generator for the ZK noise cells (the last min(1994, N/4) rows of the free data columns of the
+ * built-in circuit).  Upstream draws them from a thread RNG, so its seals are not reproducible; here (seed, noise_seed) fixes the
+ * seal.  bx_prove_segment uses noise_seed = splitmix64(seed ^ 0x5A4B4E4F49534521).  Two noise seeds give two different seals of
+ * the same statement (same header and public words), both accepted by bx_verify_segment. */
+const char* bx_prove_segment_zk(bx_prover* prover, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap,
+                                size_t* seal_words);
 /* Merkle root (8 words each) of the code, data, accum and check groups of the last proof. */
 const char* bx_prover_last_roots(const bx_prover* prover, uint32_t roots_out[32]);
 

@@ -99,6 +99,11 @@ uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint
 /* same with the circuit's knobs: product terms per derived-column constraint and factors per term (0 = defaults) */
 uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
                                uint64_t seed, size_t* seal_words, uint32_t roots_out[32]);
+/* same with an explicit seed for the ZK noise rows (the last min(1994, N/4) rows of the free data columns; upstream draws them
+ * from a thread RNG, so its seals differ run to run — SURVEY.md section 7, hard part 3).  bxo_prove_segment_ex derives
+ * noise_seed = splitmix64(seed ^ 0x5A4B4E4F49534521). */
+uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
+                               uint64_t seed, uint64_t noise_seed, size_t* seal_words, uint32_t roots_out[32]);
 /* test hook: add 1 to witness cell (group, col, row) before it is committed, making the proved statement false (group < 0: off) */
 void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
 void bxo_free(void* p);

@@ -99,7 +99,7 @@ static uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
 #define POOL 16
 typedef struct {
     uint32_t po2, wc, wd, wa, T, G;
-    size_t n;
+    size_t n, zk, act; /* rows; ZK noise rows at the end of the trace; active rows = n - zk */
     uint32_t F, J, E, pairs;
 } circ_t;
 static void circ_init(circ_t* c, uint32_t po2, uint32_t wc, uint32_t wd, uint32_t wa, uint32_t terms, uint32_t degree) {
@@ -107,6 +107,8 @@ static void circ_init(circ_t* c, uint32_t po2, uint32_t wc, uint32_t wd, uint32_
     c->T = terms ? terms : DEFAULT_TERMS;
     c->G = degree ? degree : DEFAULT_DEGREE;
     c->n = (size_t)1 << po2;
+    c->zk = c->n / 4 < 1994 ? c->n / 4 : 1994; /* risc0_zkp::ZK_CYCLES = 1994 [EXT], capped for the small sizes the tests use */
+    c->act = c->n - c->zk;
     c->F = (wd + 1) / 2;
     c->J = wd - c->F;
     c->E = wa / 4;
@@ -125,7 +127,7 @@ static uint32_t acc_src(const circ_t* c, uint32_t e) {
     return e % c->F;
 }
 /* the row permutation of pair p: data[4p+3][perm(r)] = data[4p+2][r] */
-static size_t perm_row(const circ_t* c, uint32_t p, size_t r) { return (r * 2654435761ull + 12345u + p) & (c->n - 1); }
+static size_t perm_row(const circ_t* c, uint32_t p, size_t r) { return (r * 2654435761ull + 12345u + p) % c->act; } /* a bijection of the active rows: 2654435761 is prime and > act */
 /* tap set of a column: the rows back it is opened at (first entry 0); returns their number */
 #define MAX_TAPS 8
 #define MAX_COMBOS 16
@@ -225,6 +227,11 @@ void bxo_set_witness_fault(int group, uint32_t col, uint32_t row) {
 /* Returns a malloc'ed seal (caller frees with bxo_free) or NULL on an internal consistency failure. */
 uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
                                uint64_t seed, size_t* seal_words, uint32_t roots_out[32]) {
+    /* default noise seed of include/bx_prover.h: splitmix64(seed ^ "ZKNOISE!") */
+    return bxo_prove_segment_zk(po2, w_code, w_data, w_accum, terms, degree, seed, splitmix64(seed ^ 0x5A4B4E4F49534521ull), seal_words, roots_out);
+}
+uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
+                               uint64_t seed, uint64_t noise_seed, size_t* seal_words, uint32_t roots_out[32]) {
     bxo_init();
     const size_t n = (size_t)1 << po2, dom = 4 * n;
     const uint32_t widths[4] = {w_code, w_data, w_accum, CHECK_SIZE};
@@ -252,6 +259,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         group_t* G = &grp[g];
         G->width = widths[g];
         uint64_t gseed = seed + GOLDEN * (uint64_t)(g + 1);
+        const uint64_t nseed = noise_seed + GOLDEN * (uint64_t)(g + 1); /* the ZK rows' own generator (upstream: a thread RNG) */
         if (g == 2) {
             beta = iop_random_ext(&io); /* the accumulators' mix */
             gseed ^= ((uint64_t)beta.c[0] << 32) | beta.c[1];
@@ -262,18 +270,18 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             for (uint32_t c = 0; c < G->width; c++)
                 for (size_t r = 0; r < n; r++)
                     w[(size_t)c * n + r] = c == 0 ? (r == 0 ? bxo_fp_encode(1) : 0)
-                                           : c == 1 ? (r == n - 1 ? bxo_fp_encode(1) : 0)
+                                           : c == 1 ? (r == cc.act - 1 ? bxo_fp_encode(1) : 0) /* last ACTIVE row */
                                                     : synth_word(gseed, c, (uint32_t)r);
         } else if (g == 1) {
-            /* free columns */
+            /* free columns; the last zk rows of every one of them (the permuted copies included) are ZK noise */
             for (uint32_t c = 0; c < cc.F; c++)
-                for (size_t r = 0; r < n; r++) w[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
+                for (size_t r = 0; r < n; r++) w[(size_t)c * n + r] = synth_word(r < cc.act ? gseed : nseed, c, (uint32_t)r);
             /* permuted copies, placed with the oracle's scatter (one entry per cycle) */
             for (uint32_t p = 0; p < cc.pairs; p++) {
                 uint32_t* index = (uint32_t*)malloc((n + 1) * 4);
                 uint32_t* offsets = (uint32_t*)malloc(n * 4);
-                for (size_t r = 0; r <= n; r++) index[r] = (uint32_t)r;
-                for (size_t r = 0; r < n; r++) offsets[r] = (uint32_t)((size_t)(4 * p + 3) * n + perm_row(&cc, p, r));
+                for (size_t r = 0; r <= n; r++) index[r] = (uint32_t)(r < cc.act ? r : cc.act); /* noise cycles scatter nothing */
+                for (size_t r = 0; r < n; r++) offsets[r] = r < cc.act ? (uint32_t)((size_t)(4 * p + 3) * n + perm_row(&cc, p, r)) : 0;
                 bxo_scatter(w, index, offsets, w + (size_t)(4 * p + 2) * n, n);
                 free(index);
                 free(offsets);
@@ -366,7 +374,7 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
         if (g == 1) {
             n_globals = cc.wc >= 2 ? 2 : 1;
             globals[0] = data_w[0];                                        /* data[0][0] */
-            globals[1] = data_w[(size_t)(cc.wd - 1) * n + (n - 1)];          /* data[wd-1][N-1] */
+            globals[1] = data_w[(size_t)(cc.wd - 1) * n + (cc.act - 1)];     /* data[wd-1][last active row] */
             uint32_t dg[8];
             iop_write(&io, globals, n_globals);
             bxo_hash_elem_slice(dg, globals, n_globals, 1);

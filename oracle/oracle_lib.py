@@ -73,6 +73,7 @@ def lib(path=None):
         "bxo_scatter": ([u32p, u32p, u32p, u32p, sz], None),
         "bxo_prove_segment": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_prove_segment_ex": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
+        "bxo_prove_segment_zk": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
         "bxo_free": ([C.c_void_p], None),
         "bxo_compute_image_id": ([C.c_char_p, sz, C.c_char_p, u32p], C.c_int),
@@ -113,13 +114,16 @@ def random_elems(rng, shape):
     return rng.integers(0, P, size=shape, dtype=np.uint32)
 
 
-def prove_segment(po2, w_code, w_data, w_accum, seed, L=None, terms=0, degree=0):
+def prove_segment(po2, w_code, w_data, w_accum, seed, L=None, terms=0, degree=0, noise_seed=None):
     """Run the oracle's segment prover; returns (seal as uint32 array, roots[4][8]).  terms/degree = the synthetic
-    circuit's knobs (0 = defaults)."""
+    circuit's knobs (0 = defaults); noise_seed = the ZK rows' generator (None = derived from seed)."""
     L = L or lib()
     n = C.c_size_t(0)
     roots = np.zeros(32, np.uint32)
-    ptr = L.bxo_prove_segment_ex(po2, w_code, w_data, w_accum, terms, degree, seed, C.byref(n), roots)
+    if noise_seed is None:
+        ptr = L.bxo_prove_segment_ex(po2, w_code, w_data, w_accum, terms, degree, seed, C.byref(n), roots)
+    else:
+        ptr = L.bxo_prove_segment_zk(po2, w_code, w_data, w_accum, terms, degree, seed, noise_seed, C.byref(n), roots)
     if not ptr:
         raise RuntimeError("oracle prover: DEEP remainder non-zero")
     seal = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()

@@ -370,3 +370,24 @@ def test_three_provers_in_flight_on_one_gpu_stay_bit_exact():
     finally:
         for s in servers:
             s.close()
+
+
+def test_zk_noise_seed_through_the_abi_matches_the_oracle():
+    """bx_prove_segment_zk: the ZK rows' generator is an explicit argument (upstream's is a thread RNG, hence its unreproducible
+    seals).  Same pair -> the oracle's seal word for word; another noise seed -> another seal of the same statement."""
+    from boundless_amd.prover import HipProverServer, Segment
+
+    srv = HipProverServer(0, po2=12, widths=(4, 16, 8))
+    try:
+        for seed, noise in ((7, 1), (7, 2), (8, 0xFFFFFFFFFFFFFFFF)):
+            r = srv.prove_segment(Segment(index=0, po2=12, seed=seed, noise_seed=noise))
+            want, _ = ol.prove_segment(12, 4, 16, 8, seed, noise_seed=noise)
+            assert np.array_equal(r.seal, want), (seed, noise)
+            r.verify_integrity()
+        a = srv.prove_segment(Segment(index=0, po2=12, seed=7, noise_seed=1)).seal
+        b = srv.prove_segment(Segment(index=0, po2=12, seed=7, noise_seed=2)).seal
+        d = srv.prove_segment(Segment(index=0, po2=12, seed=7)).seal  # default: derived from the seed
+        assert not np.array_equal(a, b) and np.array_equal(a[:8], b[:8]) and np.array_equal(a[:8], d[:8])
+        assert np.array_equal(d, ol.prove_segment(12, 4, 16, 8, 7)[0])
+    finally:
+        srv.close()

@@ -112,8 +112,8 @@ def test_non_canonical_words_are_rejected():
 
 
 def test_the_public_words_are_bound_to_the_trace():
-    """The seal carries the statement's public words (the first cell of data column 0 and the last cell of the last data
-    column) and proves a trace that starts and ends there: claiming other values for the same proof is refused, and a prover
+    """The seal carries the statement's public words (the first cell of data column 0 and the last ACTIVE cell of the last data
+    column: the ZK noise rows come after it) and proves a trace that starts and ends there: claiming other values for the same proof is refused, and a prover
     that honestly proves a trace with another end cell gets another (valid) claim, not the old one."""
     L = ol.lib()
     widths = (4, 16, 8)
@@ -126,7 +126,7 @@ def test_the_public_words_are_bound_to_the_trace():
         with pytest.raises(HalError):
             verify_seal(bad)
     try:  # the witness changed in the very cell g_1 reports: the constraint that defines that derived cell now fails
-        L.bxo_set_witness_fault(1, widths[1] - 1, (1 << 10) - 1)
+        L.bxo_set_witness_fault(1, widths[1] - 1, (1 << 10) - (1 << 8) - 1)  # last active row: N - min(1994, N/4) - 1
         forged, _ = ol.prove_segment(10, *widths, 99)
     finally:
         L.bxo_set_witness_fault(-1, 0, 0)
@@ -199,3 +199,19 @@ def test_a_short_seal_claiming_huge_widths_is_refused_before_any_per_column_work
     with pytest.raises(HalError):
         verify_seal(bad)
     assert time.perf_counter() - t0 < 0.25
+
+
+def test_zk_noise_rows_are_seeded_and_change_nothing_the_verifier_checks():
+    """The last min(1994, N/4) rows of the free data columns are ZK noise drawn from their own seed (upstream: a thread RNG,
+    hence its run-to-run different seals).  Same (seed, noise seed) -> same seal; another noise seed -> another seal that
+    proves the same statement (same public words) and verifies; the default noise seed is a function of the seed."""
+    a, _ = ol.prove_segment(10, 4, 16, 8, 77, noise_seed=1)
+    b, _ = ol.prove_segment(10, 4, 16, 8, 77, noise_seed=1)
+    c, _ = ol.prove_segment(10, 4, 16, 8, 77, noise_seed=2)
+    d, _ = ol.prove_segment(10, 4, 16, 8, 77)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
+    for s in (a, c, d):
+        verify_seal(s)
+    assert np.array_equal(a[:8], c[:8]) and np.array_equal(a[:8], d[:8])  # header + public words: the statement
+    assert np.array_equal(a[8:8 + 256], c[8:8 + 256])  # the code group is public and not blinded: same top layer
+    assert not np.array_equal(a[8 + 256:8 + 512], c[8 + 256:8 + 512])  # the data commitment differs
