@@ -70,6 +70,12 @@ struct bx_ctx {
     uint32_t* h_stage = nullptr;
     static constexpr size_t STAGE_WORDS = (size_t)1 << 20;  // 4 MiB: every read-back of a proof (tops, taps, queries) fits
 
+    // look-back scan state (scan.hip): two alternating buffers, each launch clears what the other one was last used with
+    uint32_t* d_scan[2] = {nullptr, nullptr};
+    size_t scan_cap = 0, scan_used[2] = {0, 0};
+    int scan_next = 0;
+    long scan_lookback = 1;  // poly_divide / prefix_products: single-pass decoupled look-back kernels (0 = the three-phase kernels)
+
     // scratch (grown on demand)
     uint32_t* d_scratch = nullptr;
     size_t scratch_words = 0;
@@ -103,6 +109,7 @@ struct bx_ctx {
     long wait_poll_us = 50;
     bool wait_poll = false;  // blocking requested but the device flag could not be set: sleep-poll an event instead
     hipEvent_t wait_ev = nullptr;
+    long eval_x4 = 1;                // batch_evaluate_any: 16-byte loads for whole 2^15-coefficient segments (0 = the dword kernel)
     long deep_bitrev = 1;            // segment prover: keep trace coefficients bit-reversed through the DEEP phase (read at bx_prover_create)
 
     // timing
@@ -202,6 +209,8 @@ constexpr uint32_t FLAG_SLOTS = 4u;
 void apply_wait_policy(bx_ctx* c);         // set the device's schedule flag from bx_ctx::wait_blocking
 hipError_t stream_wait(bx_ctx* c);           // wait for the ctx's stream under the ctx's wait policy (bx_ctx::wait_blocking)
 const char* sync_and_check_flag(bx_ctx* c);  // stream_wait + deferred device errors
+const char* poly_divide_lookback(bx_ctx* c, uint32_t* polys, size_t size, size_t count, const uint32_t* zs, uint32_t* rems, const uint32_t* which);  // scan.hip
+const char* prefix_products_lookback(bx_ctx* c, uint32_t* io, size_t n, size_t count);
 const char* ntt_init_tables(bx_ctx* c);
 void ntt_free_tables(bx_ctx* c);
 const char* poseidon2_upload_params(bx_ctx* c);

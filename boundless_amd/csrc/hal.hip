@@ -229,6 +229,8 @@ extern "C" const char* bx_free(bx_ctx* c) {
     ntt_free_tables(c);
     if (c->d_p2) (void)hipFree(c->d_p2);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    for (int b = 0; b < 2; ++b)
+        if (c->d_scan[b]) (void)hipFree(c->d_scan[b]);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -385,6 +387,10 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
+    } else if (!strcmp(name, "scan_lookback")) {
+        c->scan_lookback = value != 0;
+    } else if (!strcmp(name, "eval_x4")) {
+        c->eval_x4 = value != 0;
     } else if (!strcmp(name, "deep_bitrev")) {
         c->deep_bitrev = value != 0;
     } else if (!strcmp(name, "fold_quad")) {

@@ -201,6 +201,128 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
         st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(ld4(xpow), f4_pow(x0, ex)));
     }
 }
+// The same with 16-byte loads and per-evaluation tables, for whole segments (poly_size a multiple of 2^15, 16-byte aligned).
+// The dword kernel above rebuilds its power tables in every workgroup — ~20 dependent ext products and a dozen barriers before the
+// first coefficient is read, once per (evaluation, segment) — and was latency-bound at 2 TB/s.  Here eval_tables_kernel builds the
+// tables once per evaluation point; a workgroup of eval_partial_x4_kernel then only streams: a thread owns the four consecutive
+// positions 4t .. 4t+3 of each of the segment's 32 runs of 1024 (32 dwordx4 loads, 8 in flight), its own weight comes from one
+// 16-byte load, the 32 run weights are wave-uniform scalar loads, and the 256 partial sums meet through one cross-lane reduction
+// and one barrier.
+//   position j = seg * 2^15 + i * 1024 + 4 t + k   (i < 32, t < 256, k < 4)
+//   natural order:   exponent j             = seg 2^15 + 1024 i + 4 t + k          A = x,            B = x^4,          C = x^1024
+//   bit-reversed:    exponent bitrev_n(j)   = rev(seg) + 2^(n-15) rev5(i) + 2^(n-10) rev8(t) + 2^(n-2) rev2(k)
+//                                                                                 C = x^(2^(n-15)), B = C^32,         A = B^256
+// value = S[seg] * sum_t B^e(t) * sum_k A^e(k) * sum_i C^e(i) c[j]; the innermost sums run unreduced (LazyExtAcc).
+// Table of one evaluation (words): [0,1024) tw[t] = B^e(t) | [1024,1152) iw[i] = C^e(i), centred | [1152,1168) A^e(k), k < 4 |
+// [1168, 1168 + 4 segs) S[seg] = x^(seg 2^15) or x^rev(seg).  Already indexed by position: the main kernel never bit-reverses.
+constexpr uint32_t EVT_TW = 0, EVT_IW = 1024, EVT_KW = 1152, EVT_SW = 1168;
+__global__ __launch_bounds__(EV_T) void eval_tables_kernel(const uint32_t* __restrict__ xs, uint32_t* __restrict__ tables, uint32_t segs,
+                                                           uint32_t stride, int brev_log) {
+    __shared__ uint32_t pw[512 * 4];
+    const uint32_t e = blockIdx.x, tid = threadIdx.x;
+    uint32_t* T = tables + (size_t)e * stride;
+    const Fp4 x0 = ld4(xs + 4 * (size_t)e);
+    Fp4 A, B, Cc, G;  // G: base of the segment powers
+    if (brev_log) {
+        Cc = x0;
+        for (int i = 0; i < brev_log - 15; ++i) Cc = f4_mul(Cc, Cc);
+        B = Cc;
+        for (int i = 0; i < 5; ++i) B = f4_mul(B, B);
+        A = B;
+        for (int i = 0; i < 8; ++i) A = f4_mul(A, A);
+        G = x0;
+    } else {
+        A = x0;
+        B = f4_mul(f4_mul(x0, x0), f4_mul(x0, x0));
+        Cc = B;
+        for (int i = 0; i < 8; ++i) Cc = f4_mul(Cc, Cc);
+        G = Cc;
+        for (int i = 0; i < 5; ++i) G = f4_mul(G, G);  // x^(2^15)
+    }
+    // powers of `base` by doubling in LDS: pw[d + i] = base^d * pw[i]
+    const auto powers = [&](const Fp4& base, uint32_t count) {
+        __syncthreads();
+        if (tid == 0) {
+            st4(pw, f4_one());
+            st4(pw + 4, base);
+        }
+        __syncthreads();
+        for (uint32_t d = 2; d < count; d <<= 1) {
+            const Fp4 top = f4_mul(ld4(pw + 4 * (d - 1)), base);
+            for (uint32_t i = tid; i < d; i += EV_T) st4(pw + 4 * (d + i), f4_mul(top, ld4(pw + 4 * i)));
+            __syncthreads();
+        }
+    };
+    powers(B, EV_T);
+    st4(T + EVT_TW + 4 * tid, ld4(pw + 4 * (brev_log ? (__brev(tid) >> 24) : tid)));
+    powers(Cc, 32);
+    if (tid < 32) {
+        const Fp4 w = ld4(pw + 4 * (brev_log ? (__brev(tid) >> 27) : tid));
+        st4(T + EVT_IW + 4 * tid, Fp4{{(uint32_t)fp_centre_w(w.c[0]), (uint32_t)fp_centre_w(w.c[1]), (uint32_t)fp_centre_w(w.c[2]),
+                                       (uint32_t)fp_centre_w(w.c[3])}});
+    }
+    if (tid == 0) {
+        const Fp4 A2 = f4_mul(A, A), A3 = f4_mul(A2, A);
+        st4(T + EVT_KW, f4_one());
+        st4(T + EVT_KW + 4, brev_log ? A2 : A);  // k = 1, 2 carry exponents 1, 2 in natural order and rev2(k) = 2, 1 bit-reversed
+        st4(T + EVT_KW + 8, brev_log ? A : A2);
+        st4(T + EVT_KW + 12, A3);
+    }
+    uint32_t cnt = 2;
+    while (cnt < segs) cnt <<= 1;  // segs <= 512 (2^24 coefficients)
+    powers(G, cnt);
+    const int sbits = brev_log ? brev_log - 15 : 0;
+    for (uint32_t sgm = tid; sgm < segs; sgm += EV_T)
+        st4(T + EVT_SW + 4 * sgm, ld4(pw + 4 * (sbits ? (__brev(sgm) >> (32 - sbits)) : (brev_log ? 0u : sgm))));
+}
+__device__ __forceinline__ Fp4 f4_shfl_down(const Fp4& v, int d) {
+    return Fp4{{(uint32_t)__shfl_down((int)v.c[0], d), (uint32_t)__shfl_down((int)v.c[1], d), (uint32_t)__shfl_down((int)v.c[2], d),
+                (uint32_t)__shfl_down((int)v.c[3], d)}};
+}
+__global__ __launch_bounds__(EV_T) void eval_partial_x4_kernel(const uint32_t* __restrict__ coeffs, size_t poly_size,
+                                                               const uint32_t* __restrict__ which, const uint32_t* __restrict__ tables,
+                                                               uint32_t stride, uint32_t* __restrict__ partials, uint32_t segs) {
+    __shared__ uint32_t red[4 * 4];
+    const uint32_t e = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* T = tables + (size_t)e * stride;
+    const uint4* c4 = reinterpret_cast<const uint4*>(coeffs + (size_t)which[e] * poly_size + (size_t)seg * ((size_t)EV_T * EV_K)) + tid;
+    LazyExtAcc lz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lz[k].reset();
+    // software pipeline, fully unrolled (the accumulators' fold counters become compile-time): the next batch of EV_B loads is
+    // issued before the current one is consumed, so 8..16 x 16 bytes per lane are in flight at any time.  Left to itself the
+    // compiler emitted load / wait / use, one 16-byte load in flight per lane.
+    constexpr int EV_B = 8;
+    uint4 cur[EV_B], nxt[EV_B];
+#pragma unroll
+    for (int u = 0; u < EV_B; ++u) cur[u] = c4[(size_t)u * EV_T];
+#pragma unroll
+    for (int ib = 0; ib < 32; ib += EV_B) {
+        if (ib + EV_B < 32) {
+#pragma unroll
+            for (int u = 0; u < EV_B; ++u) nxt[u] = c4[(size_t)(ib + EV_B + u) * EV_T];
+        }
+#pragma unroll
+        for (int u = 0; u < EV_B; ++u) {
+            const W4 w = ldw4(T + EVT_IW + 4 * (ib + u));  // wave-uniform
+            lz[0].add_centred(w.c, fp_centre_w(cur[u].x)); lz[1].add_centred(w.c, fp_centre_w(cur[u].y));
+            lz[2].add_centred(w.c, fp_centre_w(cur[u].z)); lz[3].add_centred(w.c, fp_centre_w(cur[u].w));
+        }
+#pragma unroll
+        for (int u = 0; u < EV_B; ++u) cur[u] = nxt[u];
+    }
+    Fp4 inner = f4_add(f4_add(lz[0].finish(), f4_mul(ld4(T + EVT_KW + 4), lz[1].finish())),
+                       f4_add(f4_mul(ld4(T + EVT_KW + 8), lz[2].finish()), f4_mul(ld4(T + EVT_KW + 12), lz[3].finish())));
+    Fp4 acc = f4_mul(inner, ld4(T + EVT_TW + 4 * tid));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = f4_add(acc, f4_shfl_down(acc, d));
+    if ((tid & 63u) == 0) st4(red + 4 * (tid >> 6), acc);
+    __syncthreads();
+    if (tid == 0) {
+        const Fp4 tot = f4_add(f4_add(ld4(red), ld4(red + 4)), f4_add(ld4(red + 8), ld4(red + 12)));
+        st4(partials + 4 * ((size_t)e * segs + seg), f4_mul(tot, ld4(T + EVT_SW + 4 * seg)));
+    }
+}
 __global__ void eval_final_kernel(const uint32_t* __restrict__ partials, uint32_t segs, uint32_t* __restrict__ out,
                                   uint32_t evals) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,9 +646,22 @@ static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count
     size_t segs = (poly_size + seg_elems - 1) / seg_elems;
     BX_REQUIRE(c, evals <= 65535, "batch_evaluate_any: more than 65535 evaluations in one call");
     BX_TRY(ensure_scratch(c, 4 * evals * segs));
-    hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
-                       (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)xs.dptr,
-                       c->d_scratch, (uint32_t)segs, brev_log);
+    if (c->eval_x4 && poly_size % seg_elems == 0 && ((uintptr_t)coeffs.dptr & 15u) == 0 && segs <= 512) {
+        const uint32_t stride = EVT_SW + 4 * (uint32_t)segs;  // a multiple of four words: every table entry stays 16-byte aligned
+        const size_t part_words = (4 * evals * segs + 3) & ~(size_t)3;
+        BX_TRY(ensure_scratch(c, part_words + (size_t)stride * evals));
+        uint32_t* tables = c->d_scratch + part_words;
+        hipLaunchKernelGGL(eval_tables_kernel, dim3((unsigned)evals), dim3(EV_T), 0, c->stream, (const uint32_t*)xs.dptr, tables, (uint32_t)segs,
+                           stride, brev_log);
+        BX_LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(eval_partial_x4_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
+                           (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)tables, stride, c->d_scratch,
+                           (uint32_t)segs);
+    } else {
+        hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
+                           (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)xs.dptr,
+                           c->d_scratch, (uint32_t)segs, brev_log);
+    }
     BX_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(eval_final_kernel, dim3((unsigned)((evals + 63) / 64)), dim3(64), 0, c->stream, c->d_scratch,
                        (uint32_t)segs, (uint32_t*)out.dptr, (uint32_t)evals);
@@ -636,6 +771,8 @@ extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4
     size_t size = poly.len / 4;
     if (!size) return nullptr;
     OpScope op(c, "poly_divide", 8.0 * (double)poly.len);
+    if (c->scan_lookback && ((uintptr_t)poly.dptr & 15u) == 0 && ((uintptr_t)rem_out.dptr & 15u) == 0)
+        return poly_divide_lookback(c, (uint32_t*)poly.dptr, size, 1, z, (uint32_t*)rem_out.dptr, nullptr);
     BX_TRY(ensure_scratch(c, scan_scratch_words(size, DIV_L, DIV_DIRECT, 1)));
     return divide_rec(c, (uint32_t*)poly.dptr, size, host4(z), c->d_scratch, (uint32_t*)rem_out.dptr);
 }
@@ -668,6 +805,7 @@ extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t cou
     size_t n = io.len / 4 / count;
     if (n < 2) return nullptr;
     OpScope op(c, "prefix_products", 8.0 * (double)io.len);
+    if (c->scan_lookback && ((uintptr_t)io.dptr & 15u) == 0) return prefix_products_lookback(c, (uint32_t*)io.dptr, n, count);
     // chunk products -> exclusive scan of them (recursively, PP_L per level) -> inclusive replay of every chunk with its carry
     size_t chunks = (n + PP_L - 1) / PP_L;
     BX_TRY(ensure_scratch(c, 4 * chunks * count + scan_scratch_words(chunks, PP_L, PP_DIRECT, count)));

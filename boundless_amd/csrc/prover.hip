@@ -527,11 +527,26 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
                                (uint32_t*)p->combos.b.dptr, (uint32_t)(4 * N), sl, (uint32_t)n_combos);
             if (hipGetLastError() != hipSuccess) return perr(p, "bx_prove_segment: sub_low launch failed");
         }
+        // divide every combo by each of its tap points: round r divides, in one launch, every combo that has a tap r (the check
+        // combo's single point joins round 0) — max-taps launches per proof instead of one five-launch call per division
         size_t d = 0;
-        for (size_t id = 0; id < n_trace_combos; ++id)
-            for (size_t t = 0; t < pts[id].size(); ++t, ++d)
-                PV(bx_poly_divide(c, p->combos.slice(4 * N * id, 4 * N), pts[id][t].c, p->rems.slice(4 * d, 4)));
-        PV(bx_poly_divide(c, p->combos.slice(4 * N * n_trace_combos, 4 * N), Z4.c, p->rems.slice(4 * d, 4)));
+        for (size_t r = 0;; ++r) {
+            uint32_t which[BX_MAX_COMBOS];
+            uint32_t zs[4 * BX_MAX_COMBOS];
+            size_t cnt = 0;
+            for (size_t id = 0; id < n_trace_combos; ++id)
+                if (pts[id].size() > r) {
+                    which[cnt] = (uint32_t)id;
+                    memcpy(zs + 4 * cnt++, pts[id][r].c, 16);
+                }
+            if (r == 0) {
+                which[cnt] = (uint32_t)n_trace_combos;
+                memcpy(zs + 4 * cnt++, Z4.c, 16);
+            }
+            if (!cnt) break;
+            PV(bx_poly_divide_batch_indexed(c, p->combos.b, n_combos, cnt, which, zs, p->rems.slice(4 * d, 4 * cnt)));
+            d += cnt;
+        }
         std::vector<uint32_t> rems(4 * p->n_div);
         PV(bx_d2h(c, rems.data(), p->rems.b, rems.size()));
         for (uint32_t r : rems)

@@ -90,6 +90,7 @@ def load_library():
         "bx_gather_sample": [ctx, BxBuf, BxBuf, sz, sz, sz],
         "bx_poly_divide": [ctx, BxBuf, u32p, BxBuf],
         "bx_eltwise_mul_factor": [ctx, BxBuf, C.c_uint32],
+        "bx_poly_divide_batch": [ctx, BxBuf, sz, u32p, BxBuf],
         "bx_prefix_products": [ctx, BxBuf],
         "bx_batch_prefix_products": [ctx, BxBuf, sz],
         "bx_scatter": [ctx, BxBuf, BxBuf, BxBuf, BxBuf],
@@ -314,6 +315,11 @@ class HipHal:
     def poly_divide(self, poly, z, rem_out):
         _, zz = _words(z)
         self._check(self.lib.bx_poly_divide(self.ctx, poly.raw, zz, rem_out.raw))
+
+    def poly_divide_batch(self, polys, count, zs, rems_out):
+        """Extension: `count` polynomials back to back, each divided by its own point, in one launch."""
+        _, zz = _words(zs)
+        self._check(self.lib.bx_poly_divide_batch(self.ctx, polys.raw, count, zz, rems_out.raw))
 
     def prefix_products(self, io):
         self._check(self.lib.bx_prefix_products(self.ctx, io.raw))

@@ -150,6 +150,15 @@ const char* bx_scatter(bx_ctx* ctx, bx_buf into, bx_buf index_u32, bx_buf offset
  * natural-order AoS ext polynomial by (x - z); the remainder (4 words) is written to rem_out_dev. */
 const char* bx_poly_divide(bx_ctx* ctx, bx_buf poly_ext, const uint32_t z[4], bx_buf rem_out_dev);
 
+/* Extension: `count` AoS ext polynomials back to back, polynomial q divided in place by (x - zs[q]) (zs: 4 host words per
+ * polynomial), all in one launch; rem_out_dev receives 4 words per polynomial.  The prover divides every DEEP combination
+ * polynomial by its next tap point with one call per round instead of one call per division. */
+const char* bx_poly_divide_batch(bx_ctx* ctx, bx_buf polys_ext, size_t count, const uint32_t* zs, bx_buf rem_out_dev);
+/* The same over a subset: the buffer holds n_polys polynomials, division q < count divides polynomial which[q] (host array, no
+ * repeats) by (x - zs[q]) and writes its remainder to rem_out_dev[4q..]. */
+const char* bx_poly_divide_batch_indexed(bx_ctx* ctx, bx_buf polys_ext, size_t n_polys, size_t count, const uint32_t* which, const uint32_t* zs,
+                                         bx_buf rem_out_dev);
+
 /* ---- measurement (HIP events on the ctx's stream) ---- */
 const char* bx_timer_start(bx_ctx* ctx);
 const char* bx_timer_stop(bx_ctx* ctx, float* ms_out); /* blocks */

@@ -637,3 +637,45 @@ def test_empty_and_null_inputs_return_errors_or_do_nothing(hal, oracle):
     oracle.bxo_batch_interpolate_ntt(want, 1, 64)
     hal.batch_interpolate_ntt(buf, 1)
     assert np.array_equal(buf.view(), want)
+
+
+@pytest.mark.parametrize("lookback", [1, 0])
+def test_scans_single_pass_and_three_phase_agree_with_the_oracle_across_tile_boundaries(hal, oracle, lookback):
+    """poly_divide / prefix_products: the look-back kernels (scan.hip) and the three-phase kernels, on sizes around the 2048-element
+    tile and the 64-tile look-back window (131072), back to back on one ctx so that every launch finds the state the previous
+    one left (two alternating buffers, cleared by the launch that does not use them)."""
+    hal.set_tunable("scan_lookback", lookback)
+    try:
+        for size in (1, 7, 2047, 2048, 2049, 4096, 10000, 131072, 131073, 300001, 1 << 20, 5, 70000):
+            poly = rnd(size, 4 * size)
+            z = rnd(size + 1, 4)
+            buf, rem = hal.copy_from(poly), hal.alloc(4)
+            hal.poly_divide(buf, z, rem)
+            ref, ref_rem = poly.copy(), np.zeros(4, np.uint32)
+            oracle.bxo_poly_divide(ref, size, c(z), ref_rem)
+            assert np.array_equal(buf.view(), ref) and np.array_equal(rem.view(), ref_rem), ("divide", size)
+            if size >= 2:
+                x = rnd(size + 2, 4 * size)
+                b2 = hal.copy_from(x)
+                hal.prefix_products(b2)
+                r2 = x.copy()
+                oracle.bxo_prefix_products(r2, size)
+                assert np.array_equal(b2.view(), r2), ("prefix", size)
+    finally:
+        hal.set_tunable("scan_lookback", 1)
+
+
+def test_poly_divide_batch_divides_every_polynomial_by_its_own_point(hal, oracle):
+    for size, count in ((5000, 3), (1 << 16, 9), (2048, 1), (100, 16)):
+        polys = rnd(size + count, 4 * size * count)
+        zs = rnd(count, 4 * count)
+        buf, rems = hal.copy_from(polys), hal.alloc(4 * count)
+        hal.poly_divide_batch(buf, count, zs, rems)
+        got, got_rems = buf.view().reshape(count, 4 * size), rems.view().reshape(count, 4)
+        for q in range(count):
+            ref, ref_rem = polys.reshape(count, 4 * size)[q].copy(), np.zeros(4, np.uint32)
+            oracle.bxo_poly_divide(ref, size, c(zs[4 * q:4 * q + 4]), ref_rem)
+            assert np.array_equal(got[q], ref) and np.array_equal(got_rems[q], ref_rem), (size, count, q)
+    # a quotient times (x - z) plus the remainder is the polynomial again: dividing (x - z) * q leaves remainder zero
+    with pytest.raises(Exception):
+        hal.poly_divide_batch(hal.alloc(4 * 10), 3, rnd(1, 12), hal.alloc(12))
