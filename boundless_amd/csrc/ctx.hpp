@@ -90,6 +90,8 @@ struct bx_ctx {
     long ntt_group_cols = 0;   // forward transform: columns per pass-A + pass-B group (0 = all columns per pass)
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
     long hash_rows_block = 256;
+    long fold_deep = 2;              // large Merkle layers: up to this many levels per launch, depth first per lane (1 = one launch per layer)
+    long fold_deep_min_lanes = 1 << 17;  // ... as long as the launch still has this many lanes (measured: tools/foldbench2.py, profiles/r03_foldbench.jsonl)
     long fold_quad = 1;              // small Merkle layers: four lanes per node (hash_fold_quad_kernel) instead of one
     long fold_quad_wg = 512;         // ... input digests per workgroup of that kernel (a power of two, 16..512)
     long fold_fuse_below = 1 << 17;  // Merkle layers with at most this many inputs are folded 9 levels per launch

@@ -393,6 +393,12 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         c->eval_x4 = value != 0;
     } else if (!strcmp(name, "deep_bitrev")) {
         c->deep_bitrev = value != 0;
+    } else if (!strcmp(name, "fold_deep")) {
+        BX_REQUIRE(c, value >= 1 && value <= 3, "fold_deep must be 1, 2 or 3");
+        c->fold_deep = value;
+    } else if (!strcmp(name, "fold_deep_min_lanes")) {
+        BX_REQUIRE(c, value >= 1, "fold_deep_min_lanes must be positive");
+        c->fold_deep_min_lanes = value;
     } else if (!strcmp(name, "fold_quad")) {
         BX_REQUIRE(c, value == 0 || value == 1, "fold_quad must be 0 or 1");
         c->fold_quad = value;

@@ -185,6 +185,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// Several levels of a LARGE layer in one launch, every lane busy: lane j folds the 2^L consecutive input digests
+// [2^L j, 2^L (j+1)) depth first — at most L digests are alive while the next pair is hashed — and writes every intermediate
+// node to its place in the tree.  2^L - 1 permutations per lane, so the lane efficiency is that of the per-layer kernel, but a
+// 2^22-leaf tree needs two launches down to the 2^17-node layer where the latency-bound kernel takes over instead of five, and
+// the intermediate layers are never read back.
+__device__ __forceinline__ void fold_pair(uint32_t* out8, const uint32_t* a8, const uint32_t* b8, const uint32_t* __restrict__ prm) {
+    uint32_t s[CELLS];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = a8[k], s[8 + k] = b8[k];
+#pragma unroll
+    for (int k = 16; k < CELLS; ++k) s[k] = 0u;
+    poseidon2_mix(s, prm);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out8[k] = s[k];
+}
+__device__ __forceinline__ void ld_digest(uint32_t* d, const uint32_t* p) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+__device__ __forceinline__ void st_digest(uint32_t* p, const uint32_t* d) {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+// node `idx` of the layer `lvl` levels above the input layer (lvl = 1: parents of inputs), computed depth first
+template <int LVL>
+__device__ __forceinline__ void fold_subtree(uint32_t* out8, uint32_t* __restrict__ io, const uint32_t* __restrict__ prm, size_t input_size, size_t idx) {
+    uint32_t a[8], b[8];
+    if constexpr (LVL == 1) {
+        ld_digest(a, io + (input_size + 2 * idx) * 8);
+        ld_digest(b, io + (input_size + 2 * idx + 1) * 8);
+    } else {
+        fold_subtree<LVL - 1>(a, io, prm, input_size, 2 * idx);
+        fold_subtree<LVL - 1>(b, io, prm, input_size, 2 * idx + 1);
+    }
+    fold_pair(out8, a, b, prm);
+    st_digest(io + ((input_size >> LVL) + idx) * 8, out8);
+}
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_deep_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ prm,
+                                                                                               uint32_t input_size) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (input_size >> L)) return;
+    uint32_t top[8];
+    fold_subtree<L>(top, io, prm, input_size, j);
+}
+
 // Small layers in one launch: a workgroup owns `per_wg` (<= 512) consecutive input digests and folds them `levels`
 // levels deep through LDS, writing every intermediate layer.  Used once a layer no longer fills the chip, where each
 // separate launch would cost a full single-wave permutation latency.
@@ -475,20 +521,11 @@ extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx
     return nullptr;
 }
 
-extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) {
-    if (!c) return "bx_merkle_build: null ctx";
-    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
-    BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
-    BX_HIP(c, hipSetDevice(c->device));
-    uint32_t* n = (uint32_t*)nodes.dptr;
-    {
-        OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
-        BX_TRY(launch_hash_rows(c, n + 8 * rows, (const uint32_t*)matrix.dptr, rows, matrix.len / rows));
-    }
-    OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
-    // Large layers: one full-utilisation launch per layer (lane = output node).  Once a layer no longer fills the chip
-    // (<= fold_fuse_below inputs) the remaining levels are latency-bound, so a workgroup folds 512 inputs nine levels
-    // deep through LDS in one launch.
+// every layer above the leaves nodes[rows .. 2 rows), down to the root nodes[1]
+static const char* merkle_fold_layers(bx_ctx* c, uint32_t* n, size_t rows) {
+    // Large layers: full-utilisation launches (lane = output node, or a lane folds 2^L inputs depth first).  Once a layer no
+    // longer fills the chip (<= fold_fuse_below inputs) the remaining levels are latency-bound, so a workgroup folds 512 inputs
+    // nine levels deep through LDS in one launch.
     size_t size = rows;
     const size_t fuse_below = (size_t)c->fold_fuse_below;
     while (size > 1) {
@@ -504,10 +541,41 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
                                    (uint32_t)size, (uint32_t)per_wg, levels);
             BX_LAUNCH_CHECK(c);
             size >>= levels;
+        } else if (c->fold_deep >= 3 && (size >> 3) >= (size_t)c->fold_deep_min_lanes && (size >> 3) >= fuse_below) {
+            // three levels per launch while that still leaves a lane per SIMD slot of the chip and lands above the fused kernel's range
+            hipLaunchKernelGGL(hash_fold_deep_kernel<3>, dim3((unsigned)(((size >> 3) + 255) / 256)), dim3(256), 0, c->stream, n, c->d_p2, (uint32_t)size);
+            BX_LAUNCH_CHECK(c);
+            size >>= 3;
+        } else if (c->fold_deep >= 2 && (size >> 2) >= (size_t)c->fold_deep_min_lanes && (size >> 2) >= fuse_below) {
+            hipLaunchKernelGGL(hash_fold_deep_kernel<2>, dim3((unsigned)(((size >> 2) + 255) / 256)), dim3(256), 0, c->stream, n, c->d_p2, (uint32_t)size);
+            BX_LAUNCH_CHECK(c);
+            size >>= 2;
         } else {
             BX_TRY(launch_hash_fold(c, n, size, size / 2));
             size >>= 1;
         }
     }
     return nullptr;
+}
+
+extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) {
+    if (!c) return "bx_merkle_build: null ctx";
+    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
+    BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
+    BX_HIP(c, hipSetDevice(c->device));
+    uint32_t* n = (uint32_t*)nodes.dptr;
+    {
+        OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
+        BX_TRY(launch_hash_rows(c, n + 8 * rows, (const uint32_t*)matrix.dptr, rows, matrix.len / rows));
+    }
+    OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
+    return merkle_fold_layers(c, n, rows);
+}
+// Extension: the fold half of bx_merkle_build alone — the leaves are already in nodes[rows .. 2 rows).
+extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) {
+    if (!c) return "bx_merkle_fold: null ctx";
+    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_fold: nodes must hold 2*rows digests, rows a power of two");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
+    return merkle_fold_layers(c, (uint32_t*)nodes.dptr, rows);
 }

@@ -77,6 +77,7 @@ def load_library():
         "bx_hash_rows": [ctx, BxBuf, BxBuf],
         "bx_hash_fold": [ctx, BxBuf, sz, sz],
         "bx_merkle_build": [ctx, BxBuf, BxBuf, sz],
+        "bx_merkle_fold": [ctx, BxBuf, sz],
         "bx_fri_fold": [ctx, BxBuf, BxBuf, u32p],
         "bx_mix_poly_coeffs": [ctx, BxBuf, u32p, u32p, BxBuf, BxBuf, sz, sz],
         "bx_batch_evaluate_any": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],

@@ -104,6 +104,8 @@ const char* bx_hash_fold(bx_ctx* ctx, bx_buf io_digests, size_t input_size, size
 /* MerkleTreeProver::new's loop in one call: nodes has 2*rows digests; hashes the rows of `matrix` into
  * nodes[rows..2rows) and folds every layer down to nodes[1]. */
 const char* bx_merkle_build(bx_ctx* ctx, bx_buf nodes_digests, bx_buf matrix, size_t rows);
+/* Extension: the fold half alone — the leaf digests are already in nodes[rows .. 2 rows). */
+const char* bx_merkle_fold(bx_ctx* ctx, bx_buf nodes_digests, size_t rows);
 
 /* ---- Hal FRI / DEEP family ---- */
 /* Hal::fri_fold(output, input, mix): SoA planes; input.len = 16*output.len. `mix` = 4 host words. */
