@@ -103,8 +103,9 @@ struct bx_ctx {
     //            device had at its creation): waits sleep on the completion interrupt, but the runtime's event thread then
     //            handles one interrupt per kernel: 0.52 CPUs busy, 0.021 CPU-s per proof (flag is per device and process; if
     //            the runtime refuses it, falls back to 2);
-    //   2 poll   record an event and hipEventQuery it every wait_poll_us (usleep in between): no interrupts, no spinning:
-    //            0.12 CPUs busy, 0.005 CPU-s per proof, same throughput (<= 50 us added per wait, hidden by the other lanes).
+    //   2 poll   record an event and hipEventQuery it every wait_poll_us (usleep in between; the waiting thread's timer slack is
+    //            lowered to 1 us so that the period is real): no interrupts, no spinning: 0.13 CPUs busy, 0.0055 CPU-s per
+    //            proof, 24.90 against 24.95 proofs/s busy-polling (a 20 us period doubles the CPU for +0.0).
     // With 3 lanes x 8 GPUs against the 16-CPU quota of a GPU box, spinning lanes would take CPUs from each other and from the
     // seal verifiers, so 2 is the default; BX_WAIT=spin|block|poll overrides it at bx_init.
     long wait_blocking = 2;
