@@ -12,12 +12,14 @@
  * Appendix A.
  *
  * PARITY STATUS
- *   - Poseidon2 permutation: PINNED to the published BabyBear t=24 known-answer test
- *     (input 0..23) — see tests/golden/poseidon2_kat.json and oracle/README.md.
- *     Round constants are *derived* (Poseidon Grain-LFSR generator), not typed in.
+ *   - Poseidon2 permutation, rate-16 overwrite sponge and pair hash: PINNED to a vector the reference holds —
+ *     compute_image_id(crates/povw/elfs/boundless-povw-log-updater.bin) == ...log-updater.iid, the reference's own test
+ *     (crates/povw/src/log_updater.rs:383-388), reproduced by bx_oracle_image.c (tests/test_image_id_cpu.py).  Also the
+ *     published BabyBear t=24 known-answer test (tests/golden/poseidon2_kat.json).  Round constants are *derived*
+ *     (Poseidon Grain-LFSR generator), not typed in.
  *   - Field constants / roots of unity: pinned numerically (tests/golden/babybear_consts.json).
- *   - NTT / FRI-fold / Merkle / seal bytes vs. the Rust CPU prover: PARITY UNPINNED — the
- *     reference holds no vectors for them and cannot be built here.
+ *   - NTT ordering / FRI-fold indexing / Merkle top-layer rule / transcript random_bits / seal bytes vs. the Rust CPU prover:
+ *     PARITY UNPINNED — the reference holds no vectors for them and cannot be built here.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
  * The product (boundless_amd/) never links, imports or calls it.
