@@ -198,6 +198,12 @@ def test_default_multi_rank_bench_path_static_split_is_bit_exact(tmp_path):
         for i in dumps[k]["indices"].tolist():
             want, _ = ol.prove_segment(po2, 4, 12, 4, Segment.synthetic(i, po2=po2).seed)
             assert np.array_equal(dumps[k][f"seal_{i}"], want), f"segment {i} proved by rank {k}"
+    # at N > 1 the same command also measures the other multi-GPU design: rank 0 hands the GPUs (here: two device slots on the one
+    # GPU) to a child `bench.py --native-agent`, the other ranks wait on the c10d store, the child's line rides along
+    na = out["native_agent"]
+    assert "error" not in na, na
+    assert na["n_gpus"] == 2 and na["config"]["segments_proved"] == max(2, steps // 2) * lanes * 2
+    assert sum(na["segments_per_device"].values()) == na["config"]["segments_proved"] and na["value"] > 0
 
 
 def test_rccl_rendezvous_barrier_and_all_reduce_of_the_multi_rank_path(tmp_path):
