@@ -69,6 +69,11 @@ struct bx_ctx {
     // copies up to this size land here at pinned-memory latency and are handed to the caller with one memcpy
     uint32_t* h_stage = nullptr;
     static constexpr size_t STAGE_WORDS = (size_t)1 << 20;  // 4 MiB: every read-back of a proof (tops, taps, queries) fits
+    // pinned ring for small host-to-device copies that must not cost a wait (the prover's tap points and query positions): the data
+    // is copied into the ring and the async copy reads it from there, so the caller's buffer is free at once
+    uint32_t* h_up = nullptr;
+    size_t up_used = 0;
+    static constexpr size_t UP_WORDS = (size_t)1 << 18;  // 1 MiB
 
     // look-back scan state (scan.hip): two alternating buffers, each launch clears what the other one was last used with
     uint32_t* d_scan[2] = {nullptr, nullptr};
@@ -212,6 +217,12 @@ constexpr uint32_t FLAG_SLOTS = 4u;
 void apply_wait_policy(bx_ctx* c);         // set the device's schedule flag from bx_ctx::wait_blocking
 hipError_t stream_wait(bx_ctx* c);           // wait for the ctx's stream under the ctx's wait policy (bx_ctx::wait_blocking)
 const char* sync_and_check_flag(bx_ctx* c);  // stream_wait + deferred device errors
+// h2d without a wait (words <= UP_WORDS): through the pinned ring; when the ring wraps, the stream is drained first
+const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words);
+// several device-to-host copies, ONE wait: d2h_batch_add enqueues a copy into the pinned landing area (bx_ctx::h_stage) and returns
+// where it will land; the data is there after d2h_batch_wait.  `used` starts at 0; nothing else may use bx_d2h in between.
+const char* d2h_batch_add(bx_ctx* c, size_t* used, bx_buf src, size_t words, const uint32_t** host);
+const char* d2h_batch_wait(bx_ctx* c);
 const char* poly_divide_lookback(bx_ctx* c, uint32_t* polys, size_t size, size_t count, const uint32_t* zs, uint32_t* rems, const uint32_t* which);  // scan.hip
 const char* prefix_products_lookback(bx_ctx* c, uint32_t* io, size_t n, size_t count);
 const char* ntt_init_tables(bx_ctx* c);

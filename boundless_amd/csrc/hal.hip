@@ -166,6 +166,10 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
         return "bx_init: allocating the deferred error flags failed";
     }
     for (uint32_t i = 0; i < FLAG_SLOTS; ++i) c->h_flag[i] = 0;
+    if (hipHostMalloc((void**)&c->h_up, bx_ctx::UP_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
+        bx_free(c);
+        return "bx_init: allocating the pinned upload ring failed";
+    }
     if (hipHostMalloc((void**)&c->h_stage, bx_ctx::STAGE_WORDS * 4, hipHostMallocDefault) != hipSuccess) {
         bx_free(c);
         return "bx_init: allocating the pinned read-back buffer failed";
@@ -216,6 +220,27 @@ void apply_wait_policy(bx_ctx* c) {
         c->wait_poll = c->wait_blocking == 1;
     }
 }
+const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
+    BX_REQUIRE(c, words <= dst.len && words <= bx_ctx::UP_WORDS, "h2d_staged: copy too large");
+    if (!words) return nullptr;
+    if (c->up_used + words > bx_ctx::UP_WORDS) {  // wrap: earlier copies may still be reading the ring
+        BX_HIP(c, stream_wait(c));
+        c->up_used = 0;
+    }
+    uint32_t* slot = c->h_up + c->up_used;
+    memcpy(slot, src, words * 4);
+    c->up_used += (words + 3) & ~(size_t)3;
+    BX_HIP(c, hipMemcpyAsync(dst.dptr, slot, words * 4, hipMemcpyHostToDevice, c->stream));
+    return nullptr;
+}
+const char* d2h_batch_add(bx_ctx* c, size_t* used, bx_buf src, size_t words, const uint32_t** host) {
+    BX_REQUIRE(c, words <= src.len && *used + words <= bx_ctx::STAGE_WORDS, "d2h_batch_add: the pinned landing area is full");
+    *host = c->h_stage + *used;
+    if (words) BX_HIP(c, hipMemcpyAsync(c->h_stage + *used, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
+    *used += (words + 3) & ~(size_t)3;
+    return nullptr;
+}
+const char* d2h_batch_wait(bx_ctx* c) { return sync_and_check_flag(c); }
 const char* sync_and_check_flag(bx_ctx* c) {
     BX_HIP(c, stream_wait(c));
     volatile uint32_t* f = c->h_flag;
@@ -241,6 +266,7 @@ extern "C" const char* bx_free(bx_ctx* c) {
         if (c->d_scan[b]) (void)hipFree(c->d_scan[b]);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_up) (void)hipHostFree(c->h_up);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);

@@ -140,17 +140,31 @@ const char* tree_init(bx_ctx* c, Tree& t, size_t rows, size_t cols) {
     return t.nodes.alloc(c, 16 * rows);
 }
 
-// MerkleTreeProver::new + commit
-const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
-    bx_ctx* c = p->c;
-    PV(bx_merkle_build(c, t.nodes.b, matrix, t.rows));
-    size_t top = t.top_size();
-    // the root nodes[1] and the top layer nodes[top..2*top) are the two ends of one contiguous run: one copy
-    std::vector<uint32_t> host(8 * (2 * top - 1));
-    PV(bx_d2h(c, host.data(), t.nodes.slice(8, host.size()), host.size()));
-    memcpy(t.root, host.data(), 32);
-    T.write(host.data() + 8 * (top - 1), 8 * top);
+// MerkleTreeProver::new: leaves + every layer, enqueued; nothing is read back
+const char* tree_build(bx_prover* p, Tree& t, bx_buf matrix) {
+    PV(bx_merkle_build(p->c, t.nodes.b, matrix, t.rows));
+    return nullptr;
+}
+// the root nodes[1] and the top layer nodes[top..2*top) are the two ends of one contiguous run: one copy per tree
+const char* tree_fetch(bx_prover* p, Tree& t, size_t* used, const uint32_t** host) {
+    PV(d2h_batch_add(p->c, used, t.nodes.slice(8, 8 * (2 * t.top_size() - 1)), 8 * (2 * t.top_size() - 1), host));
+    return nullptr;
+}
+// MerkleTreeProver::commit from the fetched run: the top layer goes to the seal, the root into the transcript
+void tree_absorb(Tree& t, const uint32_t* host, Transcript& T) {
+    const size_t top = t.top_size();
+    memcpy(t.root, host, 32);
+    T.write(host + 8 * (top - 1), 8 * top);
     T.commit(t.root);
+}
+// build + one round trip + commit (the commits whose root the next stage's challenge needs at once)
+const char* tree_commit(bx_prover* p, Tree& t, bx_buf matrix, Transcript& T) {
+    PV(tree_build(p, t, matrix));
+    size_t used = 0;
+    const uint32_t* host = nullptr;
+    PV(tree_fetch(p, t, &used, &host));
+    PV(d2h_batch_wait(p->c));
+    tree_absorb(t, host, T);
     return nullptr;
 }
 
@@ -166,8 +180,8 @@ __global__ void sub_low_kernel(uint32_t* __restrict__ combos, uint32_t combo_wor
     }
 }
 
-// Prover::commit_group: interpolate -> zk_shift -> PolyGroup::new (expand+evaluate, bit_reverse, Merkle) -> commit
-const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
+// Prover::commit_group, device half: interpolate -> zk_shift -> PolyGroup::new (expand+evaluate, bit_reverse, Merkle); no read-back
+const char* commit_group_work(bx_prover* p, Group& g) {
     bx_ctx* c = p->c;
     PV(bx_batch_interpolate_zk(c, g.coeffs.b, g.width));  // = batch_interpolate_ntt + zk_shift
     PV(bx_batch_expand_into_evaluate_ntt(c, g.evaluated.b, g.coeffs.b, g.width, 2));
@@ -176,7 +190,16 @@ const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
     // element-wise and therefore order-agnostic, and only the two combination polynomials are bit-reversed afterwards —
     // 32 words per row moved instead of 336.
     if (!p->coeffs_bitrev) PV(bx_batch_bit_reverse(c, g.coeffs.b, g.width));
-    return tree_commit(p, g.tree, g.evaluated.b, T);
+    return tree_build(p, g.tree, g.evaluated.b);
+}
+const char* commit_group(bx_prover* p, Group& g, Transcript& T) {
+    PV(commit_group_work(p, g));
+    size_t used = 0;
+    const uint32_t* host = nullptr;
+    PV(tree_fetch(p, g.tree, &used, &host));
+    PV(d2h_batch_wait(p->c));
+    tree_absorb(g.tree, host, T);
+    return nullptr;
 }
 
 Fp4 host_pow(Fp4 a, uint64_t e) { return f4_pow(a, e); }
@@ -379,17 +402,34 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
         p->h2.hash_elems(dg, globals, p->n_globals);
         T.commit(dg);
     }
-    for (int g = 0; g < 3; ++g) {
-        Group& G = p->groups[g];
-        static const char* const commit_names[3] = {"bx:commit_code", "bx:commit_data", "bx:commit_accum"};
-        if (g == 2) {
-            beta = T.random_ext();
+    {   // code and data: neither commit needs anything from the transcript, so both are enqueued and ONE round trip brings back both
+        // roots and top layers; the transcript absorbs them in order (code, then data) and only then is beta drawn
+        size_t used = 0;
+        const uint32_t* host[2] = {nullptr, nullptr};
+        {
+            TraceRange tr(c, "bx:commit_code");
+            PV(commit_group_work(p, p->groups[0]));
+        }
+        TraceRange tr(c, "bx:commit_data");
+        PV(commit_group_work(p, p->groups[1]));
+        PV(tree_fetch(p, p->groups[0].tree, &used, &host[0]));
+        PV(tree_fetch(p, p->groups[1].tree, &used, &host[1]));
+        PV(d2h_batch_wait(c));
+        for (int g = 0; g < 2; ++g) {
+            tree_absorb(p->groups[g].tree, host[g], T);
+            memcpy(p->last_roots + 8 * g, p->groups[g].tree.root, 32);
+        }
+    }
+    {
+        Group& G = p->groups[2];
+        beta = T.random_ext();
+        {
             TraceRange tr(c, "bx:accumulate");
             PV(circ->accumulate(circ->user, p->circ_state, c, G.coeffs.b, beta.c, seed));  // CircuitHal::accumulate
         }
-        TraceRange tr(c, commit_names[g]);
+        TraceRange tr(c, "bx:commit_accum");
         PV(commit_group(p, G, T));
-        memcpy(p->last_roots + 8 * g, G.tree.root, 32);
+        memcpy(p->last_roots + 16, G.tree.root, 32);
     }
     // ---- eval_check: the constraint polynomial over the 4N domain, divided by the vanishing polynomial ----
     Group& CK = p->groups[3];
@@ -456,7 +496,7 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
                 }
         }
         const size_t ne_all = p->tap_which.size();
-        PV(bx_h2d(c, p->xs.slice(0, 4 * ne_all), xs.data(), 4 * ne_all));
+        PV(h2d_staged(c, p->xs.slice(0, 4 * ne_all), xs.data(), 4 * ne_all));  // no wait: the evaluations' read-back below is the round trip
         for (int g = 0; g < 4; ++g) {
             Group& G = p->groups[g];
             const size_t o = p->tap_first[g], ne = p->tap_first[g + 1] - p->tap_first[g];
@@ -547,10 +587,8 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
             PV(bx_poly_divide_batch_indexed(c, p->combos.b, n_combos, cnt, which, zs, p->rems.slice(4 * d, 4 * cnt)));
             d += cnt;
         }
-        std::vector<uint32_t> rems(4 * p->n_div);
-        PV(bx_d2h(c, rems.data(), p->rems.b, rems.size()));
-        for (uint32_t r : rems)
-            if (r != 0) return perr(p, "bx_prove_segment: DEEP quotient has a non-zero remainder");
+        // the remainders (all zero for a consistent proof) are looked at with the last read-back of the proof, not here: a
+        // non-zero one is an internal error, and waiting for it now would cost a round trip on every proof
     }
     PV(bx_eltwise_sum_extelem(c, p->final_poly.b, p->combos.b));
     PV(bx_batch_bit_reverse(c, p->final_poly.b, 4));
@@ -595,17 +633,31 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
             qw[t] = tr.query_words();
             off[t + 1] = off[t] + qw[t] * BX_QUERIES;
         }
-        PV(bx_h2d(c, p->positions.b, all_pos.data(), all_pos.size()));
+        PV(h2d_staged(c, p->positions.b, all_pos.data(), all_pos.size()));
         for (size_t t = 0; t < n_trees; ++t) {
             Tree& tr = t < 4 ? p->groups[t].tree : p->rounds[t - 4].tree;
             bx_buf matrix = t < 4 ? p->groups[t].evaluated.b : p->rounds[t - 4].evaluated.b;
             PV(bx_merkle_query_gather(c, p->qout.slice(off[t], qw[t] * BX_QUERIES), matrix, tr.nodes.b, tr.rows, tr.cols,
                                       p->positions.slice(t * BX_QUERIES, BX_QUERIES), BX_QUERIES, tr.top_size()));
         }
-        std::vector<uint32_t> host_all(off[n_trees]);
-        PV(bx_d2h(c, host_all.data(), p->qout.slice(0, off[n_trees]), off[n_trees]));
+        size_t used = 0;
+        const uint32_t *host_all = nullptr, *rems = nullptr;
+        std::vector<uint32_t> big;
+        if (off[n_trees] + 4 * p->n_div + 8 <= bx_ctx::STAGE_WORDS) {
+            PV(d2h_batch_add(c, &used, p->qout.slice(0, off[n_trees]), off[n_trees], &host_all));
+            PV(d2h_batch_add(c, &used, p->rems.b, 4 * p->n_div, &rems));
+            PV(d2h_batch_wait(c));
+        } else {  // seals of the largest shapes do not fit the pinned landing area: two plain copies
+            big.resize(off[n_trees] + 4 * p->n_div);
+            PV(bx_d2h(c, big.data(), p->qout.slice(0, off[n_trees]), off[n_trees]));
+            PV(bx_d2h(c, big.data() + off[n_trees], p->rems.b, 4 * p->n_div));
+            host_all = big.data();
+            rems = big.data() + off[n_trees];
+        }
+        for (size_t i = 0; i < 4 * p->n_div; ++i)
+            if (rems[i] != 0) return perr(p, "bx_prove_segment: DEEP quotient has a non-zero remainder");
         for (int q = 0; q < BX_QUERIES; ++q)
-            for (size_t t = 0; t < n_trees; ++t) T.write(host_all.data() + off[t] + (size_t)q * qw[t], qw[t]);
+            for (size_t t = 0; t < n_trees; ++t) T.write(host_all + off[t] + (size_t)q * qw[t], qw[t]);
     }
     stage.close();
     if (seal_words) *seal_words = T.seal.size();
