@@ -12,6 +12,8 @@
 // back to back, one 32-byte read-back at the end and no host round trip in between.
 #include <string.h>
 
+#include <algorithm>
+
 #include <vector>
 
 #include "ctx.hpp"
@@ -57,69 +59,125 @@ extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, si
     return nullptr;
 }
 
-static const char* image_root(bx_ctx* c, const bx_image* im, uint32_t root_out[8]) {
-    const size_t n = im->pages.size(), n1 = n + 1;  // + the zero page, always the last entry of every level
-    // per level: which two entries of the level below feed each surviving parent — (right, left) as DigestPair::digest
-    // puts the right child first — and the all-zero parent last
-    std::vector<uint32_t> idx;
-    idx.reserve(n);
-    for (auto& kv : im->pages) idx.push_back(kv.first);
-    std::vector<uint32_t> sel;
-    std::vector<size_t> level_off, level_cnt;
-    {
-        std::vector<uint32_t> cur = idx, nxt;
-        for (int d = 0; d < BX_MERKLE_DEPTH; ++d) {
-            const uint32_t zero = (uint32_t)cur.size();
-            level_off.push_back(sel.size());
-            nxt.clear();
-            for (size_t i = 0; i < cur.size();) {
-                uint32_t lhs = zero, rhs = zero;
-                const uint32_t parent = cur[i] >> 1;
-                if ((cur[i] & 1u) == 0) {
-                    lhs = (uint32_t)i;
-                    if (i + 1 < cur.size() && cur[i + 1] == cur[i] + 1) rhs = (uint32_t)++i;
-                } else {
-                    rhs = (uint32_t)i;
-                }
-                ++i;
-                sel.push_back(rhs), sel.push_back(lhs);
-                nxt.push_back(parent);
-            }
-            sel.push_back(zero), sel.push_back(zero);
-            level_cnt.push_back(nxt.size() + 1);
-            cur.swap(nxt);
+// Digest of node `top` (canonical words) from the pages and the given digests below it.  Every digest lives in one device pool:
+// [0, n) page digests | [n] the zero page | per level its parents then its zero subtree | the given digests; a level's fold reads
+// any earlier entry of the pool through absolute indices, so given digests enter at whatever level they belong to.
+static const char* image_node(bx_ctx* c, const bx_image* im, uint32_t top, uint32_t out[8]) {
+    int top_level = 0;  // levels above the leaves
+    while ((top << top_level) < (1u << BX_MERKLE_DEPTH)) ++top_level;
+    BX_REQUIRE(c, top >= 1 && (top << top_level) < (2u << BX_MERKLE_DEPTH), "image: node index outside the tree");
+    const uint32_t leaf_lo = top << top_level, leaf_hi = leaf_lo + (1u << top_level);  // node indices of the leaves below `top`
+    // the given digests at or below `top`, by level (0 = leaves); one AT an ancestor of `top` would hide it
+    std::vector<std::vector<std::pair<uint32_t, const uint32_t*>>> given(top_level + 1);
+    size_t n_given = 0;
+    for (auto& kv : im->digests) {
+        int lvl = 0;
+        while ((kv.first << lvl) < (1u << BX_MERKLE_DEPTH)) ++lvl;
+        const uint32_t lo = kv.first << lvl;
+        if (lo >= leaf_lo && lo < leaf_hi && lvl <= top_level) {
+            given[lvl].push_back({kv.first, kv.second.data()});
+            ++n_given;
+        } else if (lvl > top_level && (kv.first << (lvl - top_level)) <= top && top < ((kv.first + 1) << (lvl - top_level))) {
+            return set_msg(c, "image: the node lies inside a subtree that is only given by its digest");
         }
     }
-    // device layout, one allocation: raw pages | cell matrix | digests A | digests B | sel
-    const size_t raw_w = n1 * BX_PAGE_WORDS, mat_w = n1 * 2 * BX_PAGE_WORDS, dig_w = n1 * 8;
+    std::vector<uint32_t> page_idx;
+    for (auto it = im->pages.lower_bound(leaf_lo - (1u << BX_MERKLE_DEPTH)); it != im->pages.end() && it->first + (1u << BX_MERKLE_DEPTH) < leaf_hi; ++it)
+        page_idx.push_back(it->first);
+    const size_t n = page_idx.size();
+    // pool positions: pages [0,n), zero page n; level outputs appended; given digests at the end
+    struct Node { uint32_t idx, pos; };
+    std::vector<Node> cur;
+    for (size_t i = 0; i < n; ++i) cur.push_back({page_idx[i] + (1u << BX_MERKLE_DEPTH), (uint32_t)i});
+    uint32_t zero_pos = (uint32_t)n, pool = (uint32_t)n + 1;
+    // given digests get their pool positions after all computed entries; count computed entries first (each level: parents + zero)
+    std::vector<uint32_t> sel;
+    std::vector<size_t> level_off, level_cnt, level_out;
+    std::vector<std::pair<uint32_t, const uint32_t*>> given_order;  // pool order of the given digests
+    // two passes are avoided by reserving the given digests' positions relative to an offset fixed afterwards
+    const uint32_t GIVEN = 0x80000000u;  // position = GIVEN | ordinal, rewritten below
+    auto merge_given = [&](int lvl, std::vector<Node>& nodes) -> const char* {
+        for (auto& g : given[lvl]) {
+            nodes.push_back({g.first, GIVEN | (uint32_t)given_order.size()});
+            given_order.push_back(g);
+        }
+        std::sort(nodes.begin(), nodes.end(), [](const Node& a, const Node& b) { return a.idx < b.idx; });
+        for (size_t i = 1; i < nodes.size(); ++i)
+            if (nodes[i].idx == nodes[i - 1].idx) return "image: a subtree is given both by its digest and by pages or digests inside it";
+        return nullptr;
+    };
+    if (const char* e = merge_given(0, cur)) return set_msg(c, e);
+    for (int d = 0; d < top_level; ++d) {
+        level_off.push_back(sel.size());
+        level_out.push_back(pool);
+        std::vector<Node> nxt;
+        for (size_t i = 0; i < cur.size();) {
+            uint32_t lhs = zero_pos, rhs = zero_pos;
+            const uint32_t parent = cur[i].idx >> 1;
+            if ((cur[i].idx & 1u) == 0) {
+                lhs = cur[i].pos;
+                if (i + 1 < cur.size() && cur[i + 1].idx == cur[i].idx + 1) rhs = cur[++i].pos;
+            } else {
+                rhs = cur[i].pos;
+            }
+            ++i;
+            sel.push_back(rhs), sel.push_back(lhs);  // DigestPair::digest puts the right child first
+            nxt.push_back({parent, pool++});
+        }
+        sel.push_back(zero_pos), sel.push_back(zero_pos);  // the level's all-zero subtree
+        zero_pos = pool++;
+        level_cnt.push_back(nxt.size() + 1);
+        if (const char* e = merge_given(d + 1, nxt)) return set_msg(c, e);
+        cur.swap(nxt);
+    }
+    BX_REQUIRE(c, given_order.size() == n_given, "image: internal error (given digests)");
+    const uint32_t given_base = pool;
+    for (auto& v : sel)
+        if (v & GIVEN) v = given_base + (v & ~GIVEN);
+    uint32_t result_pos = cur.empty() ? zero_pos : cur[0].pos;
+    if (result_pos & GIVEN) result_pos = given_base + (result_pos & ~GIVEN);
+    const size_t pool_digests = (size_t)given_base + n_given;
+    // device layout, one allocation: raw pages | cell matrix | digest pool | sel
+    const size_t n1 = n + 1, raw_w = n1 * BX_PAGE_WORDS, mat_w = n1 * 2 * BX_PAGE_WORDS, pool_w = pool_digests * 8;
     bx_buf all{nullptr, 0};
-    BX_TRY(bx_alloc(c, raw_w + mat_w + 2 * dig_w + sel.size(), &all));
+    BX_TRY(bx_alloc(c, raw_w + mat_w + pool_w + sel.size() + 4, &all));
     uint32_t* base = (uint32_t*)all.dptr;
-    bx_buf raw{base, raw_w}, mat{base + raw_w, mat_w}, da{base + raw_w + mat_w, dig_w}, db{base + raw_w + mat_w + dig_w, dig_w},
-        dsel{base + raw_w + mat_w + 2 * dig_w, sel.size()};
+    bx_buf raw{base, raw_w}, mat{base + raw_w, mat_w}, dpool{base + raw_w + mat_w, pool_w}, dsel{base + raw_w + mat_w + pool_w, sel.size()};
     const char* m = nullptr;
     do {
         std::vector<uint32_t> host(raw_w, 0u);
-        size_t k = 0;
-        for (auto& kv : im->pages) memcpy(host.data() + (k++) * BX_PAGE_WORDS, kv.second.data(), BX_PAGE_BYTES);
+        for (size_t k = 0; k < n; ++k) memcpy(host.data() + k * BX_PAGE_WORDS, im->pages.at(page_idx[k]).data(), BX_PAGE_BYTES);
         if ((m = bx_h2d(c, raw, host.data(), raw_w))) break;
-        if ((m = bx_h2d(c, dsel, sel.data(), sel.size()))) break;
-        if ((m = bx_image_page_cells(c, mat, raw, n1))) break;
-        if ((m = bx_hash_rows(c, da, mat))) break;
-        bx_buf src = da, dst = db;
-        for (int d = 0; d < BX_MERKLE_DEPTH && !m; ++d) {
-            bx_buf s{(uint32_t*)dsel.dptr + level_off[d], 2 * level_cnt[d]};
-            m = bx_hash_fold_indexed(c, dst, src, s, level_cnt[d]);
-            bx_buf t = src;
-            src = dst, dst = t;
+        if (!sel.empty() && (m = bx_h2d(c, dsel, sel.data(), sel.size()))) break;
+        if (n_given) {
+            std::vector<uint32_t> g(8 * n_given);
+            for (size_t k = 0; k < n_given; ++k)
+                for (int w = 0; w < 8; ++w) g[8 * k + w] = fp_encode(given_order[k].second[w]);  // canonical -> Montgomery, as BabyBearElem::new
+            if ((m = bx_h2d(c, bx_buf{(uint32_t*)dpool.dptr + 8 * (size_t)given_base, 8 * n_given}, g.data(), g.size()))) break;
         }
+        if ((m = bx_image_page_cells(c, mat, raw, n1))) break;
+        if ((m = bx_hash_rows(c, bx_buf{dpool.dptr, 8 * n1}, mat))) break;
+        for (int d = 0; d < top_level && !m; ++d)
+            m = bx_hash_fold_indexed(c, bx_buf{(uint32_t*)dpool.dptr + 8 * level_out[d], 8 * level_cnt[d]}, dpool,
+                                     bx_buf{(uint32_t*)dsel.dptr + level_off[d], 2 * level_cnt[d]}, level_cnt[d]);
         if (m) break;
         uint32_t mont[8];
-        if ((m = bx_d2h(c, mont, src, 8))) break;  // entry 0: the root (the zero root when the image is empty)
-        for (int i = 0; i < 8; ++i) root_out[i] = fp_decode(mont[i]);
+        if ((m = bx_d2h(c, mont, bx_buf{(uint32_t*)dpool.dptr + 8 * (size_t)result_pos, 8}, 8))) break;
+        for (int i = 0; i < 8; ++i) out[i] = fp_decode(mont[i]);
     } while (0);
     const char* r = bx_release(c, all);
     return m ? m : r;
+}
+static const char* image_root(bx_ctx* c, const bx_image* im, uint32_t root_out[8]) { return image_node(c, im, 1u, root_out); }
+
+extern "C" const char* bx_image_node_digest(bx_ctx* c, const bx_image* im, uint32_t node_idx, uint32_t digest_canonical[8]) {
+    if (!c) return "bx_image_node_digest: null ctx";
+    BX_REQUIRE(c, im && digest_canonical, "image_node_digest: null argument");
+    try {
+        return image_node(c, im, node_idx, digest_canonical);
+    } catch (...) {
+        return set_msg(c, "image_node_digest: out of memory");
+    }
 }
 
 extern "C" const char* bx_image_root(bx_ctx* c, const bx_image* im, uint32_t root_canonical[8]) {

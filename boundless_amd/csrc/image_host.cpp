@@ -131,6 +131,21 @@ extern "C" const char* bx_image_new(bx_image** out) {
 }
 extern "C" void bx_image_free(bx_image* im) { delete im; }
 extern "C" size_t bx_image_page_count(const bx_image* im) { return im ? im->pages.size() : 0; }
+extern "C" size_t bx_image_digest_count(const bx_image* im) { return im ? im->digests.size() : 0; }
+extern "C" const char* bx_image_set_digest(bx_image* im, uint32_t node_idx, const uint32_t d[8]) {
+    if (!im || !d) return "bx_image_set_digest: null argument";
+    if (node_idx < 1 || node_idx >= (2u << BX_MERKLE_DEPTH)) return "bx_image_set_digest: node index outside the tree";
+    for (int k = 0; k < 8; ++k)
+        if (d[k] >= BX_P) return "bx_image_set_digest: digest words are canonical field elements (< P)";
+    try {
+        std::array<uint32_t, 8> a;
+        for (int k = 0; k < 8; ++k) a[k] = d[k];
+        im->digests[node_idx] = a;
+    } catch (...) {
+        return "bx_image_set_digest: out of memory";
+    }
+    return nullptr;
+}
 extern "C" size_t bx_image_page_indices(const bx_image* im, uint32_t* out, size_t cap) {
     if (!im) return 0;
     size_t k = 0;

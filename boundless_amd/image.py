@@ -30,6 +30,9 @@ def _lib():
             "bx_image_set_page": ([img, C.c_uint32, u32p], cp),
             "bx_image_get_page": ([img, C.c_uint32, u32p], cp),
             "bx_image_page_count": ([img], sz),
+            "bx_image_set_digest": ([img, C.c_uint32, u32p], cp),
+            "bx_image_digest_count": ([img], sz),
+            "bx_image_node_digest": ([ctx, img, C.c_uint32, u32p], cp),
             "bx_image_page_indices": ([img, u32p, sz], sz),
             "bx_image_free": ([img], None),
             "bx_image_root": ([ctx, img, u32p], cp),
@@ -108,6 +111,20 @@ class MemoryImage:
     def get_page(self, page_idx):
         out = np.zeros(PAGE_WORDS, np.uint32)
         _check(_lib().bx_image_get_page(self._h, int(page_idx), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def set_digest(self, node_idx, digest_canonical):
+        """Partial image: the digest (8 canonical words) of a subtree the segment does not touch; root = node 1, page p = node
+        2^22 + p."""
+        d = np.ascontiguousarray(digest_canonical, dtype=np.uint32)
+        if d.size != 8:
+            raise ValueError("a digest is 8 words")
+        _check(_lib().bx_image_set_digest(self._h, int(node_idx), d.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def node_digest(self, hal: HipHal, node_idx):
+        """Digest of any node (8 canonical words), computed on `hal`'s GPU from the pages and digests below it."""
+        out = np.zeros(8, np.uint32)
+        _check(_lib().bx_image_node_digest(hal.ctx, self._h, int(node_idx), out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
     def root(self, hal: HipHal):

@@ -48,6 +48,14 @@ const char* bx_image_from_program(bx_ctx* ctx, const uint8_t* blob, size_t len, 
 const char* bx_image_new(bx_image** out);
 const char* bx_image_set_page(bx_image* im, uint32_t page_idx, const uint32_t* words);
 const char* bx_image_get_page(const bx_image* im, uint32_t page_idx, uint32_t* words_out); /* zero page if absent */
+/* Partial images (the `partial_image` of a Segment: MemoryImage with `pages` for what the segment touches and `digests` for the
+ * subtrees it does not): the digest of node `node_idx` (root = 1, children of i = 2i and 2i+1, page p = node 2^22 + p), 8
+ * canonical words as they appear in risc0's Digest.  The subtree below that node must hold no page and no other digest;
+ * bx_image_root then folds pages and given digests together and fails if they overlap. */
+const char* bx_image_set_digest(bx_image* im, uint32_t node_idx, const uint32_t digest_canonical[8]);
+size_t bx_image_digest_count(const bx_image* im);
+/* Digest of any node of the tree (8 canonical words): how a full image is pruned into a partial one. Blocks. */
+const char* bx_image_node_digest(bx_ctx* ctx, const bx_image* im, uint32_t node_idx, uint32_t digest_canonical[8]);
 size_t bx_image_page_count(const bx_image* im);
 /* page indices in ascending order (cap entries at most); returns the count */
 size_t bx_image_page_indices(const bx_image* im, uint32_t* out, size_t cap);

@@ -131,3 +131,57 @@ def test_an_empty_image_and_a_dirtied_page(hal, oracle):
     page[7] ^= 0x10000
     im2.set_page(2050, page)
     assert np.array_equal(im2.root(hal), r0)
+
+
+def test_partial_images_pruned_subtrees_as_digests_give_the_same_root(hal):
+    """`Segment.partial_image`: the pages a segment touches plus the digests of the subtrees it does not.  Prune random subtrees
+    of the reference program's image into their digests (bx_image_node_digest), drop their pages, and the root — hence the image
+    ID the reference pins — must not change; a digest that overlaps pages, or a wrong digest, must not go unnoticed."""
+    from boundless_amd import image
+    from boundless_amd.hal import HalError
+
+    full = image.MemoryImage.from_program(blob())
+    root = full.root(hal)
+    assert image.system_state_digest(root, 0) == iid()
+    idx = [int(i) for i in full.page_indices()]
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        part = image.MemoryImage()
+        keep = set(rng.choice(idx, size=int(rng.integers(1, 40)), replace=False).tolist()) if trial else set()
+        # walk down from the root: a subtree without kept pages becomes one digest, the rest is descended into
+        stack, pruned = [1], 0
+        while stack:
+            node = stack.pop()
+            lvl = 22 - (node.bit_length() - 1)
+            lo, hi = (node << lvl) - (1 << 22), ((node + 1) << lvl) - (1 << 22)  # page range below the node
+            if not any(lo <= p < hi for p in keep):
+                if any(lo <= p < hi for p in idx) or rng.random() < 0.3:  # zero subtrees may be given or left implicit
+                    part.set_digest(node, full.node_digest(hal, node))
+                    pruned += 1
+                continue
+            if lvl == 0:
+                part.set_page(node - (1 << 22), full.get_page(node - (1 << 22)))
+            else:
+                stack += [2 * node, 2 * node + 1]
+        assert len(part) == len(keep) and pruned > 0
+        assert np.array_equal(part.root(hal), root), trial
+        assert part.image_id(hal) == iid()
+    # a page inside a subtree that is already given by its digest: refused
+    part.set_page(idx[0], full.get_page(idx[0]))
+    part.set_digest(2, full.node_digest(hal, 2))
+    part.set_digest(3, full.node_digest(hal, 3))
+    with pytest.raises(HalError, match="both by its digest"):
+        part.root(hal)
+    # a wrong digest changes the root (nothing is silently recomputed)
+    two = image.MemoryImage()
+    two.set_digest(2, full.node_digest(hal, 2))
+    d3 = full.node_digest(hal, 3)
+    two.set_digest(3, d3)
+    assert np.array_equal(two.root(hal), root)
+    d3[0] = (int(d3[0]) + 1) % ol.P
+    two.set_digest(3, d3)
+    assert not np.array_equal(two.root(hal), root)
+    with pytest.raises(HalError):
+        two.set_digest(3, np.full(8, ol.P, np.uint32))  # not a field element
+    with pytest.raises(HalError, match="only given by its digest"):
+        two.node_digest(hal, 7)  # inside node 3, which is only a digest here
