@@ -235,9 +235,10 @@ __global__ __launch_bounds__(EV_T) void eval_partial_kernel(const uint32_t* __re
 // [1168, 1168 + 4 segs) S[seg] = x^(seg 2^15) or x^rev(seg).  Already indexed by position: the main kernel never bit-reverses.
 constexpr uint32_t EVT_TW = 0, EVT_IW = 1024, EVT_KW = 1152, EVT_SW = 1168;
 __global__ __launch_bounds__(EV_T) void eval_tables_kernel(const uint32_t* __restrict__ xs, uint32_t* __restrict__ tables, uint32_t segs,
-                                                           uint32_t stride, int brev_log) {
+                                                           uint32_t stride, int brev_log_all, const uint32_t* __restrict__ flags, int brev_log_flagged) {
     __shared__ uint32_t pw[512 * 4];
     const uint32_t e = blockIdx.x, tid = threadIdx.x;
+    const int brev_log = flags ? ((flags[e] & 1u) ? brev_log_flagged : 0) : brev_log_all;  // per evaluation when several buffers share a launch
     uint32_t* T = tables + (size_t)e * stride;
     const Fp4 x0 = ld4(xs + 4 * (size_t)e);
     Fp4 A, B, Cc, G;  // G: base of the segment powers
@@ -299,11 +300,13 @@ __device__ __forceinline__ Fp4 f4_shfl_down(const Fp4& v, int d) {
 }
 __global__ __launch_bounds__(EV_T) void eval_partial_x4_kernel(const uint32_t* __restrict__ coeffs, size_t poly_size,
                                                                const uint32_t* __restrict__ which, const uint32_t* __restrict__ tables,
-                                                               uint32_t stride, uint32_t* __restrict__ partials, uint32_t segs) {
+                                                               uint32_t stride, uint32_t* __restrict__ partials, uint32_t segs,
+                                                               const unsigned long long* __restrict__ poly_ptrs) {
     __shared__ uint32_t red[4 * 4];
     const uint32_t e = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const uint32_t* T = tables + (size_t)e * stride;
-    const uint4* c4 = reinterpret_cast<const uint4*>(coeffs + (size_t)which[e] * poly_size + (size_t)seg * ((size_t)EV_T * EV_K)) + tid;
+    const uint32_t* poly = poly_ptrs ? reinterpret_cast<const uint32_t*>(poly_ptrs[e]) : coeffs + (size_t)which[e] * poly_size;
+    const uint4* c4 = reinterpret_cast<const uint4*>(poly + (size_t)seg * ((size_t)EV_T * EV_K)) + tid;
     LazyExtAcc lz[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lz[k].reset();
@@ -670,11 +673,11 @@ static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count
         BX_TRY(ensure_scratch(c, part_words + (size_t)stride * evals));
         uint32_t* tables = c->d_scratch + part_words;
         hipLaunchKernelGGL(eval_tables_kernel, dim3((unsigned)evals), dim3(EV_T), 0, c->stream, (const uint32_t*)xs.dptr, tables, (uint32_t)segs,
-                           stride, brev_log);
+                           stride, brev_log, (const uint32_t*)nullptr, 0);
         BX_LAUNCH_CHECK(c);
         hipLaunchKernelGGL(eval_partial_x4_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
                            (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)tables, stride, c->d_scratch,
-                           (uint32_t)segs);
+                           (uint32_t)segs, (const unsigned long long*)nullptr);
     } else {
         hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream,
                            (const uint32_t*)coeffs.dptr, poly_size, (const uint32_t*)which.dptr, (const uint32_t*)xs.dptr,
@@ -693,6 +696,34 @@ extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t po
 extern "C" const char* bx_batch_evaluate_any_bitrev(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
     if (!c) return "bx_batch_evaluate_any_bitrev: null ctx";
     return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, true, "batch_evaluate_any");
+}
+
+// Extension: the tap evaluations of several coefficient buffers in ONE launch set (the DEEP step evaluates columns of four
+// groups): evaluation i reads the poly_size coefficients at device address poly_ptrs[i] (bit-reversed storage when flags[i] & 1).
+extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_buf flags, size_t poly_size, bx_buf xs, bx_buf out) {
+    if (!c) return "bx_batch_evaluate_ptrs: null ctx";
+    const size_t evals = flags.len, seg_elems = (size_t)EV_T * EV_K;
+    BX_REQUIRE(c, poly_ptrs.len == 2 * evals && xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_ptrs: one pointer (two words), one flag, one point and one result per evaluation");
+    BX_REQUIRE(c, is_pow2(poly_size) && poly_size >= seg_elems && poly_size / seg_elems <= 512, "batch_evaluate_ptrs: polynomial size must be a power of two in [2^15, 2^24]");
+    BX_REQUIRE(c, evals <= 65535 && ((uintptr_t)poly_ptrs.dptr & 7u) == 0, "batch_evaluate_ptrs: at most 65535 evaluations, pointers 8-byte aligned");
+    BX_HIP(c, hipSetDevice(c->device));
+    OpScope op(c, "batch_evaluate_any", 4.0 * (double)(poly_size * evals));
+    if (!evals) return nullptr;
+    const size_t segs = poly_size / seg_elems;
+    const uint32_t stride = EVT_SW + 4 * (uint32_t)segs;
+    const size_t part_words = (4 * evals * segs + 3) & ~(size_t)3;
+    BX_TRY(ensure_scratch(c, part_words + (size_t)stride * evals));
+    uint32_t* tables = c->d_scratch + part_words;
+    hipLaunchKernelGGL(eval_tables_kernel, dim3((unsigned)evals), dim3(EV_T), 0, c->stream, (const uint32_t*)xs.dptr, tables, (uint32_t)segs, stride, 0,
+                       (const uint32_t*)flags.dptr, ilog2(poly_size));
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(eval_partial_x4_kernel, dim3((unsigned)segs, (unsigned)evals), dim3(EV_T), 0, c->stream, (const uint32_t*)nullptr, poly_size,
+                       (const uint32_t*)nullptr, (const uint32_t*)tables, stride, c->d_scratch, (uint32_t)segs, (const unsigned long long*)poly_ptrs.dptr);
+    BX_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(eval_final_kernel, dim3((unsigned)((evals + 63) / 64)), dim3(64), 0, c->stream, c->d_scratch, (uint32_t)segs, (uint32_t*)out.dptr,
+                       (uint32_t)evals);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
 }
 
 extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) {

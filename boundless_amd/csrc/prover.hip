@@ -105,6 +105,7 @@ struct bx_prover {
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
     DevBuf combos, final_poly, which, xs, evals, rems, positions, qout;
+    DevBuf tap_ptrs, tap_flags;  // per tap evaluation: the device address of its coefficient column and its storage order (N >= 2^15)
     std::vector<std::vector<uint32_t>> combo_backs;  // trace combos in order of first appearance; the check combo comes after them
     std::vector<uint32_t> tap_which;                 // polynomial index of every tap evaluation (fixed per shape)
     size_t tap_first[5] = {0, 0, 0, 0, 0};           // first tap evaluation of each group
@@ -304,6 +305,21 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     BX_TRY(p->evals.alloc(c, 4 * total_taps));
     BX_TRY(p->rems.alloc(c, 4 * p->n_div));
     BX_TRY(bx_h2d(c, p->which.slice(0, total_taps), p->tap_which.data(), total_taps));  // fixed per shape
+    if (N >= ((size_t)1 << 15)) {  // all four groups' taps in one launch set (bx_batch_evaluate_ptrs)
+        std::vector<uint32_t> ptrs(2 * total_taps), flags(total_taps);
+        size_t e = 0;
+        for (int g = 0; g < 4; ++g)
+            for (size_t t = p->tap_first[g]; t < p->tap_first[g + 1]; ++t, ++e) {
+                const unsigned long long a = (unsigned long long)(uintptr_t)((uint32_t*)p->groups[g].coeffs.b.dptr + (size_t)p->tap_which[t] * N);
+                ptrs[2 * e] = (uint32_t)a;
+                ptrs[2 * e + 1] = (uint32_t)(a >> 32);
+                flags[e] = (p->coeffs_bitrev && g < 3) ? 1u : 0u;
+            }
+        BX_TRY(p->tap_ptrs.alloc(c, 2 * total_taps));
+        BX_TRY(p->tap_flags.alloc(c, total_taps));
+        BX_TRY(bx_h2d(c, p->tap_ptrs.b, ptrs.data(), ptrs.size()));
+        BX_TRY(bx_h2d(c, p->tap_flags.b, flags.data(), flags.size()));
+    }
     // FRI rounds
     size_t size = N;
     size_t fri_query_words = 0;
@@ -497,13 +513,17 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
         }
         const size_t ne_all = p->tap_which.size();
         PV(h2d_staged(c, p->xs.slice(0, 4 * ne_all), xs.data(), 4 * ne_all));  // no wait: the evaluations' read-back below is the round trip
-        for (int g = 0; g < 4; ++g) {
-            Group& G = p->groups[g];
-            const size_t o = p->tap_first[g], ne = p->tap_first[g + 1] - p->tap_first[g];
-            if (p->coeffs_bitrev && g < 3)
-                PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
-            else
-                PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
+        if (p->tap_ptrs.b.dptr) {
+            PV(bx_batch_evaluate_ptrs(c, p->tap_ptrs.b, p->tap_flags.b, N, p->xs.slice(0, 4 * ne_all), p->evals.slice(0, 4 * ne_all)));
+        } else {
+            for (int g = 0; g < 4; ++g) {
+                Group& G = p->groups[g];
+                const size_t o = p->tap_first[g], ne = p->tap_first[g + 1] - p->tap_first[g];
+                if (p->coeffs_bitrev && g < 3)
+                    PV(bx_batch_evaluate_any_bitrev(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
+                else
+                    PV(bx_batch_evaluate_any(c, G.coeffs.b, G.width, p->which.slice(o, ne), p->xs.slice(4 * o, 4 * ne), p->evals.slice(4 * o, 4 * ne)));
+            }
         }
         std::vector<uint32_t> ev(4 * ne_all);
         PV(bx_d2h(c, ev.data(), p->evals.slice(0, 4 * ne_all), 4 * ne_all));

@@ -83,6 +83,7 @@ def load_library():
         "bx_batch_evaluate_any": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
         "bx_batch_evaluate_any_bitrev": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
         "bx_batch_bit_reverse_ext": [ctx, BxBuf, sz],
+        "bx_batch_evaluate_ptrs": [ctx, BxBuf, BxBuf, sz, BxBuf, BxBuf],
         "bx_batch_interpolate_zk": [ctx, BxBuf, sz],
         "bx_eltwise_add_elem": [ctx, BxBuf, BxBuf, BxBuf],
         "bx_eltwise_copy_elem": [ctx, BxBuf, BxBuf],
@@ -286,6 +287,11 @@ class HipHal:
     def batch_evaluate_any_bitrev(self, coeffs, poly_count, which, xs, out):
         """Extension: the same over bit-reversed coefficient storage (include/bx_hal.h)."""
         self._check(self.lib.bx_batch_evaluate_any_bitrev(self.ctx, coeffs.raw, poly_count, which.raw, xs.raw, out.raw))
+
+    def batch_evaluate_ptrs(self, poly_ptrs, flags, poly_size, xs, out):
+        """Extension: evaluations over several coefficient buffers in one launch set (poly_ptrs: one u64 device address per
+        evaluation as two u32 words; flags & 1 = bit-reversed storage)."""
+        self._check(self.lib.bx_batch_evaluate_ptrs(self.ctx, poly_ptrs.raw, flags.raw, poly_size, xs.raw, out.raw))
 
     def batch_interpolate_zk(self, io, count):
         """Extension: batch_interpolate_ntt + zk_shift in one call."""

@@ -125,6 +125,10 @@ const char* bx_batch_evaluate_any(bx_ctx* ctx, bx_buf coeffs, size_t poly_count,
 const char* bx_batch_evaluate_any_bitrev(bx_ctx* ctx, bx_buf coeffs_bitrev, size_t poly_count, bx_buf which_u32,
                                          bx_buf xs_ext, bx_buf out_ext);
 const char* bx_batch_bit_reverse_ext(bx_ctx* ctx, bx_buf io_ext, size_t count);
+/* Extension: evaluations over several coefficient buffers in one launch set: evaluation i evaluates, at xs[i], the polynomial of
+ * poly_size coefficients (a power of two in [2^15, 2^24]) at device address poly_ptrs[i] (a little-endian u64 in two words), stored
+ * bit-reversed when flags[i] & 1.  The prover's DEEP step evaluates the taps of all four groups with one call. */
+const char* bx_batch_evaluate_ptrs(bx_ctx* ctx, bx_buf poly_ptrs_u64, bx_buf flags_u32, size_t poly_size, bx_buf xs_ext, bx_buf out_ext);
 /* Extension: batch_interpolate_ntt(io, count) followed by zk_shift(io, count) as one call; on the register-radix path the
  * shift rides on the final store of the inverse transform.  Same result as the two calls. */
 const char* bx_batch_interpolate_zk(bx_ctx* ctx, bx_buf io, size_t count);

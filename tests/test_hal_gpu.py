@@ -679,3 +679,30 @@ def test_poly_divide_batch_divides_every_polynomial_by_its_own_point(hal, oracle
     # a quotient times (x - z) plus the remainder is the polynomial again: dividing (x - z) * q leaves remainder zero
     with pytest.raises(Exception):
         hal.poly_divide_batch(hal.alloc(4 * 10), 3, rnd(1, 12), hal.alloc(12))
+
+
+def test_batch_evaluate_ptrs_over_several_buffers_matches_per_buffer_calls(hal, oracle):
+    """The DEEP step's one-call form: evaluations over columns of several coefficient buffers, some stored bit-reversed."""
+    n, size = 15, 1 << 15
+    bufs = [rnd(40 + k, size * w) for k, w in enumerate((2, 3, 1))]
+    rev = _bitrev_perm(n)
+    dev, ptrs, flags, which_ref, xs = [], [], [], [], rnd(77, 4 * 9)
+    stored_bitrev = (True, False, True)
+    for k, b in enumerate(bufs):
+        cols = b.reshape(-1, size)
+        stored = cols[:, rev] if stored_bitrev[k] else cols  # position j holds the coefficient of x^rev(j)
+        dev.append(hal.copy_from(np.ascontiguousarray(stored).reshape(-1)))
+    for e in range(9):
+        k = e % 3
+        col = (e // 3) % (bufs[k].size // size)
+        addr = dev[k].raw.dptr + 4 * col * size
+        ptrs += [addr & 0xFFFFFFFF, addr >> 32]
+        flags.append(1 if stored_bitrev[k] else 0)
+        which_ref.append((k, col))
+    out = hal.alloc(4 * 9)
+    hal.batch_evaluate_ptrs(hal.copy_from(np.array(ptrs, np.uint32)), hal.copy_from(np.array(flags, np.uint32)), size, hal.copy_from(xs), out)
+    got = out.view().reshape(9, 4)
+    for e, (k, col) in enumerate(which_ref):
+        ref = np.zeros(4, np.uint32)
+        oracle.bxo_batch_evaluate_any(np.ascontiguousarray(bufs[k].reshape(-1, size)[col]), size, np.zeros(1, np.uint32), c(xs[4 * e:4 * e + 4]), ref, 1)
+        assert np.array_equal(got[e], ref), e
