@@ -526,37 +526,41 @@ def main():
         # hang there cannot take the primary line with it), the other ranks wait at the barrier.
         # The hand-over goes through the c10d store, not through a collective: an RCCL barrier would leave kernels spinning on
         # the other ranks' GPUs while the child measures on them.
-        import datetime
+        try:  # nothing in here may cost the primary line
+            import datetime
 
-        from torch.distributed import distributed_c10d
+            from torch.distributed import distributed_c10d
 
-        store = distributed_c10d._get_default_store()
-        torch.cuda.synchronize()
-        store.add("bx:released", 1)
-        if rank == 0:
-            import subprocess
+            store = distributed_c10d._get_default_store()
+            torch.cuda.synchronize()
+            store.add("bx:released", 1)
+            if rank == 0:
+                import subprocess
 
-            t_wait = time.time()
-            while int(store.add("bx:released", 0)) < world and time.time() - t_wait < 120:
-                time.sleep(0.05)
-            cmd = [sys.executable, os.path.abspath(__file__), "--native-agent", "--gpus", str(world), "--steps", str(max(2, args.steps // 2)),
-                   "--warmup", "1", "--po2", str(args.po2), "--widths", args.widths, "--inflight", str(args.inflight)]
-            if args.device is not None:
-                cmd += ["--device", str(args.device)]
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
-                                                                     "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
-            try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                out["native_agent"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-400:]}
-            except Exception as e:  # reported, never required for the primary number
+                t_wait = time.time()
+                while int(store.add("bx:released", 0)) < world and time.time() - t_wait < 120:
+                    time.sleep(0.05)
+                cmd = [sys.executable, os.path.abspath(__file__), "--native-agent", "--gpus", str(world), "--steps", str(max(2, args.steps // 2)),
+                       "--warmup", "1", "--po2", str(args.po2), "--widths", args.widths, "--inflight", str(args.inflight)]
+                if args.device is not None:
+                    cmd += ["--device", str(args.device)]
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                         "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    out["native_agent"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+                except Exception as e:  # reported, never required for the primary number
+                    out["native_agent"] = {"error": f"{type(e).__name__}: {e}"}
+                store.set("bx:native_done", "1")
+            else:
+                try:
+                    store.wait(["bx:native_done"], datetime.timedelta(seconds=420))
+                except Exception:  # rank 0 reports; a rank that gives up waiting just leaves
+                    pass
+        except Exception as e:
+            if rank == 0:
                 out["native_agent"] = {"error": f"{type(e).__name__}: {e}"}
-            store.set("bx:native_done", "1")
-        else:
-            try:
-                store.wait(["bx:native_done"], datetime.timedelta(seconds=420))
-            except Exception:  # rank 0 reports; a rank that gives up waiting just leaves
-                pass
     if rank == 0:
         if world == 1 and not args.no_agent_mode:
             # Untimed extra (never `value`): the same workload claimed through the native feed loop (bx_agent_poll_work:
