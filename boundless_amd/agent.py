@@ -88,6 +88,7 @@ def _lib():
         "bx_rest_client_create": ([cp, C.c_uint64, C.c_uint64, C.POINTER(vp)], cp), "bx_rest_client_destroy": ([vp], None),
         "bx_rest_taskdb_ops": ([vp], _TaskDbOps), "bx_rest_hot_store_ops": ([vp], _HotStoreOps),
         "bx_rest_client_requests": ([vp], C.c_uint64),
+        "bx_rest_client_connects": ([vp], C.c_uint64),
         "bx_agent_lane_count": ([vp], C.c_uint32), "bx_agent_lane_device": ([vp, C.c_uint32], C.c_int32),
         "bx_agent_lane_tasks_done": ([vp, C.c_uint32], C.c_uint64),
     }
@@ -235,6 +236,11 @@ class RestWorker:
     @property
     def requests(self):
         return self._lib.bx_rest_client_requests(self._h)
+
+    @property
+    def connects(self):
+        """TCP connections opened so far: connections are kept alive and pooled, so this stays near the number of lanes."""
+        return self._lib.bx_rest_client_connects(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,7 +1,7 @@
 // rest_worker.cpp — worker-side client of the next-generation Bento REST protocol, as the agent's callback tables
 // (include/bx_rest.h).  Restates prover/crates/workflow/src/assets.rs:88-420 (URLs, request/response shapes, status handling)
 // against the routes of prover/crates/api/src/lib.rs:922-1040.  Host code only: POSIX sockets, no third-party HTTP stack
-// (the image has no libcurl headers); one connection per call.
+// (the image has no libcurl headers); connections are kept alive and pooled, bodies are read once into their final buffer.
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <netinet/in.h>
@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,12 @@
 struct bx_rest_client {
     std::string host, port, prefix;  // prefix: path part of the base URL without a trailing '/'
     uint64_t claim_wait = 0, io_timeout = 30;
-    std::atomic<uint64_t> requests{0};
+    std::atomic<uint64_t> requests{0}, connects{0};
+    std::mutex mu;          // guards `idle`
+    std::vector<int> idle;  // kept-alive connections not in use
+    ~bx_rest_client() {
+        for (int fd : idle) close(fd);
+    }
 };
 
 namespace {
@@ -219,9 +225,36 @@ bool json_string_value(const std::string& raw, std::string* out) {
 // ---- one HTTP/1.1 exchange ----
 // a segment blob is ~80 MB (bento/crates/workflow/src/tasks/executor.rs:45); nothing this client fetches comes near the cap
 constexpr size_t MAX_RESPONSE_BYTES = (size_t)1 << 31;
+constexpr size_t MAX_HEADER_BYTES = (size_t)1 << 16;
+constexpr size_t MAX_IDLE_CONNECTIONS = 16;
+
+// Response body: one malloc'ed buffer that the socket is read into directly and that a hot-store GET hands to the caller as it
+// is (a segment is received once and never copied); JSON answers are moved into `body` for the decoders.
 struct Response {
     int status = 0;
     std::string body;
+    uint8_t* data = nullptr;
+    size_t len = 0, cap = 0;
+    Response() = default;
+    Response(const Response&) = delete;
+    Response& operator=(const Response&) = delete;
+    ~Response() { free(data); }
+    // room for `want` bytes in total, growing geometrically (a hostile Content-Length commits nothing before bytes arrive)
+    bool reserve(size_t want, size_t limit) {
+        if (want <= cap) return true;
+        size_t c = cap ? cap : (size_t)1 << 16;
+        while (c < want) c *= 2;
+        if (c > limit) c = limit;
+        uint8_t* q = (uint8_t*)realloc(data, c ? c : 1);
+        if (!q) return false;
+        data = q, cap = c;
+        return true;
+    }
+    uint8_t* release() {
+        uint8_t* p = data;
+        data = nullptr, cap = 0;
+        return p;
+    }
 };
 
 bool send_all(int fd, const char* p, size_t n) {
@@ -237,23 +270,70 @@ bool send_all(int fd, const char* p, size_t n) {
     return true;
 }
 
-// returns "" or the transport error
-std::string http_call(bx_rest_client* c, const char* method, const std::string& path_and_query, const char* content_type, const uint8_t* body,
-                      size_t body_len, uint64_t extra_wait, Response* out) {
-    c->requests.fetch_add(1);
+// buffered reads for the head and the chunk framing; body bytes beyond what the buffer already holds go straight to their place
+struct Reader {
+    int fd;
+    char buf[1 << 14];
+    size_t lo = 0, hi = 0;
+    bool any = false;  // a response byte was seen (a reused connection that dies before that is retried on a fresh one)
+    int err = 0;       // errno of the recv that failed (0 = the peer closed)
+    explicit Reader(int f) : fd(f) {}
+    bool fill() {
+        if (lo == hi) lo = hi = 0;
+        if (hi == sizeof buf) return false;
+        for (;;) {
+            ssize_t k = recv(fd, buf + hi, sizeof buf - hi, 0);
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) return err = k < 0 ? errno : 0, false;
+            hi += (size_t)k;
+            any = true;
+            return true;
+        }
+    }
+    // one line without its CRLF (a bare LF ends a line too); false on EOF, error or a line longer than `max`
+    bool line(std::string* out, size_t max) {
+        out->clear();
+        for (;;) {
+            while (lo < hi) {
+                char ch = buf[lo++];
+                if (ch == '\n') {
+                    if (!out->empty() && out->back() == '\r') out->pop_back();
+                    return true;
+                }
+                if (out->size() >= max) return false;
+                out->push_back(ch);
+            }
+            if (!fill()) return false;
+        }
+    }
+    bool exact(uint8_t* dst, size_t n) {
+        size_t have = hi - lo < n ? hi - lo : n;
+        memcpy(dst, buf + lo, have);
+        lo += have, dst += have, n -= have;
+        while (n) {
+            ssize_t k = recv(fd, dst, n, 0);
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) return err = k < 0 ? errno : 0, false;
+            any = true;
+            dst += k, n -= (size_t)k;
+        }
+        return true;
+    }
+};
+
+int dial(bx_rest_client* c, std::string* err) {
     addrinfo hints{}, *res = nullptr;
     hints.ai_family = AF_UNSPEC;
     hints.ai_socktype = SOCK_STREAM;
     int gai = getaddrinfo(c->host.c_str(), c->port.c_str(), &hints, &res);
-    if (gai != 0) return std::string("resolve ") + c->host + ": " + gai_strerror(gai);
+    if (gai != 0) return *err = std::string("resolve ") + c->host + ": " + gai_strerror(gai), -1;
     int fd = -1;
     std::string last = "no address";
     for (addrinfo* ai = res; ai; ai = ai->ai_next) {
         fd = socket(ai->ai_family, ai->ai_socktype, ai->ai_protocol);
         if (fd < 0) continue;
-        timeval tv{(time_t)(c->io_timeout + extra_wait), 0};
-        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
-        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        timeval tv{(time_t)c->io_timeout, 0};
+        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);  // also bounds connect()
         int one = 1;
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
         if (connect(fd, ai->ai_addr, ai->ai_addrlen) == 0) break;
@@ -262,71 +342,181 @@ std::string http_call(bx_rest_client* c, const char* method, const std::string& 
         fd = -1;
     }
     freeaddrinfo(res);
-    if (fd < 0) return "connect " + c->host + ":" + c->port + ": " + last;
+    if (fd < 0) return *err = "connect " + c->host + ":" + c->port + ": " + last, -1;
+    c->connects.fetch_add(1);
+    return fd;
+}
 
+bool all_digits(const std::string& s, int base) {
+    if (s.empty()) return false;
+    for (unsigned char ch : s)
+        if (!(base == 16 ? isxdigit(ch) : isdigit(ch))) return false;
+    return true;
+}
+std::string trimmed(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && (s[a] == ' ' || s[a] == '\t')) ++a;
+    while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\t')) --b;
+    return s.substr(a, b - a);
+}
+
+// One request on `fd`; "" or the transport error.  *reusable = the connection is positioned after a complete response and the
+// server did not ask to close it; *dead_before_answer = nothing of a response arrived (send failed or the peer had closed).
+std::string exchange(int fd, const std::string& head, const uint8_t* body, size_t body_len, Response* out, bool* reusable,
+                     bool* dead_before_answer) {
+    *reusable = false;
+    *dead_before_answer = false;
+    if (!send_all(fd, head.data(), head.size()) || (body_len && !send_all(fd, (const char*)body, body_len))) {
+        *dead_before_answer = true;
+        return std::string("send: ") + strerror(errno);
+    }
+    Reader rd(fd);
+    std::string ln;
+    if (!rd.line(&ln, MAX_HEADER_BYTES)) {
+        *dead_before_answer = !rd.any;
+        return rd.any ? "malformed HTTP response" : std::string("receive: ") + (rd.err ? strerror(rd.err) : "connection closed");
+    }
+    if (ln.compare(0, 5, "HTTP/") != 0) return "malformed HTTP response";
+    bool keep = ln.compare(0, 8, "HTTP/1.1") == 0;
+    size_t sp = ln.find(' ');
+    int status = 0;
+    if (sp != std::string::npos)
+        for (size_t k = sp + 1; k < ln.size() && k < sp + 10 && ln[k] >= '0' && ln[k] <= '9'; ++k) status = status * 10 + (ln[k] - '0');
+    out->status = status;
+    bool chunked = false, have_len = false;
+    size_t content_len = 0, head_bytes = ln.size();
+    for (;;) {
+        if (!rd.line(&ln, MAX_HEADER_BYTES)) return "malformed HTTP response";
+        if (ln.empty()) break;
+        if ((head_bytes += ln.size() + 2) > MAX_HEADER_BYTES) return "response header larger than 64 KiB";
+        size_t colon = ln.find(':');
+        if (colon == std::string::npos) continue;
+        std::string name = ln.substr(0, colon), value = trimmed(ln.substr(colon + 1));
+        for (auto& ch : name) ch = (char)tolower((unsigned char)ch);
+        for (auto& ch : value) ch = (char)tolower((unsigned char)ch);
+        if (name == "content-length") {
+            if (!all_digits(value, 10) || value.size() > 18) return "malformed Content-Length";
+            content_len = strtoull(value.c_str(), nullptr, 10);
+            have_len = true;
+        } else if (name == "transfer-encoding") {
+            if (value.find("chunked") != std::string::npos) chunked = true;
+        } else if (name == "connection") {
+            if (value.find("close") != std::string::npos) keep = false;
+            else if (value.find("keep-alive") != std::string::npos) keep = true;
+        }
+    }
+    const std::string too_large = "response larger than " + std::to_string(MAX_RESPONSE_BYTES >> 20) + " MiB";
+    if (status == 204 || status == 304 || (status >= 100 && status < 200)) {
+        // no body by definition
+    } else if (chunked) {
+        for (;;) {
+            if (!rd.line(&ln, 1024)) return "malformed chunked body";
+            size_t semi = ln.find(';');  // chunk extensions are ignored
+            std::string num = trimmed(semi == std::string::npos ? ln : ln.substr(0, semi));
+            if (!all_digits(num, 16)) return "malformed chunked body";  // no hex digits where a chunk size belongs
+            if (num.size() > 15) return "truncated chunked body";       // a size no body of this client can have
+            size_t n = strtoull(num.c_str(), nullptr, 16);
+            if (n == 0) {
+                while (rd.line(&ln, MAX_HEADER_BYTES) && !ln.empty()) {}  // trailers
+                break;
+            }
+            if (n > MAX_RESPONSE_BYTES - out->len) return too_large;
+            if (!out->reserve(out->len + n, MAX_RESPONSE_BYTES)) return "out of memory";
+            uint8_t crlf[2];
+            if (!rd.exact(out->data + out->len, n)) return "truncated chunked body";
+            out->len += n;
+            if (!rd.exact(crlf, 2) || crlf[0] != '\r' || crlf[1] != '\n') return "truncated chunked body";
+        }
+    } else if (have_len) {
+        if (content_len > MAX_RESPONSE_BYTES) return too_large;
+        // grow as bytes arrive: 1 MiB steps doubling, so a lying Content-Length costs nothing
+        while (out->len < content_len) {
+            size_t step = out->cap > out->len ? out->cap - out->len : 0;
+            if (!step) {
+                if (!out->reserve(out->len + 1, content_len)) return "out of memory";
+                step = out->cap - out->len;
+            }
+            if (step > content_len - out->len) step = content_len - out->len;
+            if (!rd.exact(out->data + out->len, step)) return "truncated body";
+            out->len += step;
+        }
+    } else {
+        keep = false;  // delimited by the end of the connection
+        for (;;) {
+            if (out->len == out->cap) {
+                if (out->len >= MAX_RESPONSE_BYTES) return too_large;
+                if (!out->reserve(out->len + 1, MAX_RESPONSE_BYTES)) return "out of memory";
+            }
+            size_t have = rd.hi - rd.lo;
+            if (have) {
+                size_t take = have < out->cap - out->len ? have : out->cap - out->len;
+                memcpy(out->data + out->len, rd.buf + rd.lo, take);
+                rd.lo += take, out->len += take;
+                continue;
+            }
+            ssize_t k = recv(fd, out->data + out->len, out->cap - out->len, 0);
+            if (k < 0 && errno == EINTR) continue;
+            if (k < 0) return std::string("receive: ") + strerror(errno);
+            if (k == 0) break;
+            out->len += (size_t)k;
+        }
+    }
+    *reusable = keep && rd.lo == rd.hi;
+    return "";
+}
+
+// returns "" or the transport error.  Connections are kept alive and reused (the reference's client is one shared, pooling reqwest::Client,
+// assets.rs:76); a reused connection that turns out to be dead before any answer byte is replaced by a fresh one, once.
+// `blob`: leave the body in out->data (hot-store values); otherwise it is moved to out->body for the JSON decoders.
+std::string http_call(bx_rest_client* c, const char* method, const std::string& path_and_query, const char* content_type, const uint8_t* body,
+                      size_t body_len, uint64_t extra_wait, Response* out, bool blob = false) {
+    c->requests.fetch_add(1);
     std::string head = std::string(method) + " " + c->prefix + path_and_query + " HTTP/1.1\r\nHost: " + c->host + ":" + c->port +
-                       "\r\nConnection: close\r\nAccept: */*\r\n";
+                       "\r\nConnection: keep-alive\r\nAccept: */*\r\n";
     if (body || !strcmp(method, "POST") || !strcmp(method, "PUT")) {
         if (content_type) head += std::string("Content-Type: ") + content_type + "\r\n";
         head += "Content-Length: " + std::to_string(body_len) + "\r\n";
     }
     head += "\r\n";
-    if (!send_all(fd, head.data(), head.size()) || (body_len && !send_all(fd, (const char*)body, body_len))) {
-        std::string e = std::string("send: ") + strerror(errno);
-        close(fd);
-        return e;
+    for (int attempt = 0;; ++attempt) {
+        int fd = -1;
+        bool reused = false;
+        if (attempt == 0) {
+            std::lock_guard<std::mutex> g(c->mu);
+            if (!c->idle.empty()) {
+                fd = c->idle.back();
+                c->idle.pop_back();
+                reused = true;
+            }
+        }
+        if (fd < 0) {
+            std::string e;
+            fd = dial(c, &e);
+            if (fd < 0) return e;
+        }
+        timeval tv{(time_t)(c->io_timeout + extra_wait), 0};
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        bool reusable = false, dead = false;
+        out->status = 0, out->len = 0;
+        std::string e = exchange(fd, head, body, body_len, out, &reusable, &dead);
+        if (e.empty() && reusable) {
+            std::lock_guard<std::mutex> g(c->mu);
+            if (c->idle.size() < MAX_IDLE_CONNECTIONS) {
+                c->idle.push_back(fd);
+                fd = -1;
+            }
+        }
+        if (fd >= 0) close(fd);
+        if (!e.empty() && reused && dead) continue;  // the server had dropped the idle connection: not this request's failure
+        if (!e.empty()) return e;
+        if (!blob) {
+            out->body.assign((const char*)out->data, out->len);
+            free(out->release());
+            out->len = 0;
+        }
+        return "";
     }
-    std::string raw;
-    char buf[1 << 16];
-    for (;;) {
-        ssize_t k = recv(fd, buf, sizeof buf, 0);
-        if (k < 0) {
-            if (errno == EINTR) continue;
-            std::string e = std::string("receive: ") + strerror(errno);
-            close(fd);
-            return e;
-        }
-        if (k == 0) break;
-        if (raw.size() + (size_t)k > MAX_RESPONSE_BYTES) {
-            close(fd);
-            return "response larger than " + std::to_string(MAX_RESPONSE_BYTES >> 20) + " MiB";
-        }
-        raw.append(buf, (size_t)k);
-    }
-    close(fd);
-    size_t he = raw.find("\r\n\r\n");
-    if (he == std::string::npos || raw.compare(0, 5, "HTTP/") != 0) return "malformed HTTP response";
-    size_t sp = raw.find(' ');
-    out->status = sp == std::string::npos ? 0 : atoi(raw.c_str() + sp + 1);
-    std::string headers = raw.substr(0, he);
-    for (auto& ch : headers) ch = (char)tolower((unsigned char)ch);
-    std::string payload = raw.substr(he + 4);
-    if (headers.find("transfer-encoding: chunked") != std::string::npos) {
-        std::string de;
-        size_t pos = 0;
-        for (;;) {
-            size_t le = payload.find("\r\n", pos);
-            if (le == std::string::npos) return "malformed chunked body";
-            char* num_end = nullptr;
-            const std::string num = payload.substr(pos, le - pos);
-            size_t n = strtoull(num.c_str(), &num_end, 16);
-            if (num_end == num.c_str()) return "malformed chunked body";  // no hex digits where a chunk size belongs
-            if (n == 0) break;
-            if (n > payload.size() - (le + 2)) return "truncated chunked body";  // (also: a size that would wrap the offsets)
-            de.append(payload, le + 2, n);
-            pos = le + 2 + n + 2;
-        }
-        out->body.swap(de);
-    } else {
-        size_t cl = headers.find("content-length:");
-        if (cl != std::string::npos) {
-            size_t n = strtoull(headers.c_str() + cl + 15, nullptr, 10);
-            if (payload.size() < n) return "truncated body";
-            payload.resize(n);
-        }
-        out->body.swap(payload);
-    }
-    return "";
 }
 
 std::string task_url(const char* job, const char* task, const char* action) {
@@ -425,14 +615,13 @@ int rest_hot_get(void* user, const char* key, uint8_t** value, size_t* len, char
     auto* c = (bx_rest_client*)user;
     try {
         Response r;
-        std::string e = http_call(c, "GET", "/worker/hot/" + enc_path(key, true), nullptr, nullptr, 0, 0, &r);
+        std::string e = http_call(c, "GET", "/worker/hot/" + enc_path(key, true), nullptr, nullptr, 0, 0, &r, /*blob=*/true);
         if (!e.empty()) return put_err(eb, cap, std::string("failed to fetch hot-store key ") + key + ": " + e), -1;
         if (r.status == 404) return 1;  // AppError::HotDataMissing
         if (r.status >= 400 || r.status < 200) return put_err(eb, cap, std::string("hot-store fetch failed for key ") + key + ": HTTP " + std::to_string(r.status)), -1;
-        *len = r.body.size();
-        *value = (uint8_t*)malloc(*len ? *len : 1);
-        if (!*value) return put_err(eb, cap, "out of memory"), -1;
-        memcpy(*value, r.body.data(), *len);
+        if (!r.data && !r.reserve(1, 1)) return put_err(eb, cap, "out of memory"), -1;  // an empty value is still a value
+        *len = r.len;
+        *value = r.release();  // the buffer the socket was read into
         return 0;
     } catch (const std::exception& ex) {
         return put_err(eb, cap, ex.what()), -1;
@@ -514,5 +703,6 @@ bx_hot_store_ops bx_rest_hot_store_ops(bx_rest_client* c) {
     return bx_hot_store_ops{c, rest_hot_get, rest_hot_free, rest_hot_set, rest_hot_unlink};
 }
 uint64_t bx_rest_client_requests(const bx_rest_client* c) { return c ? c->requests.load() : 0; }
+uint64_t bx_rest_client_connects(const bx_rest_client* c) { return c ? c->connects.load() : 0; }
 
 }  // extern "C"

@@ -20,9 +20,11 @@
  *   worker client   prover/crates/workflow/src/assets.rs:88-120 (URLs), :193-420 (calls, error_for_status, JSON shapes)
  *   its use         prover/crates/workflow/src/lib.rs:353-365 (claim with wait_timeout_secs = poll_time), :371-420
  *
- * Transport: plain HTTP/1.1 over TCP, one connection per call, blocking (the agent's lanes are threads, and a call is
- * ms-scale next to a proof).  The reference's workers reach the API inside the cluster network; TLS, if any, terminates in
- * front of it.  A client is immutable after creation and may be used from any number of threads.
+ * Transport: plain HTTP/1.1 over TCP, blocking (the agent's lanes are threads).  Connections are kept alive and pooled
+ * (up to 16 idle ones; the reference shares one pooling reqwest::Client, assets.rs:76); an idle connection the server has
+ * dropped is replaced once, transparently, when no byte of an answer had arrived.  A body with a Content-Length is received
+ * straight into the buffer `get` returns: an 80 MB segment is written once by the kernel and never copied by this client.  The reference's workers reach the API inside the cluster network; TLS, if any, terminates in
+ * front of it.  A client may be used from any number of threads (the pool is its only mutable state).
  * Errors follow bx_agent.h's callback convention (negative return + message in errbuf); HTTP status >= 400 is an error
  * except 404 on a hot-store GET, which is "key not found" (return 1) as redis nil is for the in-memory store.
  */
@@ -43,8 +45,9 @@ void bx_rest_client_destroy(bx_rest_client* c);
 /* The returned tables borrow the client; destroy it after the agent. */
 bx_taskdb_ops bx_rest_taskdb_ops(bx_rest_client* c);
 bx_hot_store_ops bx_rest_hot_store_ops(bx_rest_client* c);
-/* Number of HTTP requests issued so far (all threads). */
+/* Number of HTTP requests issued so far (all threads), and the number of TCP connections opened for them. */
 uint64_t bx_rest_client_requests(const bx_rest_client* c);
+uint64_t bx_rest_client_connects(const bx_rest_client* c);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,17 @@ int main() {
         "HTTP/1.1 500 Internal Server Error\r\nContent-Length: 300000\r\n\r\n" + std::string(300000, 'E'),
         "HTTP/1.1 999999999999999999999 Weird\r\nContent-Length: 0\r\n\r\n",
         std::string("HTTP/1.1 200 OK\r\nContent-Length: 4\r\n\r\n\0\0\0\0", 42),
+        // the pooling transport: bytes past the body, oversized heads, chunk extensions, trailers, EOF-delimited bodies
+        "HTTP/1.1 200 OK\r\nContent-Length: 2\r\nConnection: keep-alive\r\n\r\nokHTTP/1.1 200 OK\r\nContent-Length: 4\r\n\r\nnull",
+        "HTTP/1.1 200 OK\r\nX-Pad: " + std::string(70000, 'a') + "\r\nContent-Length: 4\r\n\r\nnull",
+        "HTTP/1.1 200 OK\r\n" + [] { std::string h; for (int i = 0; i < 9000; ++i) h += "X-" + std::to_string(i) + ": y\r\n"; return h; }() + "\r\nnull",
+        "HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\n4;ext=\"a\"\r\nnull\r\n0\r\nTrailer: x\r\n\r\n",
+        "HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\n4\r\nnullXX0\r\n\r\n",
+        "HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\n" + std::string(2000, '0') + "4\r\nnull\r\n0\r\n\r\n",
+        "HTTP/1.0 200 OK\r\n\r\nnull",
+        "HTTP/1.1 204 No Content\r\nContent-Length: 50\r\n\r\n",
+        "HTTP/1.1 200 OK\nContent-Length: 4\n\nnull",
+        "HTTP/1.1 200 OK\r\nContent-Length: 4\r\nContent-Length: 99999999999999999999\r\n\r\nnull",
     };
     char eb[256];
     long calls = 0;
@@ -141,6 +152,28 @@ int main() {
     uint8_t* val = nullptr;
     size_t len = 0;
     if (hot.get(hot.user, "missing", &val, &len, eb, sizeof eb) != 1) bad |= 8;
+
+    // a body delimited by the end of the connection, a chunk extension and a trailer, a bare-LF head
+    current = "HTTP/1.0 200 OK\r\n\r\nnull";
+    if (db.request_work(db.user, "prove", &t, eb, sizeof eb) != 0) bad |= 512;
+    current = "HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\n4;ext=\"a\"\r\nnull\r\n0\r\nTrailer: x\r\n\r\n";
+    if (db.request_work(db.user, "prove", &t, eb, sizeof eb) != 0) bad |= 1024;
+    // a 5 MB value arrives whole, read straight into the buffer `get` returns; the server of this harness closes every
+    // connection without saying so, so each of these calls also exercises the replacement of a dead pooled connection
+    {
+        std::string big(5u << 20, '\0');
+        for (size_t i = 0; i < big.size(); ++i) big[i] = (char)(i * 2654435761u >> 24);
+        current = "HTTP/1.1 200 OK\r\nContent-Type: application/octet-stream\r\nContent-Length: " + std::to_string(big.size()) + "\r\n\r\n" + big;
+        uint8_t* v2 = nullptr;
+        size_t l2 = 0;
+        if (hot.get(hot.user, "big", &v2, &l2, eb, sizeof eb) != 0 || l2 != big.size() || memcmp(v2, big.data(), l2) != 0) bad |= 2048;
+        if (v2) hot.free_value(hot.user, v2);
+        current = "HTTP/1.1 200 OK\r\nContent-Length: 0\r\n\r\n";
+        v2 = nullptr, l2 = 7;
+        if (hot.get(hot.user, "empty", &v2, &l2, eb, sizeof eb) != 0 || l2 != 0 || !v2) bad |= 4096;
+        if (v2) hot.free_value(hot.user, v2);
+    }
+    if (bx_rest_client_connects(c) >= bx_rest_client_requests(c) + 1 || bx_rest_client_connects(c) == 0) bad |= 8192;
 
     // serde would refuse these: a string or an out-of-range number where an i32 belongs is a decode error, not a zero
     int32_t rr = 7;

@@ -15,11 +15,15 @@ GPU_STREAMS = {"prove", "join", "coproc", "snark"}
 
 class State:
     def __init__(self):
-        self.mu = threading.Lock()
+        self.mu = threading.RLock()  # handlers answer while holding it
         self.hot = {}      # key -> (bytes, deadline or None)
         self.tasks = []    # dicts: stream, job_id, task_id, task_def, max_retries, retries, state, error, output
         self.log = []      # (method, path)
         self.fail_next = 0  # respond 500 to this many upcoming requests (fault injection)
+        self.keep_alive = True   # HTTP/1.1 persistent connections, as the reference's axum server keeps them
+        self.drop_every = 0      # close the connection after every n-th response ...
+        self.drop_silently = False  # ... without announcing it ("Connection: close" left out)
+        self.served = 0
 
     def create_task(self, stream, job_id, task_id, task_def, max_retries=0):
         with self.mu:
@@ -44,10 +48,17 @@ def make_handler(st):
             self.send_response(code)
             self.send_header("Content-Type", ctype)
             self.send_header("Content-Length", str(len(body)))
-            self.send_header("Connection", "close")
+            with st.mu:
+                st.served += 1
+                drop = not st.keep_alive or (st.drop_every and st.served % st.drop_every == 0)
+                silent = drop and st.drop_silently
+            if drop and not silent:
+                self.send_header("Connection", "close")
             self.end_headers()
             if body:
                 self.wfile.write(body)
+            if drop:
+                self.close_connection = True  # silent: what a server's idle timeout looks like to a pooling client
 
         def _json(self, obj, code=200):
             self._send(code, json.dumps(obj).encode())

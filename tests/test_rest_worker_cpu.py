@@ -183,3 +183,54 @@ def test_a_long_non_ascii_error_still_reaches_the_server_as_valid_json(server):
     e = by["t-utf8"]["error"]
     assert e.startswith("[BENTO-WF-115] Prove failed: é") and e.endswith("é") and len(e.encode()) in (1023, 1024)
     w.close()
+
+
+def _store_ops(w):
+    """The hot-store callback table of a RestWorker as plain Python calls (what the agent's lanes do through C)."""
+    import ctypes as C
+
+    ops = w.store.value if hasattr(w.store, "value") else w.store
+    return ops, C
+
+
+def test_connections_are_kept_alive_and_pooled(server):
+    """30+ requests of a run travel over a handful of TCP connections (the reference shares one pooling reqwest client,
+    assets.rs:76); with `Connection: close` on every answer the same run opens one connection per request and still works."""
+    st = server.state
+    for mode in ("keep-alive", "close"):
+        st.keep_alive = mode == "keep-alive"
+        st.tasks.clear(), st.hot.clear(), st.log.clear()
+        for i in range(6):
+            st.hot[f"job:{JOB}:segments:{i}"] = (ag.serialize_segment(Segment.synthetic(i, po2=10)), None)
+            st.create_task("prove", JOB, f"p-{mode}-{i}", {"Prove": {"index": i}}, max_retries=0)
+        w = ag.RestWorker(server.url)
+        a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, inflight=2, store=w.store, taskdb=w.taskdb)
+        try:
+            assert a.poll_work(max_idle_polls=2) == 6
+        finally:
+            a.close()
+        assert w.requests == len(st.log) >= 30
+        if mode == "keep-alive":
+            assert w.connects <= 6, (w.connects, w.requests)  # lanes + finishers, not requests
+        else:
+            assert w.connects == w.requests
+        w.close()
+
+
+def test_an_idle_connection_dropped_by_the_server_is_replaced_transparently(server):
+    """A server-side idle timeout closes a pooled connection without notice; the request that finds it dead (no byte of an
+    answer yet) goes out again on a fresh connection instead of failing the task."""
+    st = server.state
+    st.drop_every, st.drop_silently = 3, True
+    for i in range(8):
+        st.hot[f"job:{JOB}:segments:{i}"] = (ag.serialize_segment(Segment.synthetic(i, po2=10)), None)
+        st.create_task("prove", JOB, f"d-{i}", {"Prove": {"index": i}}, max_retries=0)
+    w = ag.RestWorker(server.url)
+    a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.01, store=w.store, taskdb=w.taskdb)
+    try:
+        assert a.poll_work(max_idle_polls=2) == 8
+    finally:
+        a.close()
+    assert [t["state"] for t in st.tasks] == ["done"] * 8
+    assert 1 < w.connects < w.requests
+    w.close()
