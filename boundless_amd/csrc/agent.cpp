@@ -611,20 +611,32 @@ struct bx_agent {
 
     // ---- redis.rs helpers with their metrics ----
     // returns "" on success, otherwise the error text
-    std::string store_get(const std::string& key, std::vector<uint8_t>* out) {
+    // a value as the store handed it out; given back through free_value when it goes out of scope (a segment is ~80 MB:
+    // it is read where the store put it, not copied into a container of ours)
+    struct StoreValue {
+        const bx_hot_store_ops* ops = nullptr;
+        uint8_t* p = nullptr;
+        size_t n = 0;
+        StoreValue() = default;
+        StoreValue(const StoreValue&) = delete;
+        StoreValue& operator=(const StoreValue&) = delete;
+        ~StoreValue() {
+            if (p && ops && ops->free_value) ops->free_value(ops->user, p);
+        }
+        const uint8_t* data() const { return p; }
+        size_t size() const { return n; }
+    };
+    std::string store_get(const std::string& key, StoreValue* out) {
         auto t0 = Clock::now();
         char eb[256] = {0};
-        uint8_t* v = nullptr;
-        size_t n = 0;
-        int rc = store.get(store.user, key.c_str(), &v, &n, eb, sizeof eb);
+        int rc = store.get(store.user, key.c_str(), &out->p, &out->n, eb, sizeof eb);
         std::string err;
         if (rc == 0) {
-            out->assign(v, v + n);
-            if (store.free_value) store.free_value(store.user, v);
-        } else if (rc == 1) {
-            err = "Key not found (nil response): " + key;  // redis.rs:51-55
+            out->ops = &store;
         } else {
-            err = eb[0] ? eb : "hot store get failed";
+            out->p = nullptr, out->n = 0;
+            if (rc == 1) err = "Key not found (nil response): " + key;  // redis.rs:51-55
+            else err = eb[0] ? eb : "hot store get failed";
         }
         metrics.record_redis_operation("get", rc == 0 ? "success" : "error", secs_since(t0));
         return err;
@@ -653,7 +665,7 @@ struct bx_agent {
         out->task = task;
         out->job_prefix = std::string("job:") + task.job_id;
         out->segment_key = out->job_prefix + ":segments:" + std::to_string(index);  // SEGMENTS_PATH, tasks/mod.rs:25
-        std::vector<uint8_t> blob;
+        StoreValue blob;
         std::string e = store_get(out->segment_key, &blob);
         if (!e.empty()) return "segment data not found for segment key: " + out->segment_key + ": " + e;
         out->opaque = prover.prove_blob != nullptr;
