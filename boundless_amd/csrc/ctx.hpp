@@ -139,6 +139,13 @@ inline const char* set_msg(bx_ctx* c, const char* msg) {
     return c->err;
 }
 
+// "No exception crosses the ABI" (bx_hal.h): every multi-statement extern "C" entry point is a function-try-block closed by
+// BX_ABI_CATCH — a std::bad_alloc from a host-side container (or anything else thrown below) comes back as the entry point's
+// error string like any other failure.  The message lives in the ctx when there is one, otherwise in a thread-local buffer.
+const char* abi_caught(bx_ctx* c, const char* fn) noexcept;
+#define BX_ABI_CATCH(c, fn) \
+    catch (...) { return bx::abi_caught((c), fn); }
+
 #define BX_HIP(c, call)                                                        \
     do {                                                                       \
         hipError_t _e = (call);                                                \

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <exception>
+#include <new>
 #include <mutex>
 #include <string>
 
@@ -117,10 +119,30 @@ static void drain_profile(bx_ctx* c) {
 
 using namespace bx;
 
+namespace bx {
+const char* abi_caught(bx_ctx* c, const char* fn) noexcept {
+    const char* what = "unexpected C++ exception";
+    char copy[160];
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        what = "out of host memory";
+    } catch (const std::exception& e) {
+        snprintf(copy, sizeof copy, "%s", e.what());
+        what = copy;
+    } catch (...) {
+    }
+    static thread_local char tl[224];
+    char* dst = c ? c->err : tl;
+    snprintf(dst, c ? sizeof c->err : sizeof tl, "%s: %s", fn, what);
+    return dst;
+}
+}  // namespace bx
+
 extern "C" const char* bx_trace_enable(int level) { return trace_set(level); }
 extern "C" int bx_trace_level(void) { return trace_level(); }
 
-extern "C" const char* bx_init(int device, bx_ctx** out) {
+extern "C" const char* bx_init(int device, bx_ctx** out) try {
     if (!out) return "bx_init: null out pointer";
     *out = nullptr;
     if (const char* env = getenv("BX_TRACE")) {  // BX_TRACE=1|2: ranges on from the first context on
@@ -194,7 +216,7 @@ extern "C" const char* bx_init(int device, bx_ctx** out) {
     }
     *out = c;
     return nullptr;
-}
+} BX_ABI_CATCH(nullptr, "bx_init")
 
 namespace bx {
 hipError_t stream_wait(bx_ctx* c) {
@@ -254,7 +276,7 @@ const char* sync_and_check_flag(bx_ctx* c) {
 }
 }  // namespace bx
 
-extern "C" const char* bx_free(bx_ctx* c) {
+extern "C" const char* bx_free(bx_ctx* c) try {
     if (!c) return nullptr;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -274,30 +296,30 @@ extern "C" const char* bx_free(bx_ctx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return nullptr;
-}
+} BX_ABI_CATCH(nullptr, "bx_free")  // c may be gone by then
 
-extern "C" const char* bx_device_name(bx_ctx* c, char* out, size_t cap) {
+extern "C" const char* bx_device_name(bx_ctx* c, char* out, size_t cap) try {
     if (!c) return "bx_device_name: null ctx";
     hipDeviceProp_t prop;
     BX_HIP(c, hipGetDeviceProperties(&prop, c->device));
     snprintf(out, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_device_name")
 
 // Hal::get_hash_suite / Hal::has_unified_memory: the one suite this HAL implements is the reference's default `poseidon2`
 // (ProverOpts::default(), bento/crates/workflow/src/lib.rs:246-249); MI355X HBM is not host-coherent unified memory.
 extern "C" const char* bx_hash_suite_name(void) { return "poseidon2"; }
 extern "C" int bx_has_unified_memory(bx_ctx*) { return 0; }
 
-extern "C" const char* bx_set_stream(bx_ctx* c, void* s) {
+extern "C" const char* bx_set_stream(bx_ctx* c, void* s) try {
     if (!c) return "bx_set_stream: null ctx";
     BX_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_set_stream")
 extern "C" void* bx_get_stream(bx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) {
+extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) try {
     if (!c) return "bx_alloc: null ctx";
     BX_REQUIRE(c, out != nullptr, "bx_alloc: null out");
     BX_HIP(c, hipSetDevice(c->device));
@@ -306,24 +328,24 @@ extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) {
     out->dptr = p;
     out->len = words;
     return nullptr;
-}
-extern "C" const char* bx_release(bx_ctx* c, bx_buf b) {
+} BX_ABI_CATCH(c, "bx_alloc")
+extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;
     BX_HIP(c, hipSetDevice(c->device));
     BX_HIP(c, hipStreamSynchronize(c->stream));
     BX_HIP(c, hipFree(b.dptr));
     return nullptr;
-}
-extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
+} BX_ABI_CATCH(c, "bx_release")
+extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) try {
     if (!c) return "bx_h2d: null ctx";
     BX_REQUIRE(c, words <= dst.len, "bx_h2d: copy larger than the buffer");
     BX_HIP(c, hipSetDevice(c->device));
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src, words * 4, hipMemcpyHostToDevice, c->stream));
     BX_HIP(c, stream_wait(c));  // src may be pageable and freed by the caller right after
     return nullptr;
-}
-extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words) {
+} BX_ABI_CATCH(c, "bx_h2d")
+extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words) try {
     if (!c) return "bx_d2h: null ctx";
     BX_REQUIRE(c, words <= src.len, "bx_d2h: copy larger than the buffer");
     BX_HIP(c, hipSetDevice(c->device));
@@ -336,46 +358,46 @@ extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words
     }
     BX_HIP(c, hipMemcpyAsync(dst, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
     return sync_and_check_flag(c);
-}
-extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) {
+} BX_ABI_CATCH(c, "bx_d2h")
+extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) try {
     if (!c) return "bx_d2d: null ctx";
     BX_REQUIRE(c, words <= src.len && words <= dst.len, "bx_d2d: copy larger than a buffer");
     BX_HIP(c, hipSetDevice(c->device));
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src.dptr, words * 4, hipMemcpyDeviceToDevice, c->stream));
     return nullptr;
-}
-extern "C" const char* bx_sync(bx_ctx* c) {
+} BX_ABI_CATCH(c, "bx_d2d")
+extern "C" const char* bx_sync(bx_ctx* c) try {
     if (!c) return "bx_sync: null ctx";
     BX_HIP(c, hipSetDevice(c->device));
     return sync_and_check_flag(c);
-}
+} BX_ABI_CATCH(c, "bx_sync")
 
-extern "C" const char* bx_timer_start(bx_ctx* c) {
+extern "C" const char* bx_timer_start(bx_ctx* c) try {
     if (!c) return "bx_timer_start: null ctx";
     BX_HIP(c, hipEventRecord(c->t0, c->stream));
     return nullptr;
-}
-extern "C" const char* bx_timer_stop(bx_ctx* c, float* ms) {
+} BX_ABI_CATCH(c, "bx_timer_start")
+extern "C" const char* bx_timer_stop(bx_ctx* c, float* ms) try {
     if (!c) return "bx_timer_stop: null ctx";
     BX_HIP(c, hipEventRecord(c->t1, c->stream));
     BX_HIP(c, hipEventSynchronize(c->t1));
     BX_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_timer_stop")
 
-extern "C" const char* bx_profile_enable(bx_ctx* c, int on) {
+extern "C" const char* bx_profile_enable(bx_ctx* c, int on) try {
     if (!c) return "bx_profile_enable: null ctx";
     if (!on) drain_profile(c);
     c->profile = on != 0;
     return nullptr;
-}
-extern "C" const char* bx_profile_reset(bx_ctx* c) {
+} BX_ABI_CATCH(c, "bx_profile_enable")
+extern "C" const char* bx_profile_reset(bx_ctx* c) try {
     if (!c) return "bx_profile_reset: null ctx";
     drain_profile(c);
     c->prof_agg.clear();
     return nullptr;
-}
-extern "C" const char* bx_profile_report(bx_ctx* c, char* out, size_t cap) {
+} BX_ABI_CATCH(c, "bx_profile_reset")
+extern "C" const char* bx_profile_report(bx_ctx* c, char* out, size_t cap) try {
     if (!c) return "bx_profile_report: null ctx";
     drain_profile(c);
     std::string s = "{";
@@ -391,9 +413,9 @@ extern "C" const char* bx_profile_report(bx_ctx* c, char* out, size_t cap) {
     BX_REQUIRE(c, s.size() + 1 <= cap, "bx_profile_report: output buffer too small");
     memcpy(out, s.c_str(), s.size() + 1);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_profile_report")
 
-extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
+extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) try {
     if (!c) return "bx_set_tunable: null ctx";
     BX_REQUIRE(c, name != nullptr, "bx_set_tunable: null name");
     if (!strcmp(name, "ntt_block_log")) {
@@ -454,4 +476,4 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) {
         return set_msg(c, "bx_set_tunable: unknown tunable");
     }
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_set_tunable")

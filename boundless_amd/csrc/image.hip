@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void page_cells_kernel(uint32_t* __restrict__ 
 
 using namespace bx;
 
-extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, size_t n) {
+extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, size_t n) try {
     if (!c) return "bx_image_page_cells: null ctx";
     BX_REQUIRE(c, raw.len >= n * BX_PAGE_WORDS && out.len >= n * 2 * BX_PAGE_WORDS, "image_page_cells: buffer too small");
     BX_REQUIRE(c, n <= (1u << BX_MERKLE_DEPTH) + 1u, "image_page_cells: more pages than the address space holds");
@@ -57,7 +57,7 @@ extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, si
                        (const uint32_t*)raw.dptr, (uint32_t)n);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_image_page_cells")
 
 // Digest of node `top` (canonical words) from the pages and the given digests below it.  Every digest lives in one device pool:
 // [0, n) page digests | [n] the zero page | per level its parents then its zero subtree | the given digests; a level's fold reads
@@ -170,7 +170,7 @@ static const char* image_node(bx_ctx* c, const bx_image* im, uint32_t top, uint3
 }
 static const char* image_root(bx_ctx* c, const bx_image* im, uint32_t root_out[8]) { return image_node(c, im, 1u, root_out); }
 
-extern "C" const char* bx_image_node_digest(bx_ctx* c, const bx_image* im, uint32_t node_idx, uint32_t digest_canonical[8]) {
+extern "C" const char* bx_image_node_digest(bx_ctx* c, const bx_image* im, uint32_t node_idx, uint32_t digest_canonical[8]) try {
     if (!c) return "bx_image_node_digest: null ctx";
     BX_REQUIRE(c, im && digest_canonical, "image_node_digest: null argument");
     try {
@@ -178,9 +178,9 @@ extern "C" const char* bx_image_node_digest(bx_ctx* c, const bx_image* im, uint3
     } catch (...) {
         return set_msg(c, "image_node_digest: out of memory");
     }
-}
+} BX_ABI_CATCH(c, "bx_image_node_digest")
 
-extern "C" const char* bx_image_root(bx_ctx* c, const bx_image* im, uint32_t root_canonical[8]) {
+extern "C" const char* bx_image_root(bx_ctx* c, const bx_image* im, uint32_t root_canonical[8]) try {
     if (!c) return "bx_image_root: null ctx";
     BX_REQUIRE(c, im && root_canonical, "image_root: null argument");
     try {
@@ -188,9 +188,9 @@ extern "C" const char* bx_image_root(bx_ctx* c, const bx_image* im, uint32_t roo
     } catch (...) {
         return set_msg(c, "image_root: out of memory");
     }
-}
+} BX_ABI_CATCH(c, "bx_image_root")
 
-extern "C" const char* bx_compute_image_id(bx_ctx* c, const uint8_t* blob, size_t len, uint8_t id_out[32]) {
+extern "C" const char* bx_compute_image_id(bx_ctx* c, const uint8_t* blob, size_t len, uint8_t id_out[32]) try {
     if (!c) return "bx_compute_image_id: null ctx";
     BX_REQUIRE(c, id_out, "compute_image_id: null out");
     bx_image* im = nullptr;
@@ -201,4 +201,4 @@ extern "C" const char* bx_compute_image_id(bx_ctx* c, const uint8_t* blob, size_
     if (m) return m;
     bx_system_state_digest(root, 0u, id_out);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_compute_image_id")

@@ -529,7 +529,7 @@ static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count);
 // Extension: batch_interpolate_ntt followed by zk_shift in one call.  When the register-radix path covers the shape the
 // shift rides on the final store of the inverse transform (one extra product per element instead of a read-modify-write
 // pass over the coefficients); otherwise it is the two calls.
-extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t count) {
+extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_interpolate_zk: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_zk: io.len/count must be a power of two");
     BX_HIP(c, hipSetDevice(c->device));
@@ -543,17 +543,17 @@ extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t coun
     }
     if (fused) return nullptr;
     return zk_shift_impl(c, io, count);
-}
+} BX_ABI_CATCH(c, "bx_batch_interpolate_zk")
 
-extern "C" const char* bx_batch_interpolate_ntt(bx_ctx* c, bx_buf io, size_t count) {
+extern "C" const char* bx_batch_interpolate_ntt(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_interpolate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_ntt: io.len/count must be a power of two");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "batch_interpolate_ntt", 8.0 * (double)io.len);
     return inverse(c, (uint32_t*)io.dptr, count, ilog2(io.len / count));
-}
+} BX_ABI_CATCH(c, "bx_batch_interpolate_ntt")
 
-extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count, size_t expand_bits) {
+extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count, size_t expand_bits) try {
     if (!c) return "bx_batch_evaluate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_evaluate_ntt: io.len/count must be a power of two");
     int m = ilog2(io.len / count);
@@ -561,9 +561,9 @@ extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count,
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "batch_evaluate_ntt", 8.0 * (double)io.len);
     return forward(c, (uint32_t*)io.dptr, (const uint32_t*)io.dptr, count, m, 0, (int)expand_bits);
-}
+} BX_ABI_CATCH(c, "bx_batch_evaluate_ntt")
 
-extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, bx_buf in, size_t count, size_t expand_bits) {
+extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, bx_buf in, size_t count, size_t expand_bits) try {
     if (!c) return "bx_batch_expand_into_evaluate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && in.len % count == 0 && is_pow2(in.len / count), "batch_expand_into_evaluate_ntt: in.len/count must be a power of two");
     BX_REQUIRE(c, out.len == (in.len << expand_bits), "batch_expand_into_evaluate_ntt: out.len != in.len << expand_bits");
@@ -572,9 +572,9 @@ extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, 
     OpScope op(c, "batch_expand_into_evaluate_ntt", 4.0 * (double)in.len + 4.0 * (double)out.len);
     int m = ilog2(out.len / count);
     return forward(c, (uint32_t*)out.dptr, (const uint32_t*)in.dptr, count, m, (int)expand_bits, (int)expand_bits);
-}
+} BX_ABI_CATCH(c, "bx_batch_expand_into_evaluate_ntt")
 
-extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) {
+extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_bit_reverse: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_bit_reverse: io.len/count must be a power of two");
     BX_HIP(c, hipSetDevice(c->device));
@@ -592,7 +592,7 @@ extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) 
     hipLaunchKernelGGL(bit_reverse_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint32_t*)io.dptr, n, io.len);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_batch_bit_reverse")
 
 // Bit reversal of AoS extension-field arrays (16-byte elements): one thread swaps element i with element rev(i), i < rev(i).
 __global__ void bit_reverse_ext_kernel(uint4* __restrict__ io, int n, size_t total) {
@@ -607,7 +607,7 @@ __global__ void bit_reverse_ext_kernel(uint4* __restrict__ io, int n, size_t tot
         }
     }
 }
-extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t count) {
+extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t count) try {
     if (!c) return "bx_batch_bit_reverse_ext: null ctx";
     BX_REQUIRE(c, count > 0 && io_ext.len % (4 * count) == 0 && is_pow2(io_ext.len / (4 * count)),
                "batch_bit_reverse_ext: io.len/(4*count) must be a power of two");
@@ -622,12 +622,12 @@ extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t
     hipLaunchKernelGGL(bit_reverse_ext_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, (uint4*)io_ext.dptr, n, elems);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_batch_bit_reverse_ext")
 
-extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) {
+extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_zk_shift: null ctx";
     return zk_shift_impl(c, io, count);
-}
+} BX_ABI_CATCH(c, "bx_zk_shift")
 static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count) {
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "zk_shift: io.len/count must be a power of two");
     BX_HIP(c, hipSetDevice(c->device));

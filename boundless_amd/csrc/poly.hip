@@ -610,7 +610,7 @@ static inline unsigned grid1d(size_t n, unsigned bs = 256, size_t cap = 65536) {
     return (unsigned)(b > cap ? cap : (b ? b : 1));
 }
 
-extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint32_t mix[4]) {
+extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint32_t mix[4]) try {
     if (!c) return "bx_fri_fold: null ctx";
     BX_REQUIRE(c, out.len % 4 == 0 && in.len == out.len * BX_FRI_FOLD, "fri_fold: input.len must be 16 * output.len");
     BX_HIP(c, hipSetDevice(c->device));
@@ -621,10 +621,10 @@ extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint3
                        (const uint32_t*)in.dptr, host4(mix), count);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_fri_fold")
 
 extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t mix_start[4], const uint32_t mix[4], bx_buf in,
-                                          bx_buf combos, size_t input_size, size_t count) {
+                                          bx_buf combos, size_t input_size, size_t count) try {
     if (!c) return "bx_mix_poly_coeffs: null ctx";
     BX_REQUIRE(c, in.len >= input_size * count && combos.len >= input_size, "mix_poly_coeffs: input/combos too small");
     BX_REQUIRE(c, count > 0 && out.len % (4 * count) == 0, "mix_poly_coeffs: out.len not a multiple of 4*count");
@@ -647,7 +647,7 @@ extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t 
                            (uint32_t*)out.dptr, (const uint32_t*)in.dptr, s + order_off, s + starts_off, s + pows_off, count);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_mix_poly_coeffs")
 
 static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out, bool bitrev,
                                      const char* name) {
@@ -689,18 +689,18 @@ static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
-extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
+extern "C" const char* bx_batch_evaluate_any(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) try {
     if (!c) return "bx_batch_evaluate_any: null ctx";
     return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, false, "batch_evaluate_any");
-}
-extern "C" const char* bx_batch_evaluate_any_bitrev(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) {
+} BX_ABI_CATCH(c, "bx_batch_evaluate_any")
+extern "C" const char* bx_batch_evaluate_any_bitrev(bx_ctx* c, bx_buf coeffs, size_t poly_count, bx_buf which, bx_buf xs, bx_buf out) try {
     if (!c) return "bx_batch_evaluate_any_bitrev: null ctx";
     return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, true, "batch_evaluate_any");
-}
+} BX_ABI_CATCH(c, "bx_batch_evaluate_any_bitrev")
 
 // Extension: the tap evaluations of several coefficient buffers in ONE launch set (the DEEP step evaluates columns of four
 // groups): evaluation i reads the poly_size coefficients at device address poly_ptrs[i] (bit-reversed storage when flags[i] & 1).
-extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_buf flags, size_t poly_size, bx_buf xs, bx_buf out) {
+extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_buf flags, size_t poly_size, bx_buf xs, bx_buf out) try {
     if (!c) return "bx_batch_evaluate_ptrs: null ctx";
     const size_t evals = flags.len, seg_elems = (size_t)EV_T * EV_K;
     BX_REQUIRE(c, poly_ptrs.len == 2 * evals && xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_ptrs: one pointer (two words), one flag, one point and one result per evaluation");
@@ -724,9 +724,9 @@ extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_bu
                        (uint32_t)evals);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_batch_evaluate_ptrs")
 
-extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) {
+extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) try {
     if (!c) return "bx_eltwise_add_elem: null ctx";
     BX_REQUIRE(c, out.len == a.len && a.len == b.len, "eltwise_add_elem: length mismatch");
     BX_HIP(c, hipSetDevice(c->device));
@@ -735,8 +735,8 @@ extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_b
                        (const uint32_t*)a.dptr, (const uint32_t*)b.dptr, out.len);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t factor_mont) {
+} BX_ABI_CATCH(c, "bx_eltwise_add_elem")
+extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t factor_mont) try {
     if (!c) return "bx_eltwise_mul_factor: null ctx";
     BX_REQUIRE(c, factor_mont < P, "eltwise_mul_factor: factor is not a canonical Montgomery word");
     BX_HIP(c, hipSetDevice(c->device));
@@ -745,24 +745,24 @@ extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t fact
     hipLaunchKernelGGL(eltwise_mul_factor_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, factor_mont, io.len);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-extern "C" const char* bx_eltwise_copy_elem(bx_ctx* c, bx_buf out, bx_buf in) {
+} BX_ABI_CATCH(c, "bx_eltwise_mul_factor")
+extern "C" const char* bx_eltwise_copy_elem(bx_ctx* c, bx_buf out, bx_buf in) try {
     if (!c) return "bx_eltwise_copy_elem: null ctx";
     BX_REQUIRE(c, out.len == in.len, "eltwise_copy_elem: length mismatch");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "eltwise_copy_elem", 8.0 * (double)out.len);
     BX_HIP(c, hipMemcpyAsync(out.dptr, in.dptr, out.len * 4, hipMemcpyDeviceToDevice, c->stream));
     return nullptr;
-}
-extern "C" const char* bx_eltwise_zeroize_elem(bx_ctx* c, bx_buf io) {
+} BX_ABI_CATCH(c, "bx_eltwise_copy_elem")
+extern "C" const char* bx_eltwise_zeroize_elem(bx_ctx* c, bx_buf io) try {
     if (!c) return "bx_eltwise_zeroize_elem: null ctx";
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "eltwise_zeroize_elem", 8.0 * (double)io.len);
     hipLaunchKernelGGL(eltwise_zeroize_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, io.len);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) {
+} BX_ABI_CATCH(c, "bx_eltwise_zeroize_elem")
+extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) try {
     if (!c) return "bx_eltwise_sum_extelem: null ctx";
     BX_REQUIRE(c, out.len % 4 == 0 && out.len > 0 && in.len % out.len == 0, "eltwise_sum_extelem: in.len not a multiple of out.len");
     BX_HIP(c, hipSetDevice(c->device));
@@ -772,8 +772,8 @@ extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) 
                        (uint32_t*)out.dptr, (const uint32_t*)in.dptr, count, to_add);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride) {
+} BX_ABI_CATCH(c, "bx_eltwise_sum_extelem")
+extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride) try {
     if (!c) return "bx_gather_sample: null ctx";
     BX_REQUIRE(c, dst.len >= size, "gather_sample: dst too small");
     BX_REQUIRE(c, size == 0 || idx + (size - 1) * stride < src.len, "gather_sample: source index out of range");
@@ -783,7 +783,7 @@ extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_
                        (const uint32_t*)src.dptr, idx, size, stride);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_gather_sample")
 
 // in-place division of the AoS ext array `arr` (n entries) by (x - z); `scratch` has room for every level's chunk values
 static const char* divide_rec(bx_ctx* c, uint32_t* arr, size_t n, Fp4 z, uint32_t* scratch, uint32_t* rem) {
@@ -813,7 +813,7 @@ static size_t scan_scratch_words(size_t n, size_t L, size_t direct, size_t count
     return words;
 }
 
-extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4], bx_buf rem_out) {
+extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4], bx_buf rem_out) try {
     if (!c) return "bx_poly_divide: null ctx";
     BX_REQUIRE(c, poly.len % 4 == 0 && rem_out.len >= 4, "poly_divide: poly must be AoS ext, remainder buffer >= 4 words");
     BX_HIP(c, hipSetDevice(c->device));
@@ -824,7 +824,7 @@ extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4
         return poly_divide_lookback(c, (uint32_t*)poly.dptr, size, 1, z, (uint32_t*)rem_out.dptr, nullptr);
     BX_TRY(ensure_scratch(c, scan_scratch_words(size, DIV_L, DIV_DIRECT, 1)));
     return divide_rec(c, (uint32_t*)poly.dptr, size, host4(z), c->d_scratch, (uint32_t*)rem_out.dptr);
-}
+} BX_ABI_CATCH(c, "bx_poly_divide")
 
 // exclusive running products, in place, of `count` sequences of n entries (sequence k at arr + 4 * k * stride)
 static const char* excl_scan_rec(bx_ctx* c, uint32_t* arr, size_t n, size_t stride, size_t count, uint32_t* scratch) {
@@ -845,7 +845,7 @@ static const char* excl_scan_rec(bx_ctx* c, uint32_t* arr, size_t n, size_t stri
     return nullptr;
 }
 
-extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t count) {
+extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_prefix_products: null ctx";
     BX_REQUIRE(c, io.len % 4 == 0, "prefix_products: buffer must hold AoS ext elements");
     BX_REQUIRE(c, count >= 1 && (io.len / 4) % count == 0, "prefix_products: the buffer does not split into `count` equal sequences");
@@ -866,13 +866,13 @@ extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t cou
                        c->d_scratch, chunks);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) {
+} BX_ABI_CATCH(c, "bx_batch_prefix_products")
+extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) try {
     if (!c) return "bx_prefix_products: null ctx";
     return bx_batch_prefix_products(c, io, 1);
-}
+} BX_ABI_CATCH(c, "bx_prefix_products")
 
-extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf offsets, bx_buf values) {
+extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf offsets, bx_buf values) try {
     if (!c) return "bx_scatter: null ctx";
     BX_REQUIRE(c, offsets.len == values.len, "scatter: offsets and values must have the same length");
     BX_HIP(c, hipSetDevice(c->device));
@@ -885,4 +885,4 @@ extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf o
                        into.len, c->h_flag);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_scatter")

@@ -468,7 +468,7 @@ static const char* launch_hash_fold(bx_ctx* c, uint32_t* io, size_t input_size, 
 
 using namespace bx;
 
-extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213, const uint32_t* diag24) {
+extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213, const uint32_t* diag24) try {
     if (!c) return "bx_poseidon2_set_params: null ctx";
     BX_REQUIRE(c, rc213 && diag24, "poseidon2_set_params: null table");
     // a prover snapshots the table for its host transcript at create time and bx_verify_segment uses the compiled-in one:
@@ -478,15 +478,15 @@ extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213,
     for (int i = 0; i < 213; ++i) c->h_rc[i] = rc213[i] % P;
     for (int i = 0; i < 24; ++i) c->h_diag[i] = diag24[i] % P;
     return poseidon2_upload_params(c);
-}
-extern "C" const char* bx_poseidon2_get_params(bx_ctx* c, uint32_t* rc213, uint32_t* diag24) {
+} BX_ABI_CATCH(c, "bx_poseidon2_set_params")
+extern "C" const char* bx_poseidon2_get_params(bx_ctx* c, uint32_t* rc213, uint32_t* diag24) try {
     if (!c) return "bx_poseidon2_get_params: null ctx";
     for (int i = 0; i < 213; ++i) rc213[i] = c->h_rc[i];
     for (int i = 0; i < 24; ++i) diag24[i] = c->h_diag[i];
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_poseidon2_get_params")
 
-extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) {
+extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) try {
     if (!c) return "bx_hash_rows: null ctx";
     BX_REQUIRE(c, out.len % 8 == 0, "hash_rows: digest buffer length not a multiple of 8 words");
     size_t rows = out.len / 8;
@@ -496,18 +496,18 @@ extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) {
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
     return launch_hash_rows(c, (uint32_t*)out.dptr, (const uint32_t*)matrix.dptr, rows, cols);
-}
+} BX_ABI_CATCH(c, "bx_hash_rows")
 
-extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, size_t output_size) {
+extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, size_t output_size) try {
     if (!c) return "bx_hash_fold: null ctx";
     BX_REQUIRE(c, input_size == 2 * output_size, "hash_fold: input_size must be 2*output_size");
     BX_REQUIRE(c, io.len >= (input_size + 2 * output_size) * 8, "hash_fold: digest buffer too small");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "hash_fold", 96.0 * (double)output_size);
     return launch_hash_fold(c, (uint32_t*)io.dptr, input_size, output_size);
-}
+} BX_ABI_CATCH(c, "bx_hash_fold")
 
-extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx_buf sel, size_t count) {
+extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx_buf sel, size_t count) try {
     if (!c) return "bx_hash_fold_indexed: null ctx";
     BX_REQUIRE(c, out.len >= 8 * count && sel.len >= 2 * count, "hash_fold_indexed: out or sel too small");
     BX_REQUIRE(c, count <= 0xffffffffu && in.len / 8 <= 0xffffffffu, "hash_fold_indexed: too many digests");
@@ -519,7 +519,7 @@ extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx
                        (const uint32_t*)in.dptr, (const uint32_t*)sel.dptr, c->d_p2, (uint32_t)count);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_hash_fold_indexed")
 
 // every layer above the leaves nodes[rows .. 2 rows), down to the root nodes[1]
 static const char* merkle_fold_layers(bx_ctx* c, uint32_t* n, size_t rows) {
@@ -558,7 +558,7 @@ static const char* merkle_fold_layers(bx_ctx* c, uint32_t* n, size_t rows) {
     return nullptr;
 }
 
-extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) {
+extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) try {
     if (!c) return "bx_merkle_build: null ctx";
     BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
     BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
@@ -570,12 +570,12 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
     }
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
     return merkle_fold_layers(c, n, rows);
-}
+} BX_ABI_CATCH(c, "bx_merkle_build")
 // Extension: the fold half of bx_merkle_build alone — the leaves are already in nodes[rows .. 2 rows).
-extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) {
+extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) try {
     if (!c) return "bx_merkle_fold: null ctx";
     BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_fold: nodes must hold 2*rows digests, rows a power of two");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
     return merkle_fold_layers(c, (uint32_t*)nodes.dptr, rows);
-}
+} BX_ABI_CATCH(c, "bx_merkle_fold")

@@ -208,7 +208,7 @@ Fp4 host_pow(Fp4 a, uint64_t e) { return f4_pow(a, e); }
 }  // namespace
 
 extern "C" const char* bx_merkle_query_gather(bx_ctx* c, bx_buf out, bx_buf matrix, bx_buf nodes, size_t rows, size_t cols,
-                                              bx_buf positions, size_t n_queries, size_t top_size) {
+                                              bx_buf positions, size_t n_queries, size_t top_size) try {
     if (!c) return "bx_merkle_query_gather: null ctx";
     BX_REQUIRE(c, is_pow2(rows) && is_pow2(top_size) && top_size <= rows, "merkle_query_gather: rows/top_size must be powers of two");
     BX_REQUIRE(c, matrix.len == rows * cols && nodes.len == 16 * rows, "merkle_query_gather: matrix/nodes size mismatch");
@@ -222,12 +222,12 @@ extern "C" const char* bx_merkle_query_gather(bx_ctx* c, bx_buf out, bx_buf matr
                        (const uint32_t*)positions.dptr, depth);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_merkle_query_gather")
 
-extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shape, bx_prover** out) {
+extern "C" const char* bx_prover_create(bx_ctx* c, const bx_segment_params* shape, bx_prover** out) try {
     return bx_prover_create_with_circuit(c, shape, nullptr, out);
-}
-extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment_params* shape, const bx_circuit_ops* circuit, bx_prover** out) {
+} BX_ABI_CATCH(c, "bx_prover_create")
+extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment_params* shape, const bx_circuit_ops* circuit, bx_prover** out) try {
     if (!c) return "bx_prover_create: null ctx";
     BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
     if (!circuit) circuit = bx_synthetic_circuit();
@@ -355,33 +355,33 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     c->live_provers += 1;
     *out = p.release();
     return nullptr;
-}
+} BX_ABI_CATCH(c, "bx_prover_create_with_circuit")
 
-extern "C" const char* bx_prover_destroy(bx_prover* p) {
+extern "C" const char* bx_prover_destroy(bx_prover* p) try {
     if (!p) return nullptr;
     (void)hipSetDevice(p->c->device);
     (void)hipStreamSynchronize(p->c->stream);
     p->c->live_provers -= 1;
     delete p;
     return nullptr;
-}
+} BX_ABI_CATCH(nullptr, "bx_prover_destroy")  // p may be gone by then
 extern "C" size_t bx_prover_seal_words(const bx_prover* p) { return p ? p->seal_bound : 0; }
-extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_out[32]) {
+extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_out[32]) try {
     if (!p) return "bx_prover_last_roots: null prover";
     memcpy(roots_out, p->last_roots, sizeof p->last_roots);
     return nullptr;
-}
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_last_roots")
 
 static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
-extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
+extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
     if (!p) return "bx_prove_segment: null prover";
     return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);  // the circuit derives the noise seed from the seed
-}
-extern "C" const char* bx_prove_segment_zk(bx_prover* p, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment")
+extern "C" const char* bx_prove_segment_zk(bx_prover* p, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
     if (!p) return "bx_prove_segment_zk: null prover";
     if (p->circ->set_noise_seed) p->circ->set_noise_seed(p->circ->user, p->circ_state, noise_seed);
     return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);
-}
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment_zk")
 static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
     bx_ctx* c = p->c;
     if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prove_segment: hipSetDevice failed");

@@ -23,6 +23,9 @@
 // update; an element's map is affine with a known slope (z), so a span of L elements is (z^L, B) and only B is scanned or
 // published — the slopes z^8, z^16 .. z^2048, z^(2048*64) come from the host as kernel arguments.
 #define BX_PLAIN_MAD 1  // the signed multiply-adds of lazy_ext.hpp are left to the compiler here
+#include <algorithm>
+#include <vector>
+
 #include "ctx.hpp"
 #include "lazy_ext.hpp"
 
@@ -367,7 +370,7 @@ const char* prefix_products_lookback(bx_ctx* c, uint32_t* io, size_t n, size_t c
 
 using namespace bx;
 
-extern "C" const char* bx_poly_divide_batch(bx_ctx* c, bx_buf polys, size_t count, const uint32_t* zs, bx_buf rems_out) {
+extern "C" const char* bx_poly_divide_batch(bx_ctx* c, bx_buf polys, size_t count, const uint32_t* zs, bx_buf rems_out) try {
     if (!c) return "bx_poly_divide_batch: null ctx";
     BX_REQUIRE(c, count >= 1 && count <= 65535 && polys.len % (4 * count) == 0, "poly_divide_batch: the buffer does not split into `count` AoS ext polynomials");
     BX_REQUIRE(c, zs != nullptr && rems_out.len >= 4 * count, "poly_divide_batch: one point and one remainder slot per polynomial");
@@ -377,20 +380,22 @@ extern "C" const char* bx_poly_divide_batch(bx_ctx* c, bx_buf polys, size_t coun
     if (!size) return nullptr;
     OpScope op(c, "poly_divide", 8.0 * (double)polys.len);
     return poly_divide_lookback(c, (uint32_t*)polys.dptr, size, count, zs, (uint32_t*)rems_out.dptr, nullptr);
-}
+} BX_ABI_CATCH(c, "bx_poly_divide_batch")
 extern "C" const char* bx_poly_divide_batch_indexed(bx_ctx* c, bx_buf polys, size_t n_polys, size_t count, const uint32_t* which, const uint32_t* zs,
-                                                    bx_buf rems_out) {
+                                                    bx_buf rems_out) try {
     if (!c) return "bx_poly_divide_batch_indexed: null ctx";
     BX_REQUIRE(c, n_polys >= 1 && polys.len % (4 * n_polys) == 0, "poly_divide_batch_indexed: the buffer does not split into n_polys AoS ext polynomials");
     BX_REQUIRE(c, count <= 65535 && which != nullptr && zs != nullptr && rems_out.len >= 4 * count, "poly_divide_batch_indexed: one index, one point and one remainder slot per division");
     BX_REQUIRE(c, ((uintptr_t)polys.dptr & 15u) == 0 && ((uintptr_t)rems_out.dptr & 15u) == 0, "poly_divide_batch_indexed: buffers must be 16-byte aligned");
-    for (size_t q = 0; q < count; ++q) {
-        BX_REQUIRE(c, which[q] < n_polys, "poly_divide_batch_indexed: polynomial index out of range");
-        for (size_t r = 0; r < q; ++r) BX_REQUIRE(c, which[r] != which[q], "poly_divide_batch_indexed: a polynomial may be divided once per call");
+    for (size_t q = 0; q < count; ++q) BX_REQUIRE(c, which[q] < n_polys, "poly_divide_batch_indexed: polynomial index out of range");
+    {
+        std::vector<uint32_t> seen(which, which + count);
+        std::sort(seen.begin(), seen.end());
+        BX_REQUIRE(c, std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "poly_divide_batch_indexed: a polynomial may be divided once per call");
     }
     BX_HIP(c, hipSetDevice(c->device));
     const size_t size = polys.len / 4 / n_polys;
     if (!size || !count) return nullptr;
     OpScope op(c, "poly_divide", 32.0 * (double)size * (double)count);
     return poly_divide_lookback(c, (uint32_t*)polys.dptr, size, count, zs, (uint32_t*)rems_out.dptr, which);
-}
+} BX_ABI_CATCH(c, "bx_poly_divide_batch_indexed")
