@@ -234,16 +234,29 @@ int main() {
                 uint64_t r = rnd64();
                 a[i] = t < 2000 ? pool[r % 8] : (t == 2000 ? P - 1 : (uint32_t)(r % P));
             }
+            uint32_t v[24];
             memcpy(b, a, sizeof a);
-            ref.mix(a);
+            memcpy(v, a, sizeof a);
+            ref.mix_scalar(a);
             poseidon2_mix_bounded<216>(b, prm);
             REQUIRE(memcmp(a, b, sizeof a) == 0);
+            ref.mix(v);  // the AVX2 form where the CPU has it (the transcript's and the verifier's), else the scalar one again
+            REQUIRE(memcmp(a, v, sizeof a) == 0);
         }
         // published KAT through the bounded form
         uint32_t k[24];
         for (int i = 0; i < 24; ++i) k[i] = fp_encode((uint32_t)i);
         poseidon2_mix_bounded<216>(k, prm);
         REQUIRE(fp_decode(k[0]) == 0x2ed3e23du && fp_decode(k[1]) == 0x12921fb0u && fp_decode(k[23]) == 0x57a99864u);
+    }
+    {   // the host permutation the prover's transcript and the verifier run (vector form where available): published KAT
+        HostPoseidon2 h;
+        h.load(POSEIDON2_RC, POSEIDON2_DIAG);
+        uint32_t k[24];
+        for (int i = 0; i < 24; ++i) k[i] = fp_encode((uint32_t)i);
+        h.mix(k);
+        REQUIRE(fp_decode(k[0]) == 0x2ed3e23du && fp_decode(k[1]) == 0x12921fb0u && fp_decode(k[23]) == 0x57a99864u);
+        printf("host permutation: %s form\n", h.vec ? "AVX2" : "scalar");
     }
     printf("host_arith_check ok\n");
     return 0;
