@@ -209,6 +209,22 @@ extern "C" const char* bx_init(int device, bx_ctx** out) try {
         for (int i = 0; i < 24; ++i) c->h_diag[i] = POSEIDON2_DIAG[i];
         m = poseidon2_upload_params(c);
     }
+    if (!m) {
+        // BX_TUNABLES="name=value,name=value": bx_set_tunable for every ctx of the process (A/B runs of an unmodified caller)
+        if (const char* tv = getenv("BX_TUNABLES")) {
+            std::string all(tv);
+            size_t pos = 0;
+            while (!m && pos < all.size()) {
+                size_t end = all.find(',', pos);
+                if (end == std::string::npos) end = all.size();
+                const std::string item = all.substr(pos, end - pos);
+                const size_t eq = item.find('=');
+                if (eq == std::string::npos || eq == 0) m = "BX_TUNABLES: expected name=value[,name=value...]";
+                else m = bx_set_tunable(c, item.substr(0, eq).c_str(), strtol(item.c_str() + eq + 1, nullptr, 10));
+                pos = end + 1;
+            }
+        }
+    }
     if (m) {
         snprintf(init_err, sizeof init_err, "bx_init: %s", m);
         bx_free(c);
@@ -452,6 +468,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
     } else if (!strcmp(name, "fold_deep")) {
         BX_REQUIRE(c, value >= 1 && value <= 3, "fold_deep must be 1, 2 or 3");
         c->fold_deep = value;
+    } else if (!strcmp(name, "dev_draws")) {
+        BX_REQUIRE(c, value == 0 || value == 1, "dev_draws must be 0 or 1");
+        c->dev_draws = value;
     } else if (!strcmp(name, "fold_deep_min_lanes")) {
         BX_REQUIRE(c, value >= 1, "fold_deep_min_lanes must be positive");
         c->fold_deep_min_lanes = value;

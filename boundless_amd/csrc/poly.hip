@@ -28,9 +28,10 @@ __device__ __forceinline__ void st4(uint32_t* p, const Fp4& a) {
 
 // ---- fri_fold: out[k*count + idx] = sum_i mix^i * in[(k*16 + rev4(i))*count + idx] ----
 __global__ __launch_bounds__(256) void fri_fold_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, Fp4 mix,
-                                                       size_t count) {
+                                                       const uint32_t* __restrict__ mix_dev, size_t count) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
+    if (mix_dev) mix = Fp4{{mix_dev[0], mix_dev[1], mix_dev[2], mix_dev[3]}};  // a challenge drawn on the device (bx_transcript_step)
     // Horner from the highest power keeps one running product: tot = (((f15*mix + f14)*mix + ...)*mix + f0
     Fp4 tot = f4_zero();
 #pragma unroll
@@ -618,10 +619,23 @@ extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint3
     OpScope op(c, "fri_fold", 4.0 * (double)(in.len + out.len));
     if (!count) return nullptr;
     hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
-                       (const uint32_t*)in.dptr, host4(mix), count);
+                       (const uint32_t*)in.dptr, host4(mix), (const uint32_t*)nullptr, count);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 } BX_ABI_CATCH(c, "bx_fri_fold")
+extern "C" const char* bx_fri_fold_dev(bx_ctx* c, bx_buf out, bx_buf in, bx_buf mix_ext) try {
+    if (!c) return "bx_fri_fold_dev: null ctx";
+    BX_REQUIRE(c, out.len % 4 == 0 && in.len == out.len * BX_FRI_FOLD, "fri_fold_dev: input.len must be 16 * output.len");
+    BX_REQUIRE(c, mix_ext.dptr != nullptr && mix_ext.len >= 4, "fri_fold_dev: mix is one ext element in device memory");
+    BX_HIP(c, hipSetDevice(c->device));
+    size_t count = out.len / 4;
+    OpScope op(c, "fri_fold", 4.0 * (double)(in.len + out.len));
+    if (!count) return nullptr;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
+                       (const uint32_t*)in.dptr, f4_zero(), (const uint32_t*)mix_ext.dptr, count);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+} BX_ABI_CATCH(c, "bx_fri_fold_dev")
 
 extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t mix_start[4], const uint32_t mix[4], bx_buf in,
                                           bx_buf combos, size_t input_size, size_t count) try {

@@ -437,6 +437,45 @@ __global__ __launch_bounds__(1024) void hash_fold_quad_kernel(uint32_t* __restri
     }
 }
 
+// One step of the Fiat-Shamir transcript on the device (transcript.hpp's Transcript::commit / random_elem, i.e. risc0_zkp's
+// Poseidon2Rng): four lanes hold the 24 cells as poseidon2_mix_quad wants them (lane q: cells 4k + q).  A step is 1-2 sequential
+// permutations (8.7 us each on a quad) against ~150 us for the host round trip it replaces; the long sponges of the transcript
+// (coeff_u, the final coefficients) stay on the host, where a permutation takes ~1 us.
+__global__ __launch_bounds__(64) void transcript_step_kernel(uint32_t* __restrict__ state, const uint32_t* __restrict__ digests, uint32_t n_commit,
+                                                            uint32_t* __restrict__ out, uint32_t n_elems, const uint32_t* __restrict__ prm) {
+    __shared__ uint32_t shp[DIAG_OFF + 24];
+    const uint32_t tid = threadIdx.x, q = tid & 3;
+    for (uint32_t i = tid; i < DIAG_OFF + 24; i += blockDim.x) shp[i] = prm[i];
+    __syncthreads();
+    if (tid >= 4) return;
+    uint32_t s[QS];
+#pragma unroll
+    for (int k = 0; k < QS; ++k) s[k] = state[4 * k + q];
+    uint32_t pool = state[24];
+    for (uint32_t i = 0; i < n_commit; ++i) {
+        if (pool != 0) {  // elements were handed out since the last permutation: the pool is discarded first
+            poseidon2_mix_quad(s, shp, q);
+            pool = 0;
+        }
+        s[0] = fp_add(s[0], digests[8 * i + q]);
+        s[1] = fp_add(s[1], digests[8 * i + 4 + q]);
+        poseidon2_mix_quad(s, shp, q);
+    }
+    for (uint32_t e = 0; e < n_elems; ++e) {
+        if (pool == 16) {
+            poseidon2_mix_quad(s, shp, q);
+            pool = 0;
+        }
+        const uint32_t slot = pool >> 2;
+        const uint32_t v = slot == 0 ? s[0] : slot == 1 ? s[1] : slot == 2 ? s[2] : s[3];
+        if ((pool & 3u) == q) out[e] = v;
+        ++pool;
+    }
+#pragma unroll
+    for (int k = 0; k < QS; ++k) state[4 * k + q] = s[k];
+    if (q == 0) state[24] = pool;
+}
+
 const char* poseidon2_upload_params(bx_ctx* c) {
     uint32_t h[DIAG_OFF + 24] = {0};
     // round constants ride in REDC accumulators, pre-scaled to the representation of the round they are added in
@@ -579,3 +618,17 @@ extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) try 
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
     return merkle_fold_layers(c, (uint32_t*)nodes.dptr, rows);
 } BX_ABI_CATCH(c, "bx_merkle_fold")
+
+extern "C" const char* bx_transcript_step(bx_ctx* c, bx_buf state, bx_buf digests, size_t n_commit, bx_buf out_ext, size_t n_ext) try {
+    if (!c) return "bx_transcript_step: null ctx";
+    BX_REQUIRE(c, state.dptr != nullptr && state.len >= 25, "transcript_step: the state is 24 cells and the pool counter");
+    BX_REQUIRE(c, digests.len >= 8 * n_commit && out_ext.len >= 4 * n_ext, "transcript_step: digests / out too small");
+    BX_REQUIRE(c, n_commit <= 64 && n_ext <= 64, "transcript_step: at most 64 commits and 64 challenges per step");
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!n_commit && !n_ext) return nullptr;
+    OpScope op(c, "transcript_step", 4.0 * (double)(50 + 8 * n_commit + 4 * n_ext));
+    hipLaunchKernelGGL(transcript_step_kernel, dim3(1), dim3(64), 0, c->stream, (uint32_t*)state.dptr, (const uint32_t*)digests.dptr, (uint32_t)n_commit,
+                       (uint32_t*)out_ext.dptr, (uint32_t)(4 * n_ext), c->d_p2);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+} BX_ABI_CATCH(c, "bx_transcript_step")

@@ -116,6 +116,7 @@ struct bx_prover {
     }
     std::vector<FriRound> rounds;
     DevBuf final_coeffs;
+    DevBuf tstate, dev_chal;  // device half of the transcript: 24 cells + pool counter; the challenges it drew (4 words per step)
     uint32_t last_roots[32];
     size_t seal_bound = 0;
     char err[512];
@@ -335,6 +336,8 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
         size /= BX_FRI_FOLD;
     }
     BX_TRY(p->final_coeffs.alloc(c, 4 * size));
+    BX_TRY(p->tstate.alloc(c, 32));
+    BX_TRY(p->dev_chal.alloc(c, 4 * (p->rounds.size() + 4)));
     size_t max_q = 0, trace_query_words = 0;
     for (int g = 0; g < 4; ++g) {
         max_q = std::max(max_q, p->groups[g].tree.query_words());
@@ -617,18 +620,54 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
     stage.next("bx:fri_prove");
     {
         bx_buf coeffs = p->final_poly.b;
+        const bool dev = c->dev_draws != 0 && !p->rounds.empty();
+        if (dev) {
+            // A round's challenge depends on nothing but the round's root, so the device half of the transcript draws it
+            // (bx_transcript_step: 1-2 permutations on one quad, ~20 us) and the fold reads it from device memory: no host round trip
+            // inside the loop.  Roots, top layers, the drawn challenges and the final coefficients come back in ONE copy after the
+            // loop; the host transcript then replays the same commits (it writes the seal) and must draw the same words.
+            uint32_t st[25];
+            memcpy(st, T.cells, sizeof T.cells);
+            st[24] = T.pool_used;
+            PV(h2d_staged(c, p->tstate.slice(0, 25), st, 25));
+        }
+        size_t ri = 0;
         for (FriRound& r : p->rounds) {
             PV(bx_batch_expand_into_evaluate_ntt(c, r.evaluated.b, coeffs, 4, 2));
-            PV(tree_commit(p, r.tree, r.evaluated.b, T));
-            Fp4 fold_mix = T.random_ext();
-            PV(bx_fri_fold(c, r.out_coeffs.b, coeffs, fold_mix.c));
+            if (dev) {
+                PV(tree_build(p, r.tree, r.evaluated.b));
+                PV(bx_transcript_step(c, p->tstate.b, r.tree.nodes.slice(8, 8), 1, p->dev_chal.slice(4 * ri, 4), 1));
+                PV(bx_fri_fold_dev(c, r.out_coeffs.b, coeffs, p->dev_chal.slice(4 * ri, 4)));
+            } else {
+                PV(tree_commit(p, r.tree, r.evaluated.b, T));
+                Fp4 fold_mix = T.random_ext();
+                PV(bx_fri_fold(c, r.out_coeffs.b, coeffs, fold_mix.c));
+            }
             coeffs = r.out_coeffs.b;
+            ++ri;
         }
         PV(bx_eltwise_copy_elem(c, p->final_coeffs.b, coeffs));
         PV(bx_batch_bit_reverse(c, p->final_coeffs.b, 4));
-        std::vector<uint32_t> fc(p->final_coeffs.b.len);
+        const size_t nfc = p->final_coeffs.b.len;
+        std::vector<uint32_t> fc(nfc);
         uint32_t dg[8];
-        PV(bx_d2h(c, fc.data(), p->final_coeffs.b, fc.size()));
+        if (dev) {
+            size_t used = 0;
+            std::vector<const uint32_t*> host(p->rounds.size(), nullptr);
+            const uint32_t *fc_host = nullptr, *chal = nullptr;
+            for (size_t i = 0; i < p->rounds.size(); ++i) PV(tree_fetch(p, p->rounds[i].tree, &used, &host[i]));
+            PV(d2h_batch_add(c, &used, p->dev_chal.slice(0, 4 * p->rounds.size()), 4 * p->rounds.size(), &chal));
+            PV(d2h_batch_add(c, &used, p->final_coeffs.b, nfc, &fc_host));
+            PV(d2h_batch_wait(c));
+            for (size_t i = 0; i < p->rounds.size(); ++i) {
+                tree_absorb(p->rounds[i].tree, host[i], T);
+                const Fp4 fold_mix = T.random_ext();
+                if (memcmp(fold_mix.c, chal + 4 * i, 16) != 0) return perr(p, "bx_prove_segment: the device transcript drew a different FRI challenge than the host transcript");
+            }
+            memcpy(fc.data(), fc_host, nfc * 4);
+        } else {
+            PV(bx_d2h(c, fc.data(), p->final_coeffs.b, fc.size()));
+        }
         T.write(fc.data(), fc.size());
         p->h2.hash_elems(dg, fc.data(), fc.size());
         T.commit(dg);

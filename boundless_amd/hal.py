@@ -79,6 +79,8 @@ def load_library():
         "bx_merkle_build": [ctx, BxBuf, BxBuf, sz],
         "bx_merkle_fold": [ctx, BxBuf, sz],
         "bx_fri_fold": [ctx, BxBuf, BxBuf, u32p],
+        "bx_fri_fold_dev": [ctx, BxBuf, BxBuf, BxBuf],
+        "bx_transcript_step": [ctx, BxBuf, BxBuf, sz, BxBuf, sz],
         "bx_mix_poly_coeffs": [ctx, BxBuf, u32p, u32p, BxBuf, BxBuf, sz, sz],
         "bx_batch_evaluate_any": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
         "bx_batch_evaluate_any_bitrev": [ctx, BxBuf, sz, BxBuf, BxBuf, BxBuf],
@@ -275,6 +277,14 @@ class HipHal:
     def fri_fold(self, output, inp, mix):
         _, m = _words(mix)
         self._check(self.lib.bx_fri_fold(self.ctx, output.raw, inp.raw, m))
+
+    def fri_fold_dev(self, output, inp, mix_buf):
+        """fri_fold with the challenge in device memory (4 words), e.g. one drawn by `transcript_step`."""
+        self._check(self.lib.bx_fri_fold_dev(self.ctx, output.raw, inp.raw, mix_buf.raw))
+
+    def transcript_step(self, state, digests, n_commit, out_ext, n_ext):
+        """Poseidon2Rng on the device: commit n_commit digests, then draw n_ext ext challenges into out_ext; state = 25 words."""
+        self._check(self.lib.bx_transcript_step(self.ctx, state.raw, digests.raw, n_commit, out_ext.raw, n_ext))
 
     def mix_poly_coeffs(self, output, mix_start, mix, inp, combos, input_size, count):
         _, ms = _words(mix_start)

@@ -110,6 +110,16 @@ const char* bx_merkle_fold(bx_ctx* ctx, bx_buf nodes_digests, size_t rows);
 /* ---- Hal FRI / DEEP family ---- */
 /* Hal::fri_fold(output, input, mix): SoA planes; input.len = 16*output.len. `mix` = 4 host words. */
 const char* bx_fri_fold(bx_ctx* ctx, bx_buf out, bx_buf in, const uint32_t mix[4]);
+/* Extension: the same with `mix` in device memory (4 words), so that a challenge drawn on the device (bx_transcript_step) feeds
+ * the fold without a host round trip. */
+const char* bx_fri_fold_dev(bx_ctx* ctx, bx_buf out, bx_buf in, bx_buf mix_ext);
+/* Extension: one step of the Fiat-Shamir transcript on the device (risc0_zkp Poseidon2Rng: `mix(digest)` n_commit times, then
+ * `random_elem` 4 * n_ext times).  state = 25 words: the 24 sponge cells (Montgomery) and the number of rate cells already handed
+ * out; digests = n_commit x 8 words (a Merkle root as the tree holds it: nodes[8..16)); out_ext receives the n_ext challenges.
+ * Enqueued like everything else: the prover uses it where a challenge depends on nothing but a root (the FRI rounds), reads roots,
+ * top layers and the drawn challenges back later in ONE copy, and replays the same steps on the host transcript (which also
+ * writes the seal), checking that both sides drew the same words. */
+const char* bx_transcript_step(bx_ctx* ctx, bx_buf state25, bx_buf digests, size_t n_commit, bx_buf out_ext, size_t n_ext);
 /* Hal::mix_poly_coeffs(output, mix_start, mix, input, combos, input_size, count):
  * out_ext[combos[i]*count + idx] += mix_start*mix^i * in[i*count + idx], i < input_size, idx < count. */
 const char* bx_mix_poly_coeffs(bx_ctx* ctx, bx_buf out_ext, const uint32_t mix_start[4],

@@ -106,6 +106,10 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
  * noise_seed = splitmix64(seed ^ 0x5A4B4E4F49534521). */
 uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
                                uint64_t seed, uint64_t noise_seed, size_t* seal_words, uint32_t roots_out[32]);
+/* the transcript's RNG alone ([EXT] Poseidon2Rng): state = 24 cells + the number of rate cells already handed out; `mix(digest)`
+ * n_commit times, then `random_elem` n_elems times.  What the prover's iop_commit / iop_random_elem do, exported so that the
+ * device-side step (bx_transcript_step) can be checked on its own. */
+void bxo_transcript_step(uint32_t state[25], const uint32_t* digests, size_t n_commit, uint32_t* out, size_t n_elems);
 /* test hook: add 1 to witness cell (group, col, row) before it is committed, making the proved statement false (group < 0: off) */
 void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
 void bxo_free(void* p);

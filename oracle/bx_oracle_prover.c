@@ -72,6 +72,17 @@ static uint32_t iop_random_bits(iop_t* io, unsigned bits) {
     return val & (uint32_t)(((uint64_t)1 << bits) - 1);
 }
 
+void bxo_transcript_step(uint32_t state[25], const uint32_t* digests, size_t n_commit, uint32_t* out, size_t n_elems) {
+    iop_t io;
+    memset(&io, 0, sizeof io);
+    memcpy(io.cells, state, sizeof io.cells);
+    io.pool_used = state[24];
+    for (size_t i = 0; i < n_commit; i++) iop_commit(&io, digests + 8 * i);
+    for (size_t e = 0; e < n_elems; e++) out[e] = iop_random_elem(&io);
+    memcpy(state, io.cells, sizeof io.cells);
+    state[24] = io.pool_used;
+}
+
 /* ---- ext helpers on top of the oracle field ---- */
 static e4 e4mul(e4 a, e4 b) { e4 r; bxo_fp4_mul(r.c, a.c, b.c); return r; }
 static e4 e4inv(e4 a) { e4 r; bxo_fp4_inv(r.c, a.c); return r; }

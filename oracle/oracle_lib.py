@@ -74,6 +74,7 @@ def lib(path=None):
         "bxo_prove_segment": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_prove_segment_ex": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_prove_segment_zk": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
+        "bxo_transcript_step": ([u32p, u32p, sz, u32p, sz], None),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
         "bxo_free": ([C.c_void_p], None),
         "bxo_compute_image_id": ([C.c_char_p, sz, C.c_char_p, u32p], C.c_int),
@@ -129,6 +130,16 @@ def prove_segment(po2, w_code, w_data, w_accum, seed, L=None, terms=0, degree=0,
     seal = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
     L.bxo_free(ptr)
     return seal, roots.reshape(4, 8)
+
+
+def transcript_step(state25, digests, n_elems, L=None):
+    """Poseidon2Rng: commit every digest (rows of 8 words), then draw n_elems field elements -> (new state, elements)."""
+    L = L or lib()
+    st = np.ascontiguousarray(state25, dtype=np.uint32).copy()
+    dg = np.ascontiguousarray(digests, dtype=np.uint32).reshape(-1)
+    out = np.zeros(max(n_elems, 1), np.uint32)
+    L.bxo_transcript_step(st, dg if dg.size else np.zeros(8, np.uint32), dg.size // 8, out, n_elems)
+    return st, out[:n_elems]
 
 
 def compute_image_id(blob, L=None):

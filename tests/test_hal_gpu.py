@@ -332,6 +332,28 @@ def test_fri_fold_vs_oracle(hal, oracle, count):
     assert np.array_equal(out.view(), ref)
 
 
+def test_transcript_step_and_fri_fold_dev_vs_oracle(hal, oracle):
+    """The device half of the Fiat-Shamir transcript (Poseidon2Rng: commit digests, hand out rate cells, permute when the pool runs
+    dry or was touched) word for word against the oracle's, through chained steps of every shape; a fold fed by a challenge drawn
+    on the device equals the fold fed the same words from the host."""
+    rng = np.random.default_rng(77)
+    state = np.zeros(25, np.uint32)
+    d_state = hal.copy_from(state)
+    for n_commit, n_ext in [(1, 1), (2, 1), (1, 4), (0, 3), (1, 0), (3, 5), (0, 1), (2, 2), (1, 16), (1, 1)]:
+        digests = rng.integers(0, ol.P, (max(n_commit, 1), 8), dtype=np.uint32)
+        out = hal.alloc(4 * max(n_ext, 1))
+        hal.transcript_step(d_state, hal.copy_from(digests.reshape(-1)), n_commit, out, n_ext)
+        state, want = ol.transcript_step(state, digests[:n_commit], 4 * n_ext)
+        assert np.array_equal(d_state.view(), state), (n_commit, n_ext)
+        assert np.array_equal(out.view()[: 4 * n_ext], want), (n_commit, n_ext)
+    count = 1000
+    x = rnd(count, 64 * count)
+    got, ref = hal.alloc(4 * count), hal.alloc(4 * count)
+    hal.fri_fold_dev(got, hal.copy_from(x), out)  # `out` holds the last challenge drawn above
+    hal.fri_fold(ref, hal.copy_from(x), out.view()[:4].copy())
+    assert np.array_equal(got.view(), ref.view())
+
+
 def test_fri_fold_golden(hal, golden_dir):
     g = json.load(open(os.path.join(golden_dir, "fri_vectors.json")))["fold"]
     f = g["coeffs_natural"]

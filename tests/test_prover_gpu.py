@@ -143,6 +143,29 @@ def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
     assert np.array_equal(seals[1], want)
 
 
+@pytest.mark.parametrize("po2", [10, 13, 17])
+def test_challenges_drawn_on_the_device_give_the_seal_of_the_host_transcript(po2):
+    """`dev_draws` = 1 (default): the challenges that depend only on a Merkle root are drawn by the device half of the transcript and
+    the host replays them from one late read-back; 0: every draw waits for its root on the host.  Same seal, equal to the oracle's
+    (po2 10 has a single FRI round, 17 three)."""
+    from boundless_amd.hal import HipHal
+    from boundless_amd.prover import HipProverServer, Segment
+
+    seals = []
+    for flag in (0, 1):
+        hal = HipHal(0)
+        hal.set_tunable("dev_draws", flag)
+        srv = HipProverServer(0, po2=po2, widths=(3, 9, 4), hal=hal)
+        try:
+            seals.append(srv.prove_segment(Segment(0, po2, 1717)).seal)
+            seals.append(srv.prove_segment(Segment(1, po2, 1718)).seal)  # the device state is re-seeded by every proof
+        finally:
+            srv.close()
+    assert np.array_equal(seals[0], seals[2]) and np.array_equal(seals[1], seals[3])
+    want, _ = ol.prove_segment(po2, 3, 9, 4, 1717)
+    assert np.array_equal(seals[2], want)
+
+
 def test_roctx_ranges_do_not_change_the_seal():
     """bx_trace_enable: ranges only (1) and ranges + a stream drain per stage (2) give the seal of the untraced run."""
     from boundless_amd import hal as H

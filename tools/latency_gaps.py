@@ -31,6 +31,9 @@ def main(path, out):
         seg = rows[a:b]
         busy_full = busy_small = idle = 0
         small = defaultdict(float)
+        edges = [5, 10, 20, 50, 100, 200]  # us
+        hist = [[0, 0.0] for _ in range(len(edges) + 1)]
+        gaps = []
         for i, (s, e, name, wg) in enumerate(seg):
             d = (e - s) / 1e6
             if wg >= 1024:
@@ -39,10 +42,18 @@ def main(path, out):
                 busy_small += d
                 small[name.split("(")[0][:60]] += d
             if i + 1 < len(seg):
-                idle += max(0, seg[i + 1][0] - e) / 1e6
+                g = max(0, seg[i + 1][0] - e) / 1e3  # us
+                idle += g / 1e3
+                b = sum(g >= x for x in edges)
+                hist[b][0] += 1
+                hist[b][1] += g
+                gaps.append((g, name.split("(")[0][:40], seg[i + 1][2].split("(")[0][:40]))
         res["proofs"].append({"kernels": len(seg), "ms_in_chip_filling_kernels": round(busy_full, 3), "ms_in_underfilled_kernels": round(busy_small, 3),
                               "ms_idle_between_kernels": round(idle, 3), "ms_first_to_last": round((seg[-1][1] - seg[0][0]) / 1e6, 3),
-                              "underfilled_by_kernel_ms": {k: round(v, 3) for k, v in sorted(small.items(), key=lambda kv: -kv[1])[:12]}})
+                              "underfilled_by_kernel_ms": {k: round(v, 3) for k, v in sorted(small.items(), key=lambda kv: -kv[1])[:12]},
+                              "idle_gap_histogram_us": {("<%d" % edges[0] if k == 0 else (">=%d" % edges[-1] if k == len(edges) else "%d-%d" % (edges[k - 1], edges[k]))):
+                                                        {"gaps": h[0], "ms": round(h[1] / 1e3, 3)} for k, h in enumerate(hist)},
+                              "largest_gaps_us": [{"us": round(g, 1), "after": a_, "before": b_} for g, a_, b_ in sorted(gaps, reverse=True)[:14]]})
     if res["proofs"]:
         res["proofs"] = [sorted(res["proofs"], key=lambda p: p["ms_first_to_last"])[len(res["proofs"]) // 2]]
     json.dump(res, open(out, "w"), indent=1)
