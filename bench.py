@@ -384,7 +384,12 @@ def main():
             ms = r["ms"] / max(r["calls"], 1)
             gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             iso_k[name] = {"avg_ms": round(ms, 4), "ms_per_segment": round(r["ms"], 3), "alg_GBps": round(gbps, 1),
-                           "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
+                           "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4), "calls": r["calls"],
+                           "alg_MB_per_call": round(r["alg_bytes"] / max(r["calls"], 1) / 1e6, 2)}
+            # an entry point whose average call moves a few MB in a few tens of microseconds is bounded by launch and ramp latency,
+            # not by HBM: its frac_hbm is printed for completeness and means nothing
+            if ms < 0.04:
+                iso_k[name]["latency_bound"] = True
         # HBM traffic of the LDE's two kernels from the committed PMC passes of this same command (separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/pmc_traffic.py); None when the file is absent
         traffic = None
