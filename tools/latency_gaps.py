@@ -6,8 +6,12 @@ Splits the busiest stream's timeline of the last proof-sized window into: time i
 between consecutive kernels (host round trips, launch latency)."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from boundless_amd.build import csrc_hash  # noqa: E402
 
 
 def main(path, out):
@@ -26,7 +30,7 @@ def main(path, out):
     rows.sort()
     # proofs are separated by the longest idle gaps; take the kernels between occurrences of witness_code_kernel
     starts = [i for i, r in enumerate(rows) if "witness_code_kernel" in r[2]]
-    res = {"note": "one segment in flight; per proof (median over the proofs of the run)", "proofs": []}
+    res = {"csrc_sha": csrc_hash(), "note": "one segment in flight; per proof (median over the proofs of the run)", "proofs": []}
     for a, b in zip(starts[:-1], starts[1:]):
         seg = rows[a:b]
         busy_full = busy_small = idle = 0

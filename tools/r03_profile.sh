@@ -30,3 +30,10 @@ rm -rf $O/pmc_valu
 python tools/helperbench.py > $O/r03_helperbench.jsonl
 head -14 $O/r03_bench_kernel_stats_default_cmd.csv | cut -c1-150
 cat $O/r03_inflight_sweep.jsonl
+# 5. A/B of the device-side FRI challenges, and the gap histogram of a lone proof under both settings
+bash tools/ab_inflight.sh dev_draws 0 1 > $O/r03_ab_dev_draws.jsonl
+for d in 0 1; do
+  BX_TUNABLES=dev_draws=$d rocprofv3 --kernel-trace --output-format csv -d $O/ktd$d -o kt -- $B --inflight 1 > /dev/null 2>&1
+  python tools/latency_gaps.py "$(find $O/ktd$d -name "*kernel_trace.csv" | head -1)" $O/r03_latency_gaps_dev_draws$d.json > /dev/null
+  rm -rf $O/ktd$d
+done
