@@ -96,7 +96,8 @@ struct bx_ctx {
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
     long hash_rows_block = 256;
     long fold_deep = 2;              // large Merkle layers: up to this many levels per launch, depth first per lane (1 = one launch per layer)
-    long dev_draws = 1;  // the prover draws the challenges that depend only on a Merkle root on the device (bx_transcript_step); 0 = every draw on the host
+    long dev_draws = 0;  // 1 = the prover draws the FRI challenges (which depend only on a Merkle root) on the device (bx_transcript_step): three blocking
+                         // waits fewer per proof, same seal — and measured no faster while the host polls 25-45 % longer (profiles/r03_ab_dev_draws.jsonl), so off
     long fold_deep_min_lanes = 1 << 17;  // ... as long as the launch still has this many lanes (measured: tools/foldbench2.py, profiles/r03_foldbench.jsonl)
     long fold_quad = 1;              // small Merkle layers: four lanes per node (hash_fold_quad_kernel) instead of one
     long fold_quad_wg = 512;         // ... input digests per workgroup of that kernel (a power of two, 16..512)

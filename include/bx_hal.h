@@ -116,7 +116,8 @@ const char* bx_fri_fold_dev(bx_ctx* ctx, bx_buf out, bx_buf in, bx_buf mix_ext);
 /* Extension: one step of the Fiat-Shamir transcript on the device (risc0_zkp Poseidon2Rng: `mix(digest)` n_commit times, then
  * `random_elem` 4 * n_ext times).  state = 25 words: the 24 sponge cells (Montgomery) and the number of rate cells already handed
  * out; digests = n_commit x 8 words (a Merkle root as the tree holds it: nodes[8..16)); out_ext receives the n_ext challenges.
- * Enqueued like everything else: the prover uses it where a challenge depends on nothing but a root (the FRI rounds), reads roots,
+ * Enqueued like everything else: with the tunable `dev_draws` = 1 the prover uses it where a challenge depends on nothing but a root
+ * (the FRI rounds; measured no faster than the host round trips on MI355X, hence off by default), reads roots,
  * top layers and the drawn challenges back later in ONE copy, and replays the same steps on the host transcript (which also
  * writes the seal), checking that both sides drew the same words. */
 const char* bx_transcript_step(bx_ctx* ctx, bx_buf state25, bx_buf digests, size_t n_commit, bx_buf out_ext, size_t n_ext);

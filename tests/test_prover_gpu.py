@@ -145,8 +145,8 @@ def test_deep_phase_in_natural_and_in_bit_reversed_order_give_the_same_seal():
 
 @pytest.mark.parametrize("po2", [10, 13, 17])
 def test_challenges_drawn_on_the_device_give_the_seal_of_the_host_transcript(po2):
-    """`dev_draws` = 1 (default): the challenges that depend only on a Merkle root are drawn by the device half of the transcript and
-    the host replays them from one late read-back; 0: every draw waits for its root on the host.  Same seal, equal to the oracle's
+    """`dev_draws` = 1: the FRI challenges (which depend only on a Merkle root) are drawn by the device half of the transcript and the
+    host replays them from one late read-back; 0 (default): every draw waits for its root on the host.  Same seal, equal to the oracle's
     (po2 10 has a single FRI round, 17 three)."""
     from boundless_amd.hal import HipHal
     from boundless_amd.prover import HipProverServer, Segment
