@@ -164,27 +164,43 @@ __global__ void bit_reverse_kernel(uint32_t* __restrict__ io, int n, size_t tota
 
 // Tiled bit reversal for n >= 12: index i = (a:6 | b:n-12 | c:6) maps to (rev c | rev b | rev a), so the 64x64 tile
 // {all a, all c} with middle bits b lands, transposed, on the tile with middle bits rev(b).  A workgroup loads the pair
-// (b, rev b) with 256-byte row reads, swaps them through LDS and stores 256-byte rows: each word moves HBM->HBM once.
+// (b, rev b), swaps the two tiles through LDS and stores them: each word moves HBM->HBM once.  Every lane moves 16 bytes per
+// access (a wave instruction covers four 256-byte rows) and all eight loads of a thread are issued before the first LDS write:
+// with one word per lane the launch had too few bytes in flight to cover the HBM latency (28 % of the roofline).
 __global__ __launch_bounds__(256) void bit_reverse_tiled_kernel(uint32_t* __restrict__ io, int n) {
     __shared__ uint32_t A[64][65], B[64][65];
     const int nb = n - 12;
     const uint32_t b = blockIdx.x, rb = bit_reverse(b, nb);
     if (rb < b) return;
     uint32_t* col = io + ((size_t)blockIdx.y << n);
-    const uint32_t lane = threadIdx.x & 63u, r0 = threadIdx.x >> 6;
+    const uint32_t l16 = threadIdx.x & 15u, r = threadIdx.x >> 4;  // lane: words 4 l16 .. 4 l16 + 3 of row r + 16 p
     const int hs = n - 6;
-#pragma unroll 4
-    for (uint32_t a = r0; a < 64; a += 4) {
-        A[a][lane] = col[((size_t)a << hs) + (b << 6) + lane];
-        if (rb != b) B[a][lane] = col[((size_t)a << hs) + (rb << 6) + lane];
+    const bool two = rb != b;
+    uint4 va[4], vb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const size_t row = (size_t)(r + 16u * p) << hs;
+        va[p] = *reinterpret_cast<const uint4*>(col + row + (b << 6) + 4u * l16);
+        if (two) vb[p] = *reinterpret_cast<const uint4*>(col + row + (rb << 6) + 4u * l16);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t* ar = &A[r + 16u * p][4u * l16];
+        ar[0] = va[p].x, ar[1] = va[p].y, ar[2] = va[p].z, ar[3] = va[p].w;
+        if (two) {
+            uint32_t* br = &B[r + 16u * p][4u * l16];
+            br[0] = vb[p].x, br[1] = vb[p].y, br[2] = vb[p].z, br[3] = vb[p].w;
+        }
     }
     __syncthreads();
-    const uint32_t rl = bit_reverse(lane, 6);
-#pragma unroll 4
-    for (uint32_t a = r0; a < 64; a += 4) {
-        const uint32_t ra = bit_reverse(a, 6);
-        col[((size_t)a << hs) + (rb << 6) + lane] = A[rl][ra];
-        if (rb != b) col[((size_t)a << hs) + (b << 6) + lane] = B[rl][ra];
+    // output word c = 4 l16 + i of row a comes from A[rev6(c)][rev6(a)], and rev6(4 l16 + i) = 16 rev2(i) + rev4(l16)
+    const uint32_t s0 = bit_reverse(l16, 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t a = r + 16u * p, ra = bit_reverse(a, 6);
+        const size_t row = (size_t)a << hs;
+        *reinterpret_cast<uint4*>(col + row + (rb << 6) + 4u * l16) = make_uint4(A[s0][ra], A[32u + s0][ra], A[16u + s0][ra], A[48u + s0][ra]);
+        if (two) *reinterpret_cast<uint4*>(col + row + (b << 6) + 4u * l16) = make_uint4(B[s0][ra], B[32u + s0][ra], B[16u + s0][ra], B[48u + s0][ra]);
     }
 }
 
@@ -581,7 +597,7 @@ extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) 
     OpScope op(c, "batch_bit_reverse", 8.0 * (double)io.len);
     int n = ilog2(io.len / count);
     if (n == 0) return nullptr;
-    if (n >= 12 && n <= 30) {
+    if (n >= 12 && n <= 30 && ((uintptr_t)io.dptr & 15u) == 0) {  // the tiled kernel moves 16 bytes per lane
         hipLaunchKernelGGL(bit_reverse_tiled_kernel, dim3(1u << (n - 12), (unsigned)count), dim3(256), 0, c->stream,
                            (uint32_t*)io.dptr, n);
         BX_LAUNCH_CHECK(c);

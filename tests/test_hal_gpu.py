@@ -332,6 +332,23 @@ def test_fri_fold_vs_oracle(hal, oracle, count):
     assert np.array_equal(out.view(), ref)
 
 
+@pytest.mark.parametrize("n,count,offset", [(12, 3, 0), (13, 2, 0), (16, 5, 0), (20, 2, 0), (14, 2, 1), (12, 1, 3), (15, 3, 4)])
+def test_batch_bit_reverse_tiled_and_unaligned(hal, oracle, n, count, offset):
+    """The tiled kernel moves 16 bytes per lane; a buffer that does not start on a 16-byte boundary (a slice) takes the word-wise
+    kernel instead.  Both against the oracle, and twice = identity."""
+    size = 1 << n
+    x = rnd(n * 31 + count, size * count)
+    whole = hal.copy_from(np.concatenate([np.zeros(offset, np.uint32), x]))
+    io = whole.slice(offset, size * count)
+    hal.batch_bit_reverse(io, count)
+    ref = x.copy()
+    oracle.bxo_batch_bit_reverse(ref, count, size)
+    assert np.array_equal(whole.view()[offset:], ref)
+    assert not whole.view()[:offset].any()
+    hal.batch_bit_reverse(io, count)
+    assert np.array_equal(whole.view()[offset:], x)
+
+
 def test_transcript_step_and_fri_fold_dev_vs_oracle(hal, oracle):
     """The device half of the Fiat-Shamir transcript (Poseidon2Rng: commit digests, hand out rate cells, permute when the pool runs
     dry or was touched) word for word against the oracle's, through chained steps of every shape; a fold fed by a challenge drawn
