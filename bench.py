@@ -25,7 +25,8 @@ The JSON line also carries
                 stream over the timed region, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is
                 VALU-issue-bound); measured by an isolated probe (one segment alone) because concurrent streams stretch the
                 in-region durations; `roofline_in_region` is the concurrent figure;
-  kernels       the same for every HAL entry point in the timed region;
+  kernels       the same for every HAL entry point in the timed region, from the HIP events of ONE lane per rank (bracketing
+                every entry point of every lane costs 0.9 % of the rate; `live_profile` says what was bracketed);
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
                 box's host cores: one proof of the metric's own size (2^20, ~35 s), thread count chosen on a small probe within the
                 container's CPU quota (16 on the GPU boxes).
@@ -255,6 +256,8 @@ def main():
     ap.add_argument("--native-agent", action="store_true", help="second N>1 design: ONE process, no torch.distributed; the native agent (include/bx_agent.h) runs "
                     "--inflight lanes on each of --gpus devices, all claiming from one task db; value = segments/s through the whole feed loop")
     ap.add_argument("--no-native-agent-extra", action="store_true", help="N>1 under torchrun: skip the untimed native-agent run that rank 0 spawns after the timed region")
+    ap.add_argument("--no-live-profile", action="store_true", help="do not bracket the entry points with HIP events in the timed region (measures what those events cost: "
+                    "an event record is a barrier packet between two kernels; the per-kernel figures then come from the isolated probe only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
     ap.add_argument("--cpu-sample-po2", type=int, default=20, help="size of the oracle proof timed for cpu_baseline (default: the metric's 2^20, ~40 s of CPU)")
@@ -304,6 +307,7 @@ def main():
         done = [0]
         last = [None]
         claimed = {}
+        by_server = {id(sv): 0 for sv in servers}
 
         def worker(sv):
             while True:
@@ -314,6 +318,7 @@ def main():
                     if idx is None:
                         return
                     done[0] += 1
+                    by_server[id(sv)] += 1
                 last[0] = sv.prove_segment(Segment.synthetic(index=idx, po2=args.po2))
                 if args.dump and tag == "timed":
                     claimed[idx] = last[0].seal
@@ -331,15 +336,20 @@ def main():
             order = sorted(claimed)
             np.savez(os.path.join(args.dump, f"rank{rank}.npz"), indices=np.array(order, dtype=np.int64),
                      **{f"seal_{i}": claimed[i] for i in order})
+        run.by_server = by_server
         return done[0], last[0]
 
     per_rank = args.steps * len(servers)
     total_global = args.batch if args.batch else per_rank * world
     run(args.warmup * len(servers), args.warmup * len(servers) * world, "warm")
     barrier()
+    # Live per-entry-point HIP events (the durations behind `roofline_in_region` and `kernels`) on ONE lane per rank: an event
+    # record is a barrier packet between two kernels, and bracketing every entry point of every lane costs 0.9 % of the rate at any
+    # lane count (profiles/r03_ab_live_profile.jsonl).  The profiled lane's segments are what the per-segment figures divide by.
+    live = [] if args.no_live_profile else servers[:1]
     for sv in servers:
         sv.hal.profile_reset()
-        sv.hal.profile_enable(True)
+        sv.hal.profile_enable(any(sv is x for x in live))
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     proved, receipt = run(per_rank if not args.batch else total_global, total_global, "timed")
@@ -348,8 +358,10 @@ def main():
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)  # every thread of this rank, user + system
     prof = {}
+    proved_live = sum(run.by_server[id(sv)] for sv in live)
     for sv in servers:
         sv.hal.profile_enable(False)
+    for sv in live:
         for name, r in sv.hal.profile_report().items():
             a0 = prof.setdefault(name, {"calls": 0, "ms": 0.0, "alg_bytes": 0.0})
             for k in a0:
@@ -375,8 +387,8 @@ def main():
         for name, r in prof.items():
             ms = r["ms"] / max(r["calls"], 1)
             gbps = r["alg_bytes"] / max(r["calls"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            kernels[name] = {"calls_per_step": r["calls"] / max(proved, 1), "avg_ms": round(ms, 4),
-                             "ms_per_segment": round(r["ms"] / max(proved, 1), 3), "alg_GBps": round(gbps, 1),
+            kernels[name] = {"calls_per_step": r["calls"] / max(proved_live, 1), "avg_ms": round(ms, 4),
+                             "ms_per_segment": round(r["ms"] / max(proved_live, 1), 3), "alg_GBps": round(gbps, 1),
                              "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4)}
         ntt = kernels.get("batch_expand_into_evaluate_ntt", {})
         iso_k = {}
@@ -515,6 +527,9 @@ def main():
             "roofline_dominant": dominant,
             "roofline_job": job_valu_view(proved_total / elapsed / max(world, 1)),
             "kernels": kernels,
+            "live_profile": {"lanes_with_hip_events": len(live), "lanes": len(servers), "segments_profiled": proved_live,
+                             "note": "per-entry-point HIP events bracket ONE lane per rank in the timed region (every lane: -0.9 % on the rate, "
+                                     "profiles/r03_ab_live_profile.jsonl); `kernels` and `roofline_in_region` are that lane's figures"},
             "kernels_isolated": iso_k,
             "replayed_profiles": replayed_profiles(),
         }
