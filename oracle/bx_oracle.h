@@ -112,6 +112,9 @@ uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, u
 void bxo_transcript_step(uint32_t state[25], const uint32_t* digests, size_t n_commit, uint32_t* out, size_t n_elems);
 /* test hook: add 1 to witness cell (group, col, row) before it is committed, making the proved statement false (group < 0: off) */
 void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
+/* test hook: a dishonest prover that commits its own code group (1: `last` == 0 and a false g_1; 2: `first` == 0, zero
+ * accumulators and a false g_0; 0: honest).  Only a control-ID check of the code root can refuse such a seal. */
+void bxo_set_cheat(int mode);
 void bxo_free(void* p);
 
 /* ---- program image (bx_oracle_image.c): risc0_zkvm::compute_image_id of an "R0BF" program binary.  PINNED by the

@@ -235,6 +235,16 @@ void bxo_set_witness_fault(int group, uint32_t col, uint32_t row) {
     fault_row = row;
 }
 
+/* Test hook: a DISHONEST prover that commits a code group of its own choosing (mode 0 = honest).
+ *   mode 1: the `last` selector (code column 1) is committed as the zero column and the public word g_1 is reported as g_1 + 1.
+ *           Every constraint gated by `last` (the pair closings and the g_1 boundary constraint) is then multiplied by zero, so
+ *           the constraint identity holds for ANY claimed g_1: only a check of the code root against the circuit's control ID
+ *           (risc0's check_code) can refuse the seal.
+ *   mode 2: the `first` selector (code column 0) is the zero column, every accumulator is the zero column (the recurrence
+ *           acc(r) = acc(r-1) * (beta + x) then holds on every row, cyclically) and g_0 is reported as g_0 + 1. */
+static int cheat_mode = 0;
+void bxo_set_cheat(int mode) { cheat_mode = mode; }
+
 /* Returns a malloc'ed seal (caller frees with bxo_free) or NULL on an internal consistency failure. */
 uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
                                uint64_t seed, size_t* seal_words, uint32_t roots_out[32]) {
@@ -351,6 +361,9 @@ uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             for (uint32_t c = 4 * cc.E; c < G->width; c++)
                 for (size_t r = 0; r < n; r++) w[(size_t)c * n + r] = synth_word(gseed, c, (uint32_t)r);
         }
+        if (cheat_mode == 1 && g == 0 && G->width >= 2) memset(w + n, 0, n * 4);
+        if (cheat_mode == 2 && g == 0) memset(w, 0, n * 4);
+        if (cheat_mode == 2 && g == 2) memset(w, 0, (size_t)4 * cc.E * n * 4);
         if (fault_group == g && fault_col < G->width && fault_row < n) {
             uint32_t* cell = &w[(size_t)fault_col * n + fault_row];
             *cell = bxo_fp_add(*cell, bxo_fp_encode(1));
@@ -386,6 +399,8 @@ uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, u
             n_globals = cc.wc >= 2 ? 2 : 1;
             globals[0] = data_w[0];                                        /* data[0][0] */
             globals[1] = data_w[(size_t)(cc.wd - 1) * n + (cc.act - 1)];     /* data[wd-1][last active row] */
+            if (cheat_mode == 1) globals[1] = bxo_fp_add(globals[1], bxo_fp_encode(1)); /* a false claim */
+            if (cheat_mode == 2) globals[0] = bxo_fp_add(globals[0], bxo_fp_encode(1));
             uint32_t dg[8];
             iop_write(&io, globals, n_globals);
             bxo_hash_elem_slice(dg, globals, n_globals, 1);

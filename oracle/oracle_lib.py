@@ -76,6 +76,7 @@ def lib(path=None):
         "bxo_prove_segment_zk": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_transcript_step": ([u32p, u32p, sz, u32p, sz], None),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
+        "bxo_set_cheat": ([C.c_int], None),
         "bxo_free": ([C.c_void_p], None),
         "bxo_compute_image_id": ([C.c_char_p, sz, C.c_char_p, u32p], C.c_int),
         "bxo_sha256": ([C.c_char_p, C.c_char_p, sz], None),
