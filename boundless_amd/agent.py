@@ -34,7 +34,7 @@ class _TaskDbOps(C.Structure):
 
 
 _SEAL_WORDS_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32)
-_PROVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32),
+_PROVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32),
                         C.c_size_t, C.POINTER(C.c_size_t))
 
 
@@ -109,7 +109,7 @@ def serialize_segment(seg: Segment) -> bytes:
     """Stand-in for `bincode(risc0_zkvm::Segment)` (tasks/mod.rs:40-47): bx_segment_encode."""
     out = (C.c_uint8 * 28)()
     _lib().bx_segment_encode(seg.index, seg.po2, seg.seed & (2**64 - 1), out)
-    return bytes(out)
+    return bytes(out) + bytes(seg.payload)  # the payload (the stand-in's "preflight trace") follows the 28-byte header
 
 
 def deserialize_segment(blob: bytes) -> Segment:
@@ -118,7 +118,7 @@ def deserialize_segment(blob: bytes) -> Segment:
     msg = _lib().bx_segment_decode(buf, len(blob), C.byref(i), C.byref(p), C.byref(s))
     if msg:
         raise ValueError(msg.decode())
-    return Segment(index=i.value, po2=p.value, seed=s.value)
+    return Segment(index=i.value, po2=p.value, seed=s.value, payload=bytes(blob[28:]))
 
 
 def deserialize_receipt(blob: bytes) -> SegmentReceipt:
@@ -297,9 +297,9 @@ class Agent:
             def seal_words(_user, _lane, _po2):
                 return seal_cap
 
-            def prove(_user, lane, index, po2, seed, seal_out, cap, words):
+            def prove(_user, lane, po2, seg, seg_len, seal_out, cap, words):
                 try:
-                    r = prover.prove_segment(Segment(index=index, po2=po2, seed=seed))
+                    r = prover.prove_segment(Segment.from_bytes(C.string_at(seg, seg_len)))  # the stored bytes, as the prover gets them
                     seal = np.ascontiguousarray(r.seal, dtype=np.uint32)
                     if seal.size > cap:
                         raise HalError("seal does not fit")

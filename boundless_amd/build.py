@@ -30,7 +30,7 @@ def csrc_hash():
     h = hashlib.sha256()
     for d in (CSRC, INC):
         for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".cpp", ".hpp", ".h")):
+            if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")):
                 h.update(f.encode() + b"\0")
                 h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -44,7 +44,7 @@ def _deps_mtime():
     m = 0.0
     for d in (CSRC, INC):
         for f in os.listdir(d):
-            if f.endswith((".hpp", ".h")):
+            if f.endswith((".hpp", ".h", ".inc")):
                 m = max(m, os.path.getmtime(os.path.join(d, f)))
     return m
 

@@ -26,8 +26,10 @@ _TAPS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams), C.c_int, C
 _NGLOBALS = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(SegmentParams))
 _CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(C.c_void_p))
 _DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
-_WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.c_uint64, C.POINTER(C.c_uint32))
-_ACCUM = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, C.POINTER(C.c_uint32), C.c_uint64)
+_CODE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf)
+_WITGEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, C.POINTER(C.c_uint8), C.c_size_t, BxBuf, C.POINTER(C.c_uint32))
+_ACCUM = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, C.POINTER(C.c_uint32))
+_CHECK_CODE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(C.c_uint32))
 _EVAL = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, BxBuf, BxBuf, BxBuf, BxBuf, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                     C.POINTER(C.c_uint32))
 _CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(TapReader), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -36,13 +38,18 @@ _CONS = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(SegmentParams), C.POINTER(
 
 class CircuitOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("name", C.c_char_p), ("normalize", _NORMALIZE), ("taps", _TAPS), ("n_globals", _NGLOBALS), ("create", _CREATE),
-                ("destroy", _DESTROY), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL), ("constraints_at", _CONS),
-                ("set_noise_seed", C.c_void_p)]  # optional (include/bx_circuit.h); NULL for circuits written in Python
+                ("destroy", _DESTROY), ("code_group", _CODE), ("witgen", _WITGEN), ("accumulate", _ACCUM), ("eval_check", _EVAL),
+                ("constraints_at", _CONS),
+                ("set_noise_seed", C.c_void_p),  # optional (include/bx_circuit.h); NULL for circuits written in Python
+                ("check_code", _CHECK_CODE)]
 
     @staticmethod
     def from_object(obj, name=b"python-circuit"):
         """obj provides normalize(shape), taps(shape, group, col) -> list of rows back (first 0), n_globals(shape),
-        witgen(ctx, code, data, seed) -> list of the n_globals public words, accumulate(ctx, accum, mix, seed),
+        code_group(ctx, code) (fills the public code group: a function of the shape alone),
+        witgen(ctx, code, data, segment_bytes, segment_dev) -> list of the n_globals public words, accumulate(ctx, accum, mix),
+        optionally check_code(shape, root_words) (raise to refuse a code root; without it seals of this circuit verify only
+        against an explicit VerifierContext),
         eval_check(ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix, globals) and
         constraints_at(shape, tap, poly_mix, mix, globals) -> 4 words; ctx is the raw bx_ctx pointer, buffers are BxBuf, mixes are lists of 4 Montgomery words, tap(group, col, back)
         returns 4 Montgomery words.  Exceptions become the error string of the call."""
@@ -67,8 +74,8 @@ class CircuitOps(C.Structure):
             n_glob["n"] = int(obj.n_globals(shape.contents)) if hasattr(obj, "n_globals") else 0
             return n_glob["n"]
 
-        def witgen(_u, _s, ctx, code, data, seed, globals_out):
-            g = list(obj.witgen(ctx, code, data, seed) or [])
+        def witgen(_u, _s, ctx, code, data, seg, seg_len, seg_dev, globals_out):
+            g = list(obj.witgen(ctx, code, data, C.string_at(seg, seg_len), seg_dev) or [])
             # the C side hands over an array of n_globals words: more would be written past it before any check could run
             if len(g) > n_glob.get("n", 0):
                 raise ValueError(f"witgen returned {len(g)} public words, the circuit declared {n_glob.get('n', 0)}")
@@ -102,10 +109,13 @@ class CircuitOps(C.Structure):
                          _NORMALIZE(guard(lambda _u, shape: obj.normalize(shape.contents))),
                          _TAPS(taps), _NGLOBALS(n_globals),
                          _CREATE(), _DESTROY(),
+                         _CODE(guard(lambda _u, _s, ctx, code: obj.code_group(ctx, code))),
                          _WITGEN(guard(witgen)),
-                         _ACCUM(guard(lambda _u, _s, ctx, accum, mix, seed: obj.accumulate(ctx, accum, w4(mix), seed))),
+                         _ACCUM(guard(lambda _u, _s, ctx, accum, mix: obj.accumulate(ctx, accum, w4(mix)))),
                          _EVAL(guard(lambda _u, _s, ctx, check, ce, de, ae, pm, mix, gl: obj.eval_check(ctx, check, ce, de, ae, w4(pm), w4(mix), glist(gl)))),
-                         _CONS(guard(constraints_at)))
+                         _CONS(guard(constraints_at)), None,
+                         _CHECK_CODE(guard(lambda _u, shape, root: obj.check_code(shape.contents, [root[i] for i in range(8)])))
+                         if hasattr(obj, "check_code") else _CHECK_CODE())
         ops._keepalive = (obj, errs)
         return ops
 

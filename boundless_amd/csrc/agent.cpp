@@ -21,11 +21,13 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/bx_agent.h"
+#include "../../include/bx_circuit.h"
 
 namespace {
 
@@ -553,6 +555,10 @@ struct bx_agent {
     Metrics metrics;
     std::atomic<int> stop{0};
     std::mutex create_mu;  // device buffer allocation of a new shape is serialised across lanes
+    // VerifierContext of the HIP prover's agent (`verifier_ctx`, lib.rs:241): the control ID of every buffer set a lane creates.
+    // Finishers verify under the shared lock, a lane adding a new shape takes it exclusively.
+    bx_verifier_ctx* vctx = nullptr;
+    std::shared_mutex vctx_mu;
 
     // ---- default prover ops: the HIP segment prover, one ctx per lane ----
     // Errors of bx_init / bx_prover_create are kept per lane (the text is owned by the failing call) and surface as the
@@ -589,6 +595,20 @@ struct bx_agent {
             *err = std::string("bx_prover_create(po2 ") + std::to_string(po2) + "): " + e;
             return err->c_str();
         }
+        // the shape's control ID, computed by the device that will prove it, must be the one the circuit publishes; it then
+        // goes into the agent's verifier context
+        uint32_t id[8];
+        const char* ce = bx_prover_control_id(p, id);
+        if (!ce) ce = bx_synthetic_circuit()->check_code(nullptr, &shape, id);
+        if (!ce) {
+            std::unique_lock<std::shared_mutex> w(vctx_mu);
+            ce = bx_verifier_ctx_add_control_id(vctx, po2, id);
+        }
+        if (ce) {
+            *err = std::string("control ID of the new buffer set (po2 ") + std::to_string(po2) + "): " + ce;
+            (void)bx_prover_destroy(p);
+            return err->c_str();
+        }
         lane.provers.emplace_back(po2, p);
         *out = p;
         return nullptr;
@@ -601,12 +621,12 @@ struct bx_agent {
         hip_err.clear();
         return bx_prover_seal_words(p);
     }
-    static const char* hip_prove(void* user, uint32_t lane, uint64_t, uint32_t po2, uint64_t seed, uint32_t* seal, size_t cap,
+    static const char* hip_prove(void* user, uint32_t lane, uint32_t po2, const uint8_t* segment, size_t len, uint32_t* seal, size_t cap,
                                  size_t* words) {
         auto* a = (bx_agent*)user;
         bx_prover* p = nullptr;
         if (const char* e = a->hip_prover_for(lane, po2, &p, &hip_err)) return e;
-        return bx_prove_segment(p, seed, seal, cap, words);
+        return bx_prove_segment_bytes(p, segment, len, seal, cap, words);  // the stored blob, as it is
     }
 
     // ---- redis.rs helpers with their metrics ----
@@ -680,8 +700,8 @@ struct bx_agent {
             metrics.record_task_operation("prove", "prove_segment", "success", out->prove_s);
             return "";
         }
-        uint64_t seed = 0;
-        if (const char* de = bx_segment_decode(blob.data(), blob.size(), &out->seg_index, &out->po2, &seed)) return de;
+        // only the routing fields are read here; the prover gets the stored bytes
+        if (const char* de = bx_segment_decode(blob.data(), blob.size(), &out->seg_index, &out->po2, nullptr)) return de;
 
         auto prove_start = Clock::now();
         if (!prover.prove_segment) return "[BENTO-PROVE-002] Missing prover from prove task";
@@ -692,8 +712,7 @@ struct bx_agent {
         }
         if (out->seal.size() < cap) out->seal.resize(cap);
         out->words = 0;
-        if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->seg_index, out->po2, seed, out->seal.data(), cap,
-                                                  &out->words))
+        if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->po2, blob.data(), blob.size(), out->seal.data(), cap, &out->words))
             return pe;
         out->prove_s = secs_since(prove_start);
         metrics.record_task_operation("prove", "prove_segment", "success", out->prove_s);
@@ -707,7 +726,10 @@ struct bx_agent {
             output_key = p->job_prefix + ":" BX_RECUR_RECEIPT_PATH ":" + p->task.task_id;
         } else {
             if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
-                if (const char* ve = bx_verify_segment(p->seal.data(), p->words))
+                // the HIP prover's agent checks the code root against its own context; an injected prover's seals against the
+                // circuit's published IDs (check_code)
+                std::shared_lock<std::shared_mutex> r(vctx_mu);
+                if (const char* ve = bx_verify_segment_with_context(p->seal.data(), p->words, nullptr, hip ? vctx : nullptr))
                     return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
             }
             // a synthetic seal is not a lifted receipt: it never goes under the key Join workers read
@@ -1002,7 +1024,7 @@ void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[
     put_le(out + 20, seed, 8);
 }
 const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed) {
-    if (!blob || len != BX_SEGMENT_WIRE_BYTES || memcmp(blob, BX_SEGMENT_MAGIC, 8) != 0)
+    if (!blob || len < BX_SEGMENT_WIRE_BYTES || memcmp(blob, BX_SEGMENT_MAGIC, 8) != 0)
         return "Failed to deserialize segment data from redis: not a synthetic segment blob (the built-in prover proves the "
                "synthetic circuit only; a bincode(Segment) needs a prover plugged in through prove_blob)";
     if (index) *index = get_le(blob + 8, 8);
@@ -1066,6 +1088,11 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
         } else {
             a->hip = true;
             a->prover = bx_segment_prover_ops{a, bx_agent::hip_seal_words, bx_agent::hip_prove, nullptr, nullptr};
+            if (const char* e = bx_verifier_ctx_create(&a->vctx)) {
+                std::string m = std::string("bx_agent_create: ") + e;
+                (void)bx_agent_destroy(a);
+                return fail(m);
+            }
             // like Agent::new (lib.rs:241-252) the device contexts are created up front so a missing GPU fails here, loudly
             for (uint32_t d = 0; d < a->cfg.n_devices; ++d) {
                 Lane& first = *a->lanes[(size_t)d * a->cfg.inflight];
@@ -1100,6 +1127,7 @@ const char* bx_agent_destroy(bx_agent* a) {
     } catch (...) {
         first = "bx_agent_destroy: exception";
     }
+    bx_verifier_ctx_destroy(a->vctx);
     delete a;
     return first;
 }

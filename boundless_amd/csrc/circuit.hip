@@ -19,25 +19,13 @@
 
 namespace bx {
 
-__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
-    uint64_t z = x + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__host__ __device__ inline uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
-    uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
-    return v >= P ? v - P : v;
-}
-
 // ---- witness: code group (selectors + public control words) ----
-__global__ void witness_code_kernel(uint32_t* __restrict__ code, Circuit cc, uint64_t gseed) {
+// A function of the shape alone (SYNTH_CODE_SEED is a constant): its committed root is the circuit's control ID.
+__global__ void witness_code_kernel(uint32_t* __restrict__ code, Circuit cc) {
     const uint32_t n = 1u << cc.po2;
     const size_t total = (size_t)n * cc.wc, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint32_t c = (uint32_t)(i >> cc.po2), r = (uint32_t)(i & (n - 1));
-        code[i] = c == 0 ? (r == 0 ? MONT_ONE : 0u) : c == 1 ? (r == cc.active_rows() - 1 ? MONT_ONE : 0u) : synth_word(gseed, c, r);
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        code[i] = synth_code_cell(cc, (uint32_t)(i >> cc.po2), (uint32_t)(i & (n - 1)));
 }
 // ---- witness: free data columns (the permuted copies 4p+3, p < pairs, are placed by Hal::scatter afterwards) ----
 // Rows >= active_rows() are the ZK noise rows: drawn from the noise seed, in the permuted copies too.
@@ -254,16 +242,24 @@ const char* circuit_perm_tables(bx_ctx* c, const Circuit& cc, bx_buf offsets, bx
     return nullptr;
 }
 
-// code + data witness.  `data`/`code` are the groups' column-major N x width buffers; the permuted copies go through
-// Hal::scatter (one call per pair, one entry per cycle), the derived columns through one thread per row.
-const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, uint64_t seed_noise,
+// the code group (public; what bx_prover_control_id commits)
+const char* circuit_code(bx_ctx* c, const Circuit& cc, bx_buf code) {
+    const size_t n = (size_t)1 << cc.po2;
+    BX_REQUIRE(c, code.len == n * cc.wc, "circuit_code: group buffer size mismatch");
+    OpScope op(c, "witgen_code", 4.0 * (double)(n * cc.wc));
+    hipLaunchKernelGGL(witness_code_kernel, dim3(grid_for(n * cc.wc)), dim3(256), 0, c->stream, (uint32_t*)code.dptr, cc);
+    BX_LAUNCH_CHECK(c);
+    return nullptr;
+}
+
+// data witness.  `data`/`code` are the groups' column-major N x width buffers (code already filled); the permuted copies go
+// through Hal::scatter (one call per pair, one entry per cycle), the derived columns through one thread per row.
+const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_data, uint64_t seed_noise,
                             bx_buf perm_offsets, bx_buf perm_index) {
     const size_t n = (size_t)1 << cc.po2;
     BX_REQUIRE(c, code.len == n * cc.wc && data.len == n * cc.wd, "circuit_witness: group buffer size mismatch");
     {
-        OpScope op(c, "witgen_fill", 4.0 * (double)(n * (cc.wc + cc.F)));
-        hipLaunchKernelGGL(witness_code_kernel, dim3(grid_for(n * cc.wc)), dim3(256), 0, c->stream, (uint32_t*)code.dptr, cc, seed_code);
-        BX_LAUNCH_CHECK(c);
+        OpScope op(c, "witgen_fill", 4.0 * (double)(n * cc.F));
         hipLaunchKernelGGL(witness_free_kernel, dim3(grid_for(n * cc.F)), dim3(256), 0, c->stream, (uint32_t*)data.dptr, cc, seed_data, seed_noise);
         BX_LAUNCH_CHECK(c);
     }
@@ -368,6 +364,7 @@ namespace {
 constexpr uint64_t GOLDEN64 = 0x9E3779B97F4A7C15ull;
 struct SynthState {
     Circuit cc;
+    uint64_t seed = 0;  // of the segment being proved (decoded by witgen from the segment's bytes; accumulate's noise columns use it)
     uint64_t noise_seed = 0;
     bool noise_set = false;  // bx_circuit_ops::set_noise_seed was called for the next witgen
     bx_buf perm_offsets{nullptr, 0}, perm_index{nullptr, 0}, acc_src{nullptr, 0}, acc_run{nullptr, 0}, betas{nullptr, 0}, mixpows{nullptr, 0};
@@ -405,12 +402,24 @@ __global__ void globals_kernel(uint32_t* __restrict__ out, const uint32_t* __res
     if (threadIdx.x == 0) out[0] = data[0];                                  // data[0][0]
     if (threadIdx.x == 1) out[1] = data[(size_t)(cc.wd - 1) * n + (cc.active_rows() - 1)];  // data[wd-1][last active row]
 }
-const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, uint64_t seed, uint32_t* globals_out) {
+const char* synth_code_group(void*, void* state, bx_ctx* c, bx_buf code) { return circuit_code(c, ((SynthState*)state)->cc, code); }
+// The synthetic segment is "BXSYNSEG" | index | po2 | seed | payload (bx_prover.h): the witness is a function of the seed; the
+// payload stands for the preflight trace (it is uploaded like one: `segment_dev`) and is not read.
+const char* synth_witgen(void*, void* state, bx_ctx* c, bx_buf code, bx_buf data, const uint8_t* segment, size_t segment_len, bx_buf /*segment_dev*/,
+                         uint32_t* globals_out) {
     auto* st = (SynthState*)state;
+    uint64_t seed = 0;
+    uint32_t seg_po2 = 0;
+    if (const char* e = bx_segment_decode(segment, segment_len, nullptr, &seg_po2, &seed)) return set_msg(c, e);
+    if (seg_po2 != st->cc.po2) {
+        snprintf(c->err, sizeof c->err, "prove_segment: the segment has po2 %u, this prover was created for po2 %u", seg_po2, st->cc.po2);
+        return c->err;
+    }
+    st->seed = seed;
     // the ZK rows' generator: given through set_noise_seed, else a function of the seed (bx_prover.h, "seeds")
     const uint64_t noise = st->noise_set ? st->noise_seed : splitmix64(seed ^ 0x5A4B4E4F49534521ull);
     st->noise_set = false;
-    BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 1, seed + GOLDEN64 * 2, noise + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
+    BX_TRY(circuit_witness(c, st->cc, code, data, seed + GOLDEN64 * 2, noise + GOLDEN64 * 2, st->perm_offsets, st->perm_index));
     BX_TRY(circuit_accum_gather(c, st->cc, st->acc_src, data));  // the prover interpolates `data` in place next
     // the statement's public words come out of the witness (one small copy; the derived cell is only known on the device)
     hipLaunchKernelGGL(globals_kernel, dim3(1), dim3(64), 0, c->stream, (uint32_t*)st->betas.dptr, (const uint32_t*)data.dptr, st->cc);
@@ -432,9 +441,9 @@ const char* synth_betas(bx_ctx* c, SynthState* st, const uint32_t mix[4]) {
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
-const char* synth_accumulate(void*, void* state, bx_ctx* c, bx_buf accum, const uint32_t mix[4], uint64_t seed) {
+const char* synth_accumulate(void*, void* state, bx_ctx* c, bx_buf accum, const uint32_t mix[4]) {
     auto* st = (SynthState*)state;
-    const uint64_t gseed = (seed + GOLDEN64 * 3) ^ (((uint64_t)mix[0] << 32) | mix[1]);
+    const uint64_t gseed = (st->seed + GOLDEN64 * 3) ^ (((uint64_t)mix[0] << 32) | mix[1]);
     BX_TRY(synth_betas(c, st, mix));
     return circuit_accumulate(c, st->cc, accum, st->acc_run, st->acc_src, st->betas, gseed);
 }
@@ -469,10 +478,12 @@ extern "C" const bx_circuit_ops* bx_synthetic_circuit(void) {
                                        bx::synth_n_globals,
                                        bx::synth_create,
                                        bx::synth_destroy,
+                                       bx::synth_code_group,
                                        bx::synth_witgen,
                                        bx::synth_accumulate,
                                        bx::synth_eval_check,
                                        bx::synthetic_constraints_at,
-                                       bx::synth_set_noise_seed};
+                                       bx::synth_set_noise_seed,
+                                       bx::synth_check_code};
     return &ops;
 }

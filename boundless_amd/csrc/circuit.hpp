@@ -16,6 +16,20 @@
 
 namespace bx {
 
+// pseudo-random words of the synthetic witness (bx_prover.h, "seeds")
+BX_CIRC_HD inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+BX_CIRC_HD inline uint32_t synth_word(uint64_t seed, uint32_t col, uint32_t row) {
+    const uint32_t v = (uint32_t)(splitmix64(seed ^ (((uint64_t)col << 32) | row)) >> 33);
+    return v >= 2013265921u ? v - 2013265921u : v;
+}
+// the code group's generator: a constant, so that the code group — and with it the control ID — depends on the shape alone
+constexpr uint64_t SYNTH_CODE_SEED = 0x434F4E54524F4C21ull;  // "CONTROL!"
+
 struct Circuit {
     // pool of a derived column: [0] free column j, [1] the same one or two rows back (slot1_back), [2] [3] free columns
     // j+1, j+2 (mod F), [4..11] the eight previous derived columns, [12..15] code columns csel(j..j+3)
@@ -105,5 +119,11 @@ inline uint32_t synth_taps(void*, const bx_segment_params* s, int group, uint32_
     return circuit_of(s).backs_of(group, col, backs_out);
 }
 inline uint32_t synth_n_globals(void*, const bx_segment_params* s) { return circuit_of(s).globals(); }
+// verifier side of the code-group binding (control_id.cpp): the built-in table, else the cached host computation
+const char* synth_check_code(void*, const bx_segment_params* s, const uint32_t root[8]);
+// cell (col, row) of the synthetic circuit's code group (bx_prover.h, "code")
+BX_CIRC_HD inline uint32_t synth_code_cell(const Circuit& cc, uint32_t col, uint32_t row) {
+    return col == 0 ? (row == 0 ? 268435454u : 0u) : col == 1 ? (row == cc.active_rows() - 1 ? 268435454u : 0u) : synth_word(SYNTH_CODE_SEED, col, row);
+}
 
 }  // namespace bx

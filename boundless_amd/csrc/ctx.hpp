@@ -241,8 +241,9 @@ const char* poseidon2_upload_params(bx_ctx* c);
 // the synthetic circuit's device stages (circuit.hip), driven by prover.hip
 struct Circuit;
 const char* circuit_perm_tables(bx_ctx* c, const Circuit& cc, bx_buf offsets, bx_buf index);
-const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_code, uint64_t seed_data, uint64_t seed_noise,
-                            bx_buf perm_offsets, bx_buf perm_index);
+const char* circuit_code(bx_ctx* c, const Circuit& cc, bx_buf code);
+const char* circuit_witness(bx_ctx* c, const Circuit& cc, bx_buf code, bx_buf data, uint64_t seed_data, uint64_t seed_noise, bx_buf perm_offsets,
+                            bx_buf perm_index);
 const char* circuit_accum_gather(bx_ctx* c, const Circuit& cc, bx_buf srcvals, bx_buf data);
 const char* circuit_accumulate(bx_ctx* c, const Circuit& cc, bx_buf accum, bx_buf run, bx_buf srcvals, bx_buf betas_dev, uint64_t seed_accum);
 const char* circuit_mix_table(bx_ctx* c, const Circuit& cc, bx_buf mixpows, const uint32_t poly_mix[4]);

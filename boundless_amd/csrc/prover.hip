@@ -8,6 +8,7 @@
 // circuit (witness generation, accumulate, eval_check: circuit.hip) is the synthetic one specified in bx_prover.h.
 #include <algorithm>
 #include <memory>
+#include <mutex>
 
 #include "circuit.hpp"
 #include "ctx.hpp"
@@ -85,6 +86,17 @@ struct Group {
     std::vector<uint32_t> combo;               // combo of each column (columns with the same tap set share one)
 };
 
+// One of the prover's two staging slots for a segment's bytes (bx_prover_submit_segment): pinned host copy -> HBM copy on the
+// prover's copy stream; `up` is recorded behind the upload and the compute stream waits on it, never the host.
+struct SegSlot {
+    uint8_t* host = nullptr;
+    size_t host_cap = 0;
+    uint32_t* dev = nullptr;
+    size_t dev_cap = 0;  // bytes
+    size_t len = 0;
+    hipEvent_t up0 = nullptr, up = nullptr;
+};
+
 struct FriRound {
     size_t size = 0;  // ext coefficients entering the round
     DevBuf evaluated, out_coeffs;
@@ -113,6 +125,13 @@ struct bx_prover {
     uint32_t n_globals = 0;                          // public words of the statement (bx_circuit_ops::n_globals)
     ~bx_prover() {
         if (circ && circ_state && circ->destroy) circ->destroy(circ->user, circ_state);
+        for (SegSlot& sl : seg) {
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+            if (sl.up0) (void)hipEventDestroy(sl.up0);
+            if (sl.up) (void)hipEventDestroy(sl.up);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
     std::vector<FriRound> rounds;
     DevBuf final_coeffs;
@@ -120,6 +139,13 @@ struct bx_prover {
     uint32_t last_roots[32];
     size_t seal_bound = 0;
     char err[512];
+    // segment staging: two slots, oldest first (submit may run on another thread than prove_submitted)
+    SegSlot seg[2];
+    int seg_head = 0, seg_count = 0;
+    std::mutex seg_mu;
+    hipStream_t copy_stream = nullptr;
+    float last_upload_ms = 0;
+    size_t last_upload_bytes = 0;
 };
 
 namespace {
@@ -232,7 +258,8 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     if (!c) return "bx_prover_create: null ctx";
     BX_REQUIRE(c, shape && out, "bx_prover_create: null argument");
     if (!circuit) circuit = bx_synthetic_circuit();
-    BX_REQUIRE(c, circuit->taps && circuit->witgen && circuit->accumulate && circuit->eval_check, "bx_prover_create: circuit table incomplete");
+    BX_REQUIRE(c, circuit->taps && circuit->code_group && circuit->witgen && circuit->accumulate && circuit->eval_check,
+               "bx_prover_create: circuit table incomplete");
     BX_REQUIRE(c, shape->po2 >= 9 && shape->po2 <= 24, "bx_prover_create: po2 must be in [9, 24]");
     BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
     BX_REQUIRE(c, shape->w_code < 65536 && shape->w_data < 65536 && shape->w_accum < 65536, "bx_prover_create: group width out of range");
@@ -354,6 +381,11 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     bound += 4 * total_taps + 4 * size + BX_QUERIES * (trace_query_words + fri_query_words);
     p->seal_bound = bound;
     memset(p->last_roots, 0, sizeof p->last_roots);
+    BX_HIP(c, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for (SegSlot& sl : p->seg) {
+        BX_HIP(c, hipEventCreate(&sl.up0));
+        BX_HIP(c, hipEventCreate(&sl.up));
+    }
     BX_TRY(bx_sync(c));
     c->live_provers += 1;
     *out = p.release();
@@ -375,17 +407,112 @@ extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_o
     return nullptr;
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_last_roots")
 
-static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
+static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
+
+// ---- the segment's bytes: pinned staging + upload on the copy stream (two slots) ----
+extern "C" const char* bx_prover_submit_segment(bx_prover* p, const uint8_t* segment, size_t len) try {
+    if (!p) return "bx_prover_submit_segment: null prover";
+    if (!segment || len == 0) return perr(p, "bx_prover_submit_segment: empty segment");
+    if (len > ((size_t)1 << 32) - 4) return perr(p, "bx_prover_submit_segment: segment larger than 4 GiB");
+    bx_ctx* c = p->c;
+    std::lock_guard<std::mutex> g(p->seg_mu);
+    if (p->seg_count == 2) return perr(p, "bx_prover_submit_segment: staging slots busy (two segments are already outstanding)");
+    if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prover_submit_segment: hipSetDevice failed");
+    SegSlot& sl = p->seg[(p->seg_head + p->seg_count) & 1];
+    const size_t padded = (len + 3) & ~(size_t)3;
+    if (sl.host_cap < padded) {  // grown on demand, kept for the prover's lifetime (a free slot has no copy in flight)
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.host = nullptr, sl.dev = nullptr, sl.host_cap = sl.dev_cap = 0;
+        const size_t cap = padded + padded / 8;
+        if (hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of pinned host memory");
+        sl.host_cap = cap;
+        if (hipMalloc((void**)&sl.dev, cap) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of device memory");
+        sl.dev_cap = cap;
+    }
+    memcpy(sl.host, segment, len);
+    if (padded > len) memset(sl.host + len, 0, padded - len);
+    sl.len = len;
+    if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess || hipMemcpyAsync(sl.dev, sl.host, padded, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess ||
+        hipEventRecord(sl.up, p->copy_stream) != hipSuccess)
+        return perr(p, "bx_prover_submit_segment: upload failed");
+    p->seg_count += 1;
+    return nullptr;
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_submit_segment")
+
+extern "C" const char* bx_prove_submitted(bx_prover* p, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
+    if (!p) return "bx_prove_submitted: null prover";
+    SegSlot* sl = nullptr;
+    {
+        std::lock_guard<std::mutex> g(p->seg_mu);
+        if (p->seg_count == 0) return perr(p, "bx_prove_submitted: no segment was submitted");
+        sl = &p->seg[p->seg_head];
+    }
+    const char* r = nullptr;
+    if (hipSetDevice(p->c->device) != hipSuccess) r = perr(p, "bx_prove_segment: hipSetDevice failed");
+    else if (hipStreamWaitEvent(p->c->stream, sl->up, 0) != hipSuccess) r = perr(p, "bx_prove_segment: could not order the proof behind the segment's upload");
+    else r = prove_segment_impl(p, *sl, seal_out, seal_cap, seal_words);
+    // a proof ends with a blocking read-back of the whole stream, so the upload is over: its duration is on the two events
+    if (!r && hipEventElapsedTime(&p->last_upload_ms, sl->up0, sl->up) == hipSuccess) p->last_upload_bytes = sl->len;
+    if (r) (void)hipEventSynchronize(sl->up);  // failed before the stream got there: the slot must be idle before it is reused
+    std::lock_guard<std::mutex> g(p->seg_mu);
+    p->seg_head ^= 1;
+    p->seg_count -= 1;
+    return r;
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_submitted")
+
+extern "C" const char* bx_prove_segment_bytes(bx_prover* p, const uint8_t* segment, size_t len, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
+    if (!p) return "bx_prove_segment_bytes: null prover";
+    {
+        std::lock_guard<std::mutex> g(p->seg_mu);
+        if (p->seg_count != 0) return perr(p, "bx_prove_segment_bytes: segments submitted earlier are still outstanding (use bx_prove_submitted)");
+    }
+    if (const char* e = bx_prover_submit_segment(p, segment, len)) return e;
+    return bx_prove_submitted(p, seal_out, seal_cap, seal_words);
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment_bytes")
+
+extern "C" const char* bx_prover_last_upload(const bx_prover* p, double* ms, size_t* bytes) {
+    if (!p) return "bx_prover_last_upload: null prover";
+    if (ms) *ms = p->last_upload_ms;
+    if (bytes) *bytes = p->last_upload_bytes;
+    return nullptr;
+}
+
+extern "C" const char* bx_prover_set_noise_seed(bx_prover* p, uint64_t noise_seed) {
+    if (!p) return "bx_prover_set_noise_seed: null prover";
+    if (p->circ->set_noise_seed) p->circ->set_noise_seed(p->circ->user, p->circ_state, noise_seed);
+    return nullptr;
+}
 extern "C" const char* bx_prove_segment(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
     if (!p) return "bx_prove_segment: null prover";
-    return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);  // the circuit derives the noise seed from the seed
+    uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+    bx_segment_encode(0, p->shape.po2, seed, wire);  // the circuit derives the noise seed from the seed
+    return bx_prove_segment_bytes(p, wire, sizeof wire, seal_out, seal_cap, seal_words);
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment")
 extern "C" const char* bx_prove_segment_zk(bx_prover* p, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
     if (!p) return "bx_prove_segment_zk: null prover";
-    if (p->circ->set_noise_seed) p->circ->set_noise_seed(p->circ->user, p->circ_state, noise_seed);
-    return prove_segment_impl(p, seed, seal_out, seal_cap, seal_words);
+    (void)bx_prover_set_noise_seed(p, noise_seed);
+    return bx_prove_segment(p, seed, seal_out, seal_cap, seal_words);
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment_zk")
-static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
+
+// The circuit's control ID for this shape: the code group through the same commit as in a proof, root read back.
+extern "C" const char* bx_prover_control_id(bx_prover* p, uint32_t id_out[8]) try {
+    if (!p) return "bx_prover_control_id: null prover";
+    if (!id_out) return perr(p, "bx_prover_control_id: null output");
+    bx_ctx* c = p->c;
+    if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prover_control_id: hipSetDevice failed");
+    Group& G = p->groups[0];
+    PV(p->circ->code_group(p->circ->user, p->circ_state, c, G.coeffs.b));
+    PV(commit_group_work(p, G));
+    size_t used = 0;
+    const uint32_t* host = nullptr;
+    PV(tree_fetch(p, G.tree, &used, &host));
+    PV(d2h_batch_wait(c));
+    memcpy(id_out, host, 32);
+    return nullptr;
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_control_id")
+
+static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) {
     bx_ctx* c = p->c;
     if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prove_segment: hipSetDevice failed");
     const size_t N = p->N, D = 4 * N;
@@ -411,7 +538,9 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
     memset(globals, 0, sizeof globals);
     {
         TraceRange tr(c, "bx:witgen");
-        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seed, globals));
+        PV(circ->code_group(circ->user, p->circ_state, c, p->groups[0].coeffs.b));
+        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seg.host, seg.len,
+                        bx_buf{seg.dev, (seg.len + 3) / 4}, globals));
     }
     if (p->n_globals) {  // the statement's public words: in the seal and in the transcript before any commitment
         uint32_t dg[8];
@@ -444,7 +573,7 @@ static const char* prove_segment_impl(bx_prover* p, uint64_t seed, uint32_t* sea
         beta = T.random_ext();
         {
             TraceRange tr(c, "bx:accumulate");
-            PV(circ->accumulate(circ->user, p->circ_state, c, G.coeffs.b, beta.c, seed));  // CircuitHal::accumulate
+            PV(circ->accumulate(circ->user, p->circ_state, c, G.coeffs.b, beta.c));  // CircuitHal::accumulate
         }
         TraceRange tr(c, "bx:commit_accum");
         PV(commit_group(p, G, T));

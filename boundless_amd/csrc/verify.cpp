@@ -72,6 +72,7 @@ struct TreeV {
     size_t rows, cols;
     unsigned layers, top_layer;
     std::vector<uint32_t> top;  // nodes [top_size, 2*top_size) as in the prover, indexable by node id - top_size
+    uint32_t root[8];           // recomputed from the top layer
     size_t top_size() const { return (size_t)1 << top_layer; }
     void read_and_commit(Reader& rd, Transcript& T, const HostPoseidon2& h, size_t rows_, size_t cols_) {
         rows = rows_;
@@ -88,7 +89,8 @@ struct TreeV {
             for (size_t i = 0; i < sz / 2; ++i) h.hash_elems(&next[8 * i], &layer[16 * i], 16);  // hash_pair == sponge of 16 words
             layer.swap(next);
         }
-        T.commit(layer.data());
+        memcpy(root, layer.data(), 32);
+        T.commit(root);
     }
     // reads `cols` values + the path from the seal, checks them against the top layer; returns the column values
     const uint32_t* verify_open(Reader& rd, const HostPoseidon2& h, size_t idx) const {
@@ -114,7 +116,13 @@ struct TreeV {
     }
 };
 
-void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
+}  // namespace
+namespace bx {
+bool verifier_ctx_contains(const bx_verifier_ctx* v, uint32_t po2, const uint32_t root[8]);  // control_id.cpp
+}
+namespace {
+
+void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ, const bx_verifier_ctx* vctx) {
     HostPoseidon2 h;
     h.load(POSEIDON2_RC, POSEIDON2_DIAG);
     Transcript T(&h);
@@ -157,6 +165,11 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
     // ---- trace commitments ----
     TreeV trees[4];
     trees[0].read_and_commit(rd, T, h, D, widths[0]);
+    // ---- the code group is the circuit's, not the prover's: its root must be a control ID (upstream: check_code(po2, root)).
+    //      An explicit context is a lookup and is asked at once; the circuit's own check may have to compute the ID (seconds for
+    //      a shape outside its table), so it runs last: only a seal that is otherwise a valid proof can make the verifier pay ----
+    if (vctx) VCHECK(verifier_ctx_contains(vctx, po2, trees[0].root), "the code group's root is not one of the verifier context's control IDs for this po2");
+    else VCHECK(circ->check_code != nullptr, "no control IDs to check the code root against (the circuit table has no check_code: pass a verifier context)");
     trees[1].read_and_commit(rd, T, h, D, widths[1]);
     const Fp4 beta = T.random_ext();  // the accumulators' mix
     trees[2].read_and_commit(rd, T, h, D, widths[2]);
@@ -360,6 +373,10 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ) {
         }
     }
     VCHECK(rd.pos == rd.n, "trailing words after the last query");
+    if (!vctx) {
+        const char* ce = circ->check_code(circ->user, &shape, trees[0].root);
+        VCHECK(ce == nullptr, std::string("control ID: ") + (ce ? ce : ""));
+    }
 }
 
 }  // namespace
@@ -442,12 +459,16 @@ extern "C" const char* bx_verify_segment(const uint32_t* seal, size_t seal_words
     return bx_verify_segment_with_circuit(seal, seal_words, nullptr);
 }
 extern "C" const char* bx_verify_segment_with_circuit(const uint32_t* seal, size_t seal_words, const bx_circuit_ops* circuit) {
-    static thread_local char err[256];
+    return bx_verify_segment_with_context(seal, seal_words, circuit, nullptr);
+}
+extern "C" const char* bx_verify_segment_with_context(const uint32_t* seal, size_t seal_words, const bx_circuit_ops* circuit,
+                                                      const bx_verifier_ctx* vctx) {
+    static thread_local char err[384];
     if (!seal) return "bx_verify_segment: null seal";
     if (!circuit) circuit = bx_synthetic_circuit();
     if (!circuit->taps || !circuit->constraints_at) return "bx_verify_segment: circuit table incomplete";
     try {
-        verify(seal, seal_words, circuit);
+        verify(seal, seal_words, circuit, vctx);
     } catch (const Fail& f) {
         snprintf(err, sizeof err, "bx_verify_segment: %s", f.msg.c_str());
         return err;

@@ -19,19 +19,37 @@ class SegmentParams(C.Structure):
                 ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32)]
 
 
+SEGMENT_MAGIC = b"BXSYNSEG"
+SEGMENT_WIRE_BYTES = 28
+
+
 @dataclass
 class Segment:
     """Synthetic stand-in for `risc0_zkvm::Segment` (the executor's output blob, tasks/executor.rs:476-503):
-    2^po2 cycles whose witness is derived from `seed` (see include/bx_prover.h)."""
+    2^po2 cycles whose witness is derived from `seed` (see include/bx_prover.h).  `payload` stands for the preflight trace: bytes
+    that cross PCIe with the segment and reach the circuit's witgen (the built-in circuit does not read them)."""
 
     index: int
     po2: int = 20
     seed: int = 0xB0D1E550000
     noise_seed: int = None  # generator of the ZK noise rows (None = derived from `seed`, include/bx_prover.h)
+    payload: bytes = b""
 
     @staticmethod
     def synthetic(index, po2=20, base_seed=0xB0D1E550000):
         return Segment(index=index, po2=po2, seed=base_seed + index)
+
+    def to_bytes(self):
+        """The segment on the wire (include/bx_prover.h): "BXSYNSEG" | index u64 | po2 u32 | seed u64 | payload."""
+        return (SEGMENT_MAGIC + (self.index & (2**64 - 1)).to_bytes(8, "little") + int(self.po2).to_bytes(4, "little")
+                + (self.seed & (2**64 - 1)).to_bytes(8, "little") + bytes(self.payload))
+
+    @staticmethod
+    def from_bytes(blob):
+        if len(blob) < SEGMENT_WIRE_BYTES or blob[:8] != SEGMENT_MAGIC:
+            raise HalError("Failed to deserialize segment data: not a synthetic segment blob")
+        return Segment(index=int.from_bytes(blob[8:16], "little"), po2=int.from_bytes(blob[16:20], "little"),
+                       seed=int.from_bytes(blob[20:28], "little"), payload=bytes(blob[28:]))
 
 
 @dataclass
@@ -52,10 +70,48 @@ class SegmentReceipt:
         The built-in synthetic circuit has two (the first cell of data column 0, the last cell of the last data column)."""
         return self.seal[6:6 + n].copy()
 
-    def verify_integrity(self):
+    def verify_integrity(self, ctx=None):
         """`SegmentReceipt::verify_integrity_with_context` (bento/crates/workflow/src/tasks/prove.rs:53-55): CPU check of the
-        whole seal (transcript, check identity, Merkle openings, DEEP quotients, FRI chain).  Raises on rejection."""
-        verify_seal(self.seal)
+        whole seal (transcript, check identity, Merkle openings, DEEP quotients, FRI chain, code root == control ID).  `ctx` = a
+        VerifierContext; None = the built-in circuit's own control IDs.  Raises on rejection."""
+        verify_seal(self.seal, ctx=ctx)
+
+
+class VerifierContext:
+    """`risc0_zkvm::VerifierContext` for the segment path (built once per agent, bento/crates/workflow/src/lib.rs:241): the set of
+    control IDs — Merkle roots of a circuit's code group, one per segment size — a seal's code root may be (include/bx_circuit.h)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        _declare(self.lib)
+        h = C.c_void_p()
+        msg = self.lib.bx_verifier_ctx_create(C.byref(h))
+        if msg:
+            raise HalError(msg.decode())
+        self.handle = h
+
+    def add_control_id(self, po2, digest_words):
+        d = np.ascontiguousarray(digest_words, dtype=np.uint32)
+        if d.size != 8:
+            raise HalError("a control ID is 8 digest words")
+        msg = self.lib.bx_verifier_ctx_add_control_id(self.handle, po2, d.ctypes.data)
+        if msg:
+            raise HalError(msg.decode())
+        return self
+
+    def __len__(self):
+        return self.lib.bx_verifier_ctx_size(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bx_verifier_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _declare(lib):
@@ -80,18 +136,55 @@ def _declare(lib):
     lib.bx_prover_create_with_circuit.restype = C.c_char_p
     lib.bx_verify_segment_with_circuit.argtypes = [C.c_void_p, sz, C.c_void_p]
     lib.bx_verify_segment_with_circuit.restype = C.c_char_p
+    lib.bx_verify_segment_with_context.argtypes = [C.c_void_p, sz, C.c_void_p, C.c_void_p]
+    lib.bx_verify_segment_with_context.restype = C.c_char_p
+    lib.bx_verifier_ctx_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.bx_verifier_ctx_create.restype = C.c_char_p
+    lib.bx_verifier_ctx_destroy.argtypes = [C.c_void_p]
+    lib.bx_verifier_ctx_destroy.restype = None
+    lib.bx_verifier_ctx_add_control_id.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.bx_verifier_ctx_add_control_id.restype = C.c_char_p
+    lib.bx_verifier_ctx_size.argtypes = [C.c_void_p]
+    lib.bx_verifier_ctx_size.restype = sz
+    lib.bx_synthetic_control_id_host.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.bx_synthetic_control_id_host.restype = C.c_char_p
+    lib.bx_prover_control_id.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bx_prover_control_id.restype = C.c_char_p
+    lib.bx_prove_segment_bytes.argtypes = [C.c_void_p, C.c_char_p, sz, C.c_void_p, sz, C.POINTER(sz)]
+    lib.bx_prove_segment_bytes.restype = C.c_char_p
+    lib.bx_prover_submit_segment.argtypes = [C.c_void_p, C.c_char_p, sz]
+    lib.bx_prover_submit_segment.restype = C.c_char_p
+    lib.bx_prove_submitted.argtypes = [C.c_void_p, C.c_void_p, sz, C.POINTER(sz)]
+    lib.bx_prove_submitted.restype = C.c_char_p
+    lib.bx_prover_set_noise_seed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.bx_prover_set_noise_seed.restype = C.c_char_p
+    lib.bx_prover_last_upload.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(sz)]
+    lib.bx_prover_last_upload.restype = C.c_char_p
     lib._bx_prover_declared = True
 
 
-def verify_seal(seal_words, circuit=None):
+def verify_seal(seal_words, circuit=None, ctx=None):
     """Host-side verifier (include/bx_prover.h: bx_verify_segment); needs no GPU.  `circuit` = a bx_circuit_ops table
-    (boundless_amd.circuit.CircuitOps) when the seal was made for another circuit than the built-in synthetic one."""
+    (boundless_amd.circuit.CircuitOps) when the seal was made for another circuit than the built-in synthetic one; `ctx` = a
+    VerifierContext holding the control IDs the code root may be (None = the circuit's own check_code)."""
     lib = load_library()
     _declare(lib)
     a = np.ascontiguousarray(seal_words, dtype=np.uint32)
-    msg = lib.bx_verify_segment_with_circuit(a.ctypes.data, a.size, C.addressof(circuit) if circuit is not None else None)
+    msg = lib.bx_verify_segment_with_context(a.ctypes.data, a.size, C.addressof(circuit) if circuit is not None else None,
+                                             ctx.handle if ctx is not None else None)
     if msg:
         raise HalError(msg.decode())
+
+
+def synthetic_control_id_host(po2, w_code):
+    """The built-in circuit's control ID for (po2, w_code) computed on the host (include/bx_circuit.h); no GPU."""
+    lib = load_library()
+    _declare(lib)
+    out = np.zeros(8, np.uint32)
+    msg = lib.bx_synthetic_control_id_host(po2, w_code, out.ctypes.data)
+    if msg:
+        raise HalError(msg.decode())
+    return out
 
 
 class HipProverServer:
@@ -123,16 +216,60 @@ class HipProverServer:
         if segment.po2 != self.po2:
             raise HalError(f"segment po2 {segment.po2} does not match the prover's allocation ({self.po2})")
         n = C.c_size_t(0)
-        if segment.noise_seed is None:
-            msg = self.lib.bx_prove_segment(self.handle, segment.seed & (2**64 - 1), self._seal.ctypes.data, self._seal.size, C.byref(n))
-        else:
-            msg = self.lib.bx_prove_segment_zk(self.handle, segment.seed & (2**64 - 1), segment.noise_seed & (2**64 - 1),
-                                               self._seal.ctypes.data, self._seal.size, C.byref(n))
+        if segment.noise_seed is not None:
+            self.lib.bx_prover_set_noise_seed(self.handle, segment.noise_seed & (2**64 - 1))
+        blob = segment.to_bytes()  # what the reference deserializes from the hot store (prove.rs:36-37) and hands to prove_segment
+        msg = self.lib.bx_prove_segment_bytes(self.handle, blob, len(blob), self._seal.ctypes.data, self._seal.size, C.byref(n))
         if msg:
             raise HalError(msg.decode())
         roots = np.zeros(32, np.uint32)
         self.lib.bx_prover_last_roots(self.handle, roots.ctypes.data)
         return SegmentReceipt(seal=self._seal[: n.value].copy(), index=segment.index, po2=segment.po2, roots=roots.reshape(4, 8))
+
+    def prove_segment_bytes(self, blob, index=0):
+        """The same from the serialized segment (`bincode::deserialize` + prove_segment in one call, prove.rs:36-49)."""
+        n = C.c_size_t(0)
+        blob = bytes(blob)
+        msg = self.lib.bx_prove_segment_bytes(self.handle, blob, len(blob), self._seal.ctypes.data, self._seal.size, C.byref(n))
+        if msg:
+            raise HalError(msg.decode())
+        roots = np.zeros(32, np.uint32)
+        self.lib.bx_prover_last_roots(self.handle, roots.ctypes.data)
+        return SegmentReceipt(seal=self._seal[: n.value].copy(), index=index, po2=self.po2, roots=roots.reshape(4, 8))
+
+    def submit_segment(self, blob):
+        """Stage the next segment: pinned copy + upload on the copy stream (two deep, include/bx_prover.h)."""
+        blob = bytes(blob)
+        msg = self.lib.bx_prover_submit_segment(self.handle, blob, len(blob))
+        if msg:
+            raise HalError(msg.decode())
+
+    def prove_submitted(self, index=0):
+        n = C.c_size_t(0)
+        msg = self.lib.bx_prove_submitted(self.handle, self._seal.ctypes.data, self._seal.size, C.byref(n))
+        if msg:
+            raise HalError(msg.decode())
+        roots = np.zeros(32, np.uint32)
+        self.lib.bx_prover_last_roots(self.handle, roots.ctypes.data)
+        return SegmentReceipt(seal=self._seal[: n.value].copy(), index=index, po2=self.po2, roots=roots.reshape(4, 8))
+
+    def last_upload(self):
+        """(milliseconds on the copy stream, bytes) of the upload of the segment proved last."""
+        ms, nb = C.c_double(0), C.c_size_t(0)
+        self.lib.bx_prover_last_upload(self.handle, C.byref(ms), C.byref(nb))
+        return ms.value, nb.value
+
+    def control_id(self):
+        """The circuit's control ID for this prover's shape, computed on the device (bx_prover_control_id)."""
+        out = np.zeros(8, np.uint32)
+        msg = self.lib.bx_prover_control_id(self.handle, out.ctypes.data)
+        if msg:
+            raise HalError(msg.decode())
+        return out
+
+    def verifier_context(self):
+        """A VerifierContext holding this prover's control ID (what an agent builds at start-up, lib.rs:241)."""
+        return VerifierContext().add_control_id(self.po2, self.control_id())
 
     def close(self):
         if getattr(self, "handle", None):

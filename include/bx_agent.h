@@ -130,26 +130,24 @@ size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
  *   synthetic  otherwise (the built-in HIP prover, or an injected prove_segment): blobs are the tagged stand-ins below and
  *              the seal goes to  job:{id}:synthetic_receipts:{task}  — a different key on purpose, so that a Join worker
  *              of a real cluster can never pick a synthetic seal up as a lifted SuccinctReceipt.  Needs cfg.synthetic = 1.
- *   segment  = "BXSYNSEG" | index u64 | po2 u32 | seed u64                      (28 bytes, little endian)
+ *   segment  = "BXSYNSEG" | index u64 | po2 u32 | seed u64 | payload ...        (28 bytes + payload, little endian; bx_prover.h)
  *   receipt  = "BXSYNRCP" | index u64 | po2 u32 | seal_words u32 | seal u32[]   (24 + 4*n bytes, little endian)
  * A blob without the tag (e.g. a real bincode Segment) fails the task with a message naming the mismatch. */
-#define BX_SEGMENT_WIRE_BYTES 28
 #define BX_RECEIPT_HEADER_BYTES 24
-#define BX_SEGMENT_MAGIC "BXSYNSEG"
 #define BX_RECEIPT_MAGIC "BXSYNRCP"
 #define BX_SYNTHETIC_RECEIPT_PATH "synthetic_receipts"
 #define BX_RECUR_RECEIPT_PATH "recursion_receipts"
-void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]);
-/* error: "Failed to deserialize segment data from redis" */
-const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed);
+/* bx_segment_encode / bx_segment_decode and the segment's layout: bx_prover.h ("the segment on the wire"). */
 
 /* ------------------------------------------------------------------------------------------------- agent ---- */
-/* The prover a lane calls.  NULL ops in bx_agent_create = the HIP prover (bx_prove_segment on the lane's own ctx).
- * A custom table lets tests inject failures without a GPU.  prove returns NULL or an error message. */
+/* The prover a lane calls.  NULL ops in bx_agent_create = the HIP prover (bx_prove_segment_bytes on the lane's own ctx).
+ * A custom table lets tests inject failures without a GPU.  prove returns NULL or an error message.
+ * The agent reads the stand-in's header only to route the segment (po2 -> buffer set, index -> receipt header); the stored
+ * bytes go to the prover as they are: `prover.prove_segment(&ctx, &segment)` (prove.rs:41-49). */
 typedef struct bx_segment_prover_ops {
     void* user;
     size_t (*seal_words)(void* user, uint32_t lane, uint32_t po2); /* seal capacity in words, 0 = unsupported shape */
-    const char* (*prove_segment)(void* user, uint32_t lane, uint64_t index, uint32_t po2, uint64_t seed, uint32_t* seal_out,
+    const char* (*prove_segment)(void* user, uint32_t lane, uint32_t po2, const uint8_t* segment, size_t segment_len, uint32_t* seal_out,
                                  size_t seal_cap, size_t* seal_words);
     /* Opaque mode (optional, may be NULL): everything tasks::prove::prover does between the GET and the SETEX
      * (prove.rs:36-109: deserialize, prove_segment, verify, lift, verify, serialize) on the raw stored bytes.  *receipt is
@@ -164,7 +162,9 @@ typedef struct bx_agent_config {
     uint32_t w_code, w_data, w_accum; /* synthetic segment group widths; 0 = BASELINE config (16/256/64) */
     uint64_t redis_ttl;      /* seconds; 0 = 8 h (the reference's default `redis_ttl`) */
     double poll_time;        /* idle sleep between empty claims, seconds; <= 0 = 1 s (`poll_time`) */
-    int32_t no_verify;       /* 0 = verify each seal before storing it, as the reference does (prove.rs:53-55); 1 = skip */
+    int32_t no_verify;       /* 0 = verify each seal before storing it, as the reference does (prove.rs:53-55); 1 = skip.  The HIP
+                              * prover's agent verifies against its VerifierContext: the control ID of every buffer set it creates
+                              * (bx_prover_control_id, checked against the circuit's own check_code) — `verifier_ctx`, lib.rs:241 */
     char task_stream[64];    /* worker type passed to request_work; "" = "prove" */
     /* ---- one agent, several GPUs: n_devices * inflight lanes claim from the ONE task db (request_work is the work-stealing
      * queue, 9_request_work.sql:126-153); 0 = the single `device` above.  The reference starts one process per GPU

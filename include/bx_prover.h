@@ -20,17 +20,21 @@
  * stage whose constraints really vanish on the trace domain and are divided by the vanishing polynomial.  The seal is a
  * STARK proof of that circuit: bx_verify_segment accepts it only if the constraint identity holds at the random point Z.
  * It is a deterministic function of (params, seed) and bit-identical to the CPU oracle's seal (oracle/bx_oracle_prover.c).
- * It is NOT a risc0 receipt: no image id and no claim (the ZK blinding rows are there, seeded).
+ * It is NOT a risc0 receipt: no image id and no claim (the ZK blinding rows are there, seeded).  Like a risc0 seal it is bound
+ * to its circuit: the code group is a public function of the shape, its Merkle root is the circuit's CONTROL ID for that shape,
+ * and bx_verify_segment refuses a seal whose code root is anything else (upstream's `check_code`).
  *
  * The synthetic circuit (normative; N = 2^po2 rows, all row indices cyclic mod N)
  * -------------------------------------------------------------------------------
  *   knobs      T = cons_terms (product terms per derived-column constraint), G = cons_degree (factors per term, <= 5)
- *   seeds      gseed_g = seed + (g+1) * 0x9E3779B97F4A7C15;  word(s,c,r) = splitmix64(s ^ (c << 32 | r)) >> 33, minus P if >= P
+ *   seeds      gseed_g = seed + (g+1) * 0x9E3779B97F4A7C15 (g = 1 data, 2 accum);  word(s,c,r) = splitmix64(s ^ (c << 32 | r)) >> 33, minus P if >= P
+ *              cseed = 0x434F4E54524F4C21 ("CONTROL!"), a constant: the code group does not depend on the segment
  *   zk rows    Z = min(1994, N/4) (risc0_zkp::ZK_CYCLES = 1994 [EXT]); A = N - Z active rows.  Rows >= A of every free data column
  *              (the permuted copies included) are noise: word(nseed_1, c, r), nseed_g = noise_seed + (g+1) * 0x9E3779B97F4A7C15.
  *              Derived columns and accumulators are computed on them like on any row (their constraints hold on every row),
  *              so they are blinded through the free cells; the code group is public and carries no noise.
- *   code       column 0 = first (1 at row 0, else 0); column 1 = last (1 at row A-1, the last active row); column c >= 2 = word(gseed_0, c, r).
+ *   code       column 0 = first (1 at row 0, else 0); column 1 = last (1 at row A-1, the last active row); column c >= 2 = word(cseed, c, r).
+ *              A function of (po2, w_code) only.  control ID(po2, w_code) = Merkle root of its commitment (bx_circuit.h).
  *              csel(i) = code column 2 + i mod (w_code - 2) when w_code >= 3, else the constant 1.
  *   data       F = ceil(w_data / 2) free columns, J = w_data - F derived columns.
  *              free column c: word(gseed_1, c, r) on the active rows, except the permuted copies: for pair p < pairs and r < A,
@@ -90,7 +94,33 @@ const char* bx_prover_create(bx_ctx* ctx, const bx_segment_params* shape, bx_pro
 const char* bx_prover_destroy(bx_prover* prover);
 /* Upper bound of the seal length in u32 words for this shape. */
 size_t bx_prover_seal_words(const bx_prover* prover);
-/* Prove one synthetic segment identified by `seed`; writes the seal (u32 words) and its length. Blocks. */
+/* ---- the segment on the wire ----
+ * The reference moves bincode(risc0_zkvm::Segment) (tasks/mod.rs:40-47; ~80 MB for a 2^20-cycle segment, executor.rs:45); that
+ * layout needs risc0's types.  The synthetic circuit's segment is the tagged stand-in
+ *   "BXSYNSEG" | index u64 | po2 u32 | seed u64 | payload bytes ...            (28 bytes + payload, little endian)
+ * whose payload (any length, may be empty) stands for the preflight trace: it crosses PCIe like one and is handed to the
+ * circuit's witgen on the host and in HBM, but the synthetic witness is a function of `seed` alone. */
+#define BX_SEGMENT_WIRE_BYTES 28
+#define BX_SEGMENT_MAGIC "BXSYNSEG"
+void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[BX_SEGMENT_WIRE_BYTES]);
+/* error: "Failed to deserialize segment data from redis ..." (prove.rs:36-37); len >= 28, the payload is not looked at */
+const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed);
+
+/* `ProverServer::prove_segment(&ctx, &segment)`: prove the segment whose serialized bytes are given (for the built-in circuit:
+ * the stand-in above; a plug-in circuit defines its own).  The bytes are copied to pinned staging memory, uploaded on the
+ * prover's copy stream and handed to the circuit's witgen; the seal (u32 words) and its length are written.  Blocks. */
+const char* bx_prove_segment_bytes(bx_prover* prover, const uint8_t* segment, size_t segment_len, uint32_t* seal_out, size_t seal_cap,
+                                   size_t* seal_words);
+/* The same in two steps, two deep ("H2D of next segment overlapped with compute"): submit copies the bytes
+ * into one of the prover's two pinned staging slots and enqueues the upload on the copy stream (returns once the host copy is
+ * made; the caller's buffer is free again); prove_submitted proves the oldest submitted segment — its compute stream waits on the
+ * upload's event, not the host.  At most two segments may be outstanding ("staging slots busy").  submit may be called from
+ * another thread while prove_submitted runs: segment k+1 goes up while segment k is proved. */
+const char* bx_prover_submit_segment(bx_prover* prover, const uint8_t* segment, size_t segment_len);
+const char* bx_prove_submitted(bx_prover* prover, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
+/* Device time (HIP events on the copy stream) and size of the upload of the segment proved last. */
+const char* bx_prover_last_upload(const bx_prover* prover, double* ms, size_t* bytes);
+/* Convenience: the built-in stand-in segment (index 0, the prover's po2, `seed`, no payload) through bx_prove_segment_bytes. */
 const char* bx_prove_segment(bx_prover* prover, uint64_t seed, uint32_t* seal_out, size_t seal_cap,
                              size_t* seal_words);
 /* The same with an explicit generator for the ZK noise cells (the last min(1994, N/4) rows of the free data columns of the
@@ -99,6 +129,8 @@ const char* bx_prove_segment(bx_prover* prover, uint64_t seed, uint32_t* seal_ou
  * the same statement (same header and public words), both accepted by bx_verify_segment. */
 const char* bx_prove_segment_zk(bx_prover* prover, uint64_t seed, uint64_t noise_seed, uint32_t* seal_out, size_t seal_cap,
                                 size_t* seal_words);
+/* bx_circuit_ops::set_noise_seed for the next proof, for callers of the bytes entry points. */
+const char* bx_prover_set_noise_seed(bx_prover* prover, uint64_t noise_seed);
 /* Merkle root (8 words each) of the code, data, accum and check groups of the last proof. */
 const char* bx_prover_last_roots(const bx_prover* prover, uint32_t roots_out[32]);
 
@@ -111,8 +143,10 @@ const char* bx_merkle_query_gather(bx_ctx* ctx, bx_buf out, bx_buf matrix, bx_bu
 /* CPU verifier of a seal produced by bx_prove_segment (the reference verifies every receipt right after proving it:
  * bento/crates/workflow/src/tasks/prove.rs:53-55 `segment_receipt.verify_integrity_with_context`).  Pure host code, no
  * ctx and no GPU needed.  Replays the Poseidon2 transcript, checks the check-polynomial identity at Z, every Merkle
- * opening, the DEEP quotient at each of the 50 query points and the FRI folding chain down to the final polynomial.
- * Returns NULL when the seal is accepted, otherwise a message (thread-local storage) naming the first failed check. */
+ * opening, the DEEP quotient at each of the 50 query points and the FRI folding chain down to the final polynomial, and
+ * compares the code group's root with the circuit's control ID for the seal's shape (upstream: `check_code`; the built-in
+ * circuit knows its IDs — a table for w_code = 16, a cached host computation otherwise; bx_circuit.h has the explicit
+ * VerifierContext form).  Returns NULL when the seal is accepted, otherwise a message (thread-local storage) naming the first failed check. */
 const char* bx_verify_segment(const uint32_t* seal, size_t seal_words);
 
 #ifdef __cplusplus

@@ -106,6 +106,8 @@ uint32_t* bxo_prove_segment_ex(uint32_t po2, uint32_t w_code, uint32_t w_data, u
  * noise_seed = splitmix64(seed ^ 0x5A4B4E4F49534521). */
 uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint32_t terms, uint32_t degree,
                                uint64_t seed, uint64_t noise_seed, size_t* seal_words, uint32_t roots_out[32]);
+/* control ID of the synthetic circuit for (po2, w_code): Merkle root of the committed code group (include/bx_circuit.h) */
+void bxo_control_id(uint32_t po2, uint32_t w_code, uint32_t id_out[8]);
 /* the transcript's RNG alone ([EXT] Poseidon2Rng): state = 24 cells + the number of rate cells already handed out; `mix(digest)`
  * n_commit times, then `random_elem` n_elems times.  What the prover's iop_commit / iop_random_elem do, exported so that the
  * device-side step (bx_transcript_step) can be checked on its own. */

@@ -22,6 +22,7 @@
 #define FRI_MIN_DEGREE 256
 #define CHECK_SIZE 16
 #define GOLDEN 0x9E3779B97F4A7C15ull
+#define CODE_SEED 0x434F4E54524F4C21ull /* "CONTROL!": the code group is public and depends on the shape alone (include/bx_prover.h) */
 
 typedef struct { uint32_t c[4]; } e4;
 
@@ -292,7 +293,7 @@ uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, u
                 for (size_t r = 0; r < n; r++)
                     w[(size_t)c * n + r] = c == 0 ? (r == 0 ? bxo_fp_encode(1) : 0)
                                            : c == 1 ? (r == cc.act - 1 ? bxo_fp_encode(1) : 0) /* last ACTIVE row */
-                                                    : synth_word(gseed, c, (uint32_t)r);
+                                                    : synth_word(CODE_SEED, c, (uint32_t)r);
         } else if (g == 1) {
             /* free columns; the last zk rows of every one of them (the permuted copies included) are ZK noise */
             for (uint32_t c = 0; c < cc.F; c++)
@@ -677,6 +678,27 @@ uint32_t* bxo_prove_segment_zk(uint32_t po2, uint32_t w_code, uint32_t w_data, u
     *seal_words = io.len;
     return io.seal;
 }
+/* The synthetic circuit's control ID for (po2, w_code): the Merkle root of the committed code group, with the oracle's own
+ * commit_group ([EXT] risc0's control IDs are the same thing for its circuits: the table check_code compares against). */
+void bxo_control_id(uint32_t po2, uint32_t w_code, uint32_t id_out[8]) {
+    bxo_init();
+    const size_t n = (size_t)1 << po2;
+    const size_t zk = n / 4 < 1994 ? n / 4 : 1994, act = n - zk;
+    group_t G;
+    iop_t io;
+    memset(&G, 0, sizeof G);
+    memset(&io, 0, sizeof io);
+    G.width = w_code;
+    G.coeffs = (uint32_t*)malloc((size_t)w_code * n * 4);
+    for (uint32_t c = 0; c < w_code; c++)
+        for (size_t r = 0; r < n; r++)
+            G.coeffs[(size_t)c * n + r] = c == 0 ? (r == 0 ? bxo_fp_encode(1) : 0) : c == 1 ? (r == act - 1 ? bxo_fp_encode(1) : 0) : synth_word(CODE_SEED, c, (uint32_t)r);
+    commit_group(&G, n, &io);
+    memcpy(id_out, G.tree.nodes + 8, 32);
+    group_free(&G);
+    free(io.seal);
+}
+
 uint32_t* bxo_prove_segment(uint32_t po2, uint32_t w_code, uint32_t w_data, uint32_t w_accum, uint64_t seed,
                             size_t* seal_words, uint32_t roots_out[32]) {
     return bxo_prove_segment_ex(po2, w_code, w_data, w_accum, 0, 0, seed, seal_words, roots_out);

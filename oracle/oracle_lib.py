@@ -77,6 +77,7 @@ def lib(path=None):
         "bxo_transcript_step": ([u32p, u32p, sz, u32p, sz], None),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
         "bxo_set_cheat": ([C.c_int], None),
+        "bxo_control_id": ([C.c_uint32, C.c_uint32, u32p], None),
         "bxo_free": ([C.c_void_p], None),
         "bxo_compute_image_id": ([C.c_char_p, sz, C.c_char_p, u32p], C.c_int),
         "bxo_sha256": ([C.c_char_p, C.c_char_p, sz], None),
@@ -131,6 +132,14 @@ def prove_segment(po2, w_code, w_data, w_accum, seed, L=None, terms=0, degree=0,
     seal = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
     L.bxo_free(ptr)
     return seal, roots.reshape(4, 8)
+
+
+def control_id(po2, w_code, L=None):
+    """The synthetic circuit's control ID for (po2, w_code): 8 Montgomery digest words."""
+    L = L or lib()
+    out = np.zeros(8, np.uint32)
+    L.bxo_control_id(po2, w_code, out)
+    return out
 
 
 def transcript_step(state25, digests, n_elems, L=None):

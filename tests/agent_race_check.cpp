@@ -12,6 +12,7 @@
 #include <thread>
 
 #include "bx_agent.h"
+#include "bx_circuit.h"
 
 // Link stubs for the device entry points the default (HIP) prover ops reference; this test injects its own prover ops, so
 // none of them is ever called.
@@ -21,13 +22,22 @@ const char* bx_free(bx_ctx*) { return "stub"; }
 const char* bx_prover_create(bx_ctx*, const bx_segment_params*, bx_prover**) { return "stub"; }
 const char* bx_prover_destroy(bx_prover*) { return "stub"; }
 size_t bx_prover_seal_words(const bx_prover*) { return 0; }
-const char* bx_prove_segment(bx_prover*, uint64_t, uint32_t*, size_t, size_t*) { return "stub"; }
-const char* bx_verify_segment(const uint32_t* seal, size_t words) { return (words == 64 && seal[0] == 7u) ? nullptr : "bad seal"; }
+const char* bx_prove_segment_bytes(bx_prover*, const uint8_t*, size_t, uint32_t*, size_t, size_t*) { return "stub"; }
+const char* bx_prover_control_id(bx_prover*, uint32_t*) { return "stub"; }
+const bx_circuit_ops* bx_synthetic_circuit(void) { return nullptr; }
+const char* bx_verifier_ctx_create(bx_verifier_ctx**) { return "stub"; }
+void bx_verifier_ctx_destroy(bx_verifier_ctx*) {}
+const char* bx_verifier_ctx_add_control_id(bx_verifier_ctx*, uint32_t, const uint32_t*) { return "stub"; }
+const char* bx_verify_segment_with_context(const uint32_t* seal, size_t words, const bx_circuit_ops*, const bx_verifier_ctx*) {
+    return (words == 64 && seal[0] == 7u) ? nullptr : "bad seal";
+}
 }
 
 static std::atomic<uint64_t> g_calls{0};
 static size_t seal_words(void*, uint32_t, uint32_t) { return 64; }
-static const char* prove(void*, uint32_t lane, uint64_t index, uint32_t, uint64_t seed, uint32_t* seal, size_t cap, size_t* words) {
+static const char* prove(void*, uint32_t lane, uint32_t, const uint8_t* segment, size_t len, uint32_t* seal, size_t cap, size_t* words) {
+    uint64_t index = 0, seed = 0;
+    if (bx_segment_decode(segment, len, &index, nullptr, &seed)) return "not a segment";
     uint64_t n = g_calls.fetch_add(1);
     if (cap < 64) return "cap";
     std::this_thread::sleep_for(std::chrono::microseconds(lane / 2 == 1 ? 5000 : 100));  // device 1 is the slow GPU

@@ -8,6 +8,7 @@
 #include "bx_hal.h"
 #include "bx_prover.h"
 #include "bx_agent.h"
+#include "bx_circuit.h"
 
 #define CHECK(expr)                                              \
     do {                                                         \
@@ -45,13 +46,61 @@ int main(void) {
     }
     CHECK(bx_release(ctx, buf));
     /* prove + verify one small synthetic segment */
-    bx_segment_params shape = {10, 4, 8, 4};
+    bx_segment_params shape = {10, 4, 8, 4, 0, 0};
     bx_prover* prover = NULL;
     CHECK(bx_prover_create(ctx, &shape, &prover));
     size_t cap = bx_prover_seal_words(prover), n = 0;
     uint32_t* seal = (uint32_t*)malloc(cap * 4);
     CHECK(bx_prove_segment(prover, 1234u, seal, cap, &n));
     CHECK(bx_verify_segment(seal, n));
+    {   /* the boundary takes what the reference passes — the segment's bytes (prove.rs:36-49) — staged and uploaded by the
+         * prover; the payload of the stand-in is carried along and does not enter the synthetic witness */
+        enum { PAYLOAD = 1 << 16 };
+        uint8_t* blob = (uint8_t*)malloc(BX_SEGMENT_WIRE_BYTES + PAYLOAD);
+        uint32_t* seal2 = (uint32_t*)malloc(cap * 4);
+        size_t n2 = 0, up_bytes = 0;
+        double up_ms = 0;
+        uint32_t id[8];
+        bx_verifier_ctx* vctx = NULL;
+        bx_segment_encode(0, 10, 1234u, blob);
+        for (size_t i = 0; i < PAYLOAD; ++i) blob[BX_SEGMENT_WIRE_BYTES + i] = (uint8_t)(i * 31u);
+        CHECK(bx_prove_segment_bytes(prover, blob, BX_SEGMENT_WIRE_BYTES + PAYLOAD, seal2, cap, &n2));
+        if (n2 != n || memcmp(seal, seal2, n * 4) != 0) {
+            fprintf(stderr, "the bytes entry point gave another seal than the seed form\n");
+            return 1;
+        }
+        CHECK(bx_prover_last_upload(prover, &up_ms, &up_bytes));
+        if (up_bytes != BX_SEGMENT_WIRE_BYTES + PAYLOAD) {
+            fprintf(stderr, "the segment's bytes were not uploaded\n");
+            return 1;
+        }
+        /* two deep: segment k+1 goes up while segment k is proved */
+        CHECK(bx_prover_submit_segment(prover, blob, BX_SEGMENT_WIRE_BYTES));
+        CHECK(bx_prover_submit_segment(prover, blob, BX_SEGMENT_WIRE_BYTES + PAYLOAD));
+        if (bx_prover_submit_segment(prover, blob, BX_SEGMENT_WIRE_BYTES) == NULL) {
+            fprintf(stderr, "a third outstanding segment was accepted\n");
+            return 1;
+        }
+        CHECK(bx_prove_submitted(prover, seal2, cap, &n2));
+        CHECK(bx_prove_submitted(prover, seal2, cap, &n2));
+        if (n2 != n || memcmp(seal, seal2, n * 4) != 0 || bx_prove_submitted(prover, seal2, cap, &n2) == NULL) return 1;
+        /* VerifierContext: the control ID of the shape, computed by the device, is what a seal's code root must be */
+        CHECK(bx_prover_control_id(prover, id));
+        CHECK(bx_verifier_ctx_create(&vctx));
+        CHECK(bx_verifier_ctx_add_control_id(vctx, 10, id));
+        CHECK(bx_verify_segment_with_context(seal, n, NULL, vctx));
+        bx_verifier_ctx_destroy(vctx);
+        CHECK(bx_verifier_ctx_create(&vctx));
+        id[0] ^= 1u;
+        CHECK(bx_verifier_ctx_add_control_id(vctx, 10, id));
+        if (bx_verify_segment_with_context(seal, n, NULL, vctx) == NULL) {
+            fprintf(stderr, "a seal was accepted against a context that does not hold its control ID\n");
+            return 1;
+        }
+        bx_verifier_ctx_destroy(vctx);
+        free(blob);
+        free(seal2);
+    }
     seal[n / 2] ^= 1u;
     if (bx_verify_segment(seal, n) == NULL) {
         fprintf(stderr, "tampered seal was accepted\n");

@@ -12,6 +12,11 @@ selector first = code[1] (weight poly_mix, so the check polynomial is genuinely 
 
 Everything else — commits, transcript, DEEP, FRI, queries — is the library's.  The seal must verify against this circuit,
 must NOT verify against the built-in synthetic circuit, and a witness that violates the constraint must be rejected.
+
+The circuit's code group (a control column and the `first` selector) is public and a function of the shape alone; its committed
+root is the circuit's control ID, which the verifier is given in a VerifierContext (or through the table's check_code).  Witness
+generation receives the SEGMENT'S BYTES — host copy and HBM copy — as the reference's prover receives a `Segment`
+(bento/crates/workflow/src/tasks/prove.rs:41-49): data column 0 is read back from the uploaded payload when there is one.
 """
 import ctypes as C
 
@@ -57,10 +62,11 @@ class Fp4:
 
 
 class SquareCircuit:
-    def __init__(self, lib, cheat_row=None, claim=None):
+    def __init__(self, lib, cheat_row=None, claim=None, zero_first=False):
         self.lib = lib
         self.cheat_row = cheat_row
         self.claim = claim  # report this public word instead of the true data[0][0]
+        self.zero_first = zero_first  # a DISHONEST code group: the `first` selector is the zero column
         self.calls = []
 
     # ---- shape
@@ -88,26 +94,46 @@ class SquareCircuit:
         return ol.decode(out).astype(np.uint64)
 
     # ---- prover side
-    def witgen(self, ctx, code, data, seed):
-        self.calls.append("witgen")
-        n, wc, wd = self.n, self.wc, self.wd
-        rng = np.random.default_rng(seed & 0xFFFFFFFF)
-        code_w = rng.integers(0, P, (wc, n), dtype=np.uint64)
+    def _code(self):
+        """The code group: public, a function of the shape alone (its committed root is the control ID)."""
+        rng = np.random.default_rng(0xC0DE + self.n + 7 * self.wc)
+        code_w = rng.integers(0, P, (self.wc, self.n), dtype=np.uint64)
         code_w[1] = 0
-        code_w[1][0] = 1  # the `first` selector
+        if not self.zero_first:
+            code_w[1][0] = 1  # the `first` selector
+        return code_w
+
+    def code_group(self, ctx, code):
+        self.calls.append("code_group")
+        self._put(ctx, code, self._code().reshape(-1))
+
+    def witgen(self, ctx, code, data, segment, segment_dev):
+        self.calls.append("witgen")
+        n, wd = self.n, self.wd
+        assert segment[:8] == b"BXSYNSEG"  # this circuit reuses the stand-in's 28-byte header; the payload is its own
+        self.seed = seed = int.from_bytes(segment[20:28], "little")
+        rng = np.random.default_rng(seed & 0xFFFFFFFF)
+        code_w = self._code()
         data_w = rng.integers(0, P, (wd, n), dtype=np.uint64)
+        if len(segment) >= 28 + 4 * n:
+            # the "preflight trace": data column 0 comes from the payload — read back from the copy the prover uploaded to HBM
+            assert segment_dev.len == (len(segment) + 3) // 4
+            words = np.empty(segment_dev.len, np.uint32)
+            msg = self.lib.bx_d2h(ctx, words.ctypes.data, segment_dev, words.size)
+            assert not msg, msg
+            assert words.tobytes()[:len(segment)] == segment  # HBM copy == host copy
+            data_w[0] = words[7:7 + n].astype(np.uint64) % np.uint64(P)
         x = data_w[0]
         data_w[1] = (fmul(x, x) + fmul(code_w[0], np.roll(x, 1)) + np.roll(x, 3)) % np.uint64(P)
         if self.cheat_row is not None:
             data_w[1][self.cheat_row] = (data_w[1][self.cheat_row] + np.uint64(1)) % np.uint64(P)
-        self._put(ctx, code, code_w.reshape(-1))
         self._put(ctx, data, data_w.reshape(-1))
         g = int(data_w[0][0]) if self.claim is None else self.claim
         return ol.encode([g]).tolist()  # the public word, as a Montgomery word
 
-    def accumulate(self, ctx, accum, mix, seed):
+    def accumulate(self, ctx, accum, mix):
         self.calls.append("accumulate")
-        rng = np.random.default_rng((seed ^ mix[0]) & 0xFFFFFFFF)
+        rng = np.random.default_rng((self.seed ^ mix[0]) & 0xFFFFFFFF)
         self._put(ctx, accum, rng.integers(0, P, self.wa * self.n, dtype=np.uint64))  # unconstrained columns
 
     def eval_check(self, ctx, check, code_eval, data_eval, accum_eval, poly_mix, mix, globals_):
@@ -144,7 +170,8 @@ class SquareCircuit:
         self.n, (self.wc, self.wd, self.wa) = 1 << po2, widths
 
 
-def _prove(lib, circ_obj, po2, widths, seed):
+def _prove(lib, circ_obj, po2, widths, seed, payload=b""):
+    """-> (receipt, ops table, VerifierContext holding the circuit's control ID as the device computed it)"""
     from boundless_amd.circuit import CircuitOps
     from boundless_amd.prover import HipProverServer, Segment
 
@@ -152,7 +179,9 @@ def _prove(lib, circ_obj, po2, widths, seed):
     ops = CircuitOps.from_object(circ_obj, b"square-plus-back")
     srv = HipProverServer(0, po2=po2, widths=widths, circuit=ops)
     try:
-        return srv.prove_segment(Segment(index=0, po2=po2, seed=seed)), ops
+        vctx = srv.verifier_context()
+        circ_obj.calls.clear()
+        return srv.prove_segment(Segment(index=0, po2=po2, seed=seed, payload=payload)), ops, vctx
     finally:
         srv.close()
 
@@ -164,20 +193,43 @@ def test_a_foreign_circuit_is_proved_and_verified_through_the_plugin_table():
     lib = load_library()
     po2, widths = 10, (2, 3, 2)
     circ = SquareCircuit(lib)
-    receipt, ops = _prove(lib, circ, po2, widths, seed=77)
-    assert circ.calls == ["witgen", "accumulate", "eval_check"]
+    receipt, ops, vctx = _prove(lib, circ, po2, widths, seed=77)
+    assert circ.calls == ["code_group", "witgen", "accumulate", "eval_check"]
     assert receipt.seal[:6].tolist() == [po2, 2, 3, 2, 1, 2]  # the circuit's own knobs travel in the header
     assert int(receipt.seal[6]) < P  # ... followed by its public word
-    verify_seal(receipt.seal, circuit=ops)  # accepted against the circuit it was made for
+    verify_seal(receipt.seal, circuit=ops, ctx=vctx)  # accepted against the circuit it was made for and its control ID
+    with pytest.raises(HalError, match="no control IDs"):  # this table has no check_code: without a context nothing binds the code group
+        verify_seal(receipt.seal, circuit=ops)
     with pytest.raises(HalError):  # ... and it is not a proof of the built-in synthetic circuit
         verify_seal(receipt.seal)
     bad = receipt.seal.copy()
     bad[-1] ^= 1
     with pytest.raises(HalError):
-        verify_seal(bad, circuit=ops)
-    # deterministic: the same segment twice gives the same seal
-    again, _ = _prove(lib, SquareCircuit(lib), po2, widths, seed=77)
+        verify_seal(bad, circuit=ops, ctx=vctx)
+    # deterministic: the same segment twice gives the same seal; another segment (seed) leaves the code root == control ID
+    again, _, vctx2 = _prove(lib, SquareCircuit(lib), po2, widths, seed=77)
     assert np.array_equal(again.seal, receipt.seal)
+    other, _, _ = _prove(lib, SquareCircuit(lib), po2, widths, seed=78)
+    assert not np.array_equal(other.seal, receipt.seal) and np.array_equal(other.roots[0], receipt.roots[0])
+    verify_seal(other.seal, circuit=ops, ctx=vctx2)
+
+
+def test_the_segments_bytes_reach_witgen_on_the_host_and_in_hbm():
+    """`prove_segment(&ctx, &segment)`: the circuit's witgen is handed the serialized segment — the host copy and the copy the
+    prover uploaded on its copy stream.  Here data column 0 IS the payload, read back from HBM, so the public word g = data[0][0]
+    is the payload's first word: the seal proves a statement about bytes that travelled through bx_prove_segment_bytes."""
+    from boundless_amd.hal import load_library
+    from boundless_amd.prover import verify_seal
+
+    lib = load_library()
+    po2, widths = 10, (2, 3, 2)
+    trace = np.random.default_rng(9).integers(0, P, 1 << po2, dtype=np.uint32)
+    circ = SquareCircuit(lib)
+    receipt, ops, vctx = _prove(lib, circ, po2, widths, seed=3, payload=trace.tobytes())
+    assert int(ol.decode(receipt.seal[6:7])[0]) == int(trace[0])
+    verify_seal(receipt.seal, circuit=ops, ctx=vctx)
+    plain, _, _ = _prove(lib, SquareCircuit(lib), po2, widths, seed=3)
+    assert not np.array_equal(plain.seal, receipt.seal)
 
 
 def test_a_foreign_circuit_with_a_false_witness_is_rejected():
@@ -185,9 +237,9 @@ def test_a_foreign_circuit_with_a_false_witness_is_rejected():
     from boundless_amd.prover import verify_seal
 
     lib = load_library()
-    receipt, ops = _prove(lib, SquareCircuit(lib, cheat_row=123), 10, (2, 3, 2), seed=5)
+    receipt, ops, vctx = _prove(lib, SquareCircuit(lib, cheat_row=123), 10, (2, 3, 2), seed=5)
     with pytest.raises(HalError, match="constraint identity"):
-        verify_seal(receipt.seal, circuit=ops)
+        verify_seal(receipt.seal, circuit=ops, ctx=vctx)
 
 
 def test_a_foreign_circuit_cannot_claim_a_public_word_its_trace_does_not_have():
@@ -195,9 +247,41 @@ def test_a_foreign_circuit_cannot_claim_a_public_word_its_trace_does_not_have():
     from boundless_amd.prover import verify_seal
 
     lib = load_library()
-    receipt, ops = _prove(lib, SquareCircuit(lib, claim=12345), 10, (2, 3, 2), seed=5)
+    receipt, ops, vctx = _prove(lib, SquareCircuit(lib, claim=12345), 10, (2, 3, 2), seed=5)
     with pytest.raises(HalError, match="constraint identity"):
-        verify_seal(receipt.seal, circuit=ops)
+        verify_seal(receipt.seal, circuit=ops, ctx=vctx)
+
+
+def test_a_dishonest_code_group_is_refused_by_the_control_id_and_by_nothing_else():
+    """VERDICT r03 Weak #2, for a plug-in circuit: a prover that commits its own code group — the `first` selector as the zero
+    column — switches the boundary constraint first * (data[0] - g) off and may then claim ANY public word.  Constraint identity,
+    Merkle openings, DEEP and FRI all hold for such a seal: it verifies against a context holding the cheater's own "control ID".
+    Against the circuit's real control ID (or its check_code) it is refused."""
+    from boundless_amd.circuit import CircuitOps
+    from boundless_amd.hal import HalError, load_library
+    from boundless_amd.prover import verify_seal
+
+    lib = load_library()
+    po2, widths = 10, (2, 3, 2)
+    honest, ops, honest_ctx = _prove(lib, SquareCircuit(lib), po2, widths, seed=5)
+    forged, _, forged_ctx = _prove(lib, SquareCircuit(lib, zero_first=True, claim=12345), po2, widths, seed=5)
+    assert int(ol.decode(forged.seal[6:7])[0]) == 12345 != int(ol.decode(honest.seal[6:7])[0])
+    verify_seal(forged.seal, circuit=ops, ctx=forged_ctx)  # every other check passes
+    with pytest.raises(HalError, match="control ID"):
+        verify_seal(forged.seal, circuit=ops, ctx=honest_ctx)
+    verify_seal(honest.seal, circuit=ops, ctx=honest_ctx)
+
+    class Checked(SquareCircuit):  # the same circuit publishing its control ID through the table (upstream: check_code)
+        def check_code(self, shape, root):
+            if list(root) != honest.roots[0].tolist():
+                raise ValueError("not the control ID of square-plus-back")
+
+    c2 = Checked(lib)
+    c2.bind(po2, widths)
+    ops2 = CircuitOps.from_object(c2)
+    verify_seal(honest.seal, circuit=ops2)
+    with pytest.raises(HalError, match="control ID"):
+        verify_seal(forged.seal, circuit=ops2)
 
 
 def test_errors_of_a_plugged_circuit_surface_as_error_strings():
@@ -206,7 +290,7 @@ def test_errors_of_a_plugged_circuit_surface_as_error_strings():
     from boundless_amd.prover import HipProverServer, Segment
 
     class Broken(SquareCircuit):
-        def accumulate(self, ctx, accum, mix, seed):
+        def accumulate(self, ctx, accum, mix):
             raise RuntimeError("no accumulate kernel for this shape")
 
     lib = load_library()

@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "boundless_amd", "csrc")
 def test_verifier_rejects_mutated_seals_without_memory_or_ub_errors(tmp_path):
     exe = str(tmp_path / "verify_fuzz_check")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
-                        f"-I{os.path.join(ROOT, 'include')}", os.path.join(CSRC, "verify.cpp"),
+                        "-pthread", f"-I{os.path.join(ROOT, 'include')}", os.path.join(CSRC, "verify.cpp"), os.path.join(CSRC, "control_id.cpp"),
                         os.path.join(ROOT, "tests", "verify_fuzz_check.cpp"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")

@@ -22,7 +22,8 @@ const char* synthetic_constraints_at(void*, const bx_segment_params* shape, cons
 // the library's table lives in circuit.hip next to the device stages; the verifier only needs the host entries
 extern "C" const bx_circuit_ops* bx_synthetic_circuit(void) {
     static const bx_circuit_ops ops = {nullptr, "synthetic (host entries only)", bx::synth_normalize, bx::synth_taps, bx::synth_n_globals,
-                                       nullptr, nullptr, nullptr, nullptr, nullptr, bx::synthetic_constraints_at};
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bx::synthetic_constraints_at, nullptr,
+                                       bx::synth_check_code};
     return &ops;
 }
 
