@@ -41,9 +41,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r03"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
+PROFILE_ROUND = "r04"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_GOPS = 39321.6  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz non-packed VALU lane-ops (measured ~37k, profiles/r01_microbench_valu.jsonl)
+# VALU issue model used throughout (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 units; measured in profiles/r01_microbench2_instr_cost.jsonl):
+# a wave64 instruction of the cheap integer class issues in 2 cycles per SIMD, one of the multiply class (v_mul_lo/hi_u32, v_mad_u64_u32,
+# v_mad_i64_i32) in 4, so the chip's issue peaks are 1024 SIMDs x 2.4 GHz / 2 and / 4 wave-instructions per second.
+VALU_PEAK_GOPS = 39321.6  # = 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes: multiply-class lane-ops per second (informational)
 
 
 _replayed = {}  # profile file -> csrc hash it was collected on (None when the file predates the stamps)
@@ -51,7 +54,7 @@ _replayed = {}  # profile file -> csrc hash it was collected on (None when the f
 
 def _profile(name):
     """profiles/<PROFILE_ROUND>_<name>, or an earlier round's file while this round's has not been collected yet"""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(p):
             return p
@@ -263,6 +266,10 @@ def main():
     ap.add_argument("--cpu-sample-po2", type=int, default=20, help="size of the oracle proof timed for cpu_baseline (default: the metric's 2^20, ~40 s of CPU)")
     ap.add_argument("--terms", type=int, default=0, help="synthetic circuit: product terms per constraint (0 = default)")
     ap.add_argument("--degree", type=int, default=0, help="synthetic circuit: factors per term (0 = default)")
+    ap.add_argument("--segment-bytes", type=int, default=0, help="size of every segment's serialized form: the 28-byte stand-in header + a payload that is uploaded "
+                    "(pinned staging slot -> copy stream -> HBM) and handed to witgen like a preflight trace; 0 = header only.  The reference's 2^20-cycle segment is ~80 MB (executor.rs:45)")
+    ap.add_argument("--two-deep", action="store_true", help="with --segment-bytes: a feeder thread per lane submits segment k+1 (bx_prover_submit_segment) while segment k is proved")
+    ap.add_argument("--no-pcie-extra", action="store_true", help="skip the untimed PCIe-inclusive leg (80 MB segments) of the default N=1 run")
     ap.add_argument("--dump", type=str, default=None, help="directory: every rank writes rank{r}.npz with the segment indices it claimed in the timed region and their seals (parity tests of the N>1 path)")
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
@@ -278,7 +285,7 @@ def main():
 
     import torch
 
-    from boundless_amd.dist import SegmentQueue, init_distributed, max_over_ranks, sum_over_ranks
+    from boundless_amd.dist import SegmentQueue, gather_over_ranks, init_distributed, max_over_ranks, sum_over_ranks
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
@@ -300,8 +307,19 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run(total_per_rank, total_global, tag):
+    def segment_buffer(nbytes):
+        import numpy as np
+
+        b = bytearray(nbytes)
+        if nbytes > 28:
+            b[28:] = np.random.default_rng(nbytes).integers(0, 256, nbytes - 28, dtype=np.uint8).tobytes()
+        return b
+
+    def run(total_per_rank, total_global, tag, seg_bytes=None):
         """Prove segments claimed from the queue with `inflight` provers per GPU; returns (proved by this rank, last receipt)."""
+        seg_bytes = args.segment_bytes if seg_bytes is None else seg_bytes
+        if seg_bytes and seg_bytes < 28:
+            raise SystemExit("--segment-bytes must be 0 or at least the 28-byte header")
         q = SegmentQueue(total_global, rank=rank, world=world, dist=dist, mode="steal" if args.steal else "static", name=tag)
         lock = threading.Lock()
         done = [0]
@@ -309,19 +327,66 @@ def main():
         claimed = {}
         by_server = {id(sv): 0 for sv in servers}
 
+        def claim(sv):
+            with lock:
+                if not args.steal and done[0] >= total_per_rank:
+                    return None
+                idx = q.claim()
+                if idx is None:
+                    return None
+                done[0] += 1
+                by_server[id(sv)] += 1
+                return idx
+
         def worker(sv):
+            # the segment as the hot store hands it over: header + payload in one host buffer per lane (only the header changes from
+            # one synthetic segment to the next; the payload is uploaded every time)
+            buf = segment_buffer(seg_bytes) if seg_bytes else None
+            if buf is not None and args.two_deep:
+                return worker_two_deep(sv, buf)
             while True:
-                with lock:
-                    if not args.steal and done[0] >= total_per_rank:
-                        return
-                    idx = q.claim()
-                    if idx is None:
-                        return
-                    done[0] += 1
-                    by_server[id(sv)] += 1
-                last[0] = sv.prove_segment(Segment.synthetic(index=idx, po2=args.po2))
+                idx = claim(sv)
+                if idx is None:
+                    return
+                seg = Segment.synthetic(index=idx, po2=args.po2)
+                if buf is None:
+                    last[0] = sv.prove_segment(seg)
+                else:
+                    buf[:28] = seg.to_bytes()[:28]
+                    last[0] = sv.prove_segment_buffer(buf, index=idx)
                 if args.dump and tag == "timed":
                     claimed[idx] = last[0].seal
+
+        def worker_two_deep(sv, buf):
+            # segment k+1 is staged and uploaded while segment k is proved — the feeder thread makes the pinned copy and
+            # enqueues the upload (bx_prover_submit_segment), the lane thread proves what was submitted (bx_prove_submitted)
+            import queue as _q
+
+            handed = _q.Queue()
+            free = threading.Semaphore(2)
+
+            def feeder():
+                while True:
+                    free.acquire()
+                    idx = claim(sv)
+                    if idx is None:
+                        handed.put(None)
+                        return
+                    buf[:28] = Segment.synthetic(index=idx, po2=args.po2).to_bytes()[:28]
+                    sv.submit_segment_buffer(buf)  # returns once the pinned copy is made: buf may be rewritten
+                    handed.put(idx)
+
+            ft = threading.Thread(target=feeder)
+            ft.start()
+            while True:
+                idx = handed.get()
+                if idx is None:
+                    break
+                last[0] = sv.prove_submitted(index=idx)
+                free.release()
+                if args.dump and tag == "timed":
+                    claimed[idx] = last[0].seal
+            ft.join()
 
         if len(servers) == 1:
             worker(servers[0])
@@ -353,6 +418,7 @@ def main():
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     proved, receipt = run(per_rank if not args.batch else total_global, total_global, "timed")
+    elapsed_own = time.perf_counter() - t0  # this rank's own work, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
@@ -368,6 +434,22 @@ def main():
                 a0[k] += r[k]
     elapsed = max_over_ranks(elapsed, dist)
     proved_total = int(round(sum_over_ranks(proved, dist)))
+    # who did what: one row per rank, so that a SCALE run says by itself whether the backend saw N ranks and whether they were balanced
+    per_rank_rows = [{"rank": int(r[0]), "device": int(r[1]), "proofs": int(r[2]), "seconds": round(r[3], 4)}
+                     for r in gather_over_ranks([rank, local_rank, proved, elapsed_own], dist)]
+
+    # One proof alone (untimed, rank 0): the reference's agent proves one segment at a time per process.  No HIP events around the
+    # entry points here (an event record is a barrier packet), wall clock around bx_prove_segment_bytes.
+    single_ms = None
+    if rank == 0:
+        sv = servers[0]
+        ts = []
+        for k in range(4):
+            t1 = time.perf_counter()
+            sv.prove_segment(Segment.synthetic(index=2 * 10**6 + k, po2=args.po2))
+            ts.append(1e3 * (time.perf_counter() - t1))
+        single_ms = {"min": round(min(ts[1:]), 3), "median": round(sorted(ts[1:])[1], 3), "runs": [round(x, 3) for x in ts[1:]]}
+    barrier()
 
     # Isolated probe (untimed, rank 0 only): with several segments in flight the HIP-event durations of the timed region
     # include time-slicing with the other stream, so one extra segment is proved alone to get each entry point's own
@@ -405,7 +487,9 @@ def main():
         # HBM traffic of the LDE's two kernels from the committed PMC passes of this same command (separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/pmc_traffic.py); None when the file is absent
         traffic = None
+        traffic_file = "(none)"
         try:
+            traffic_file = os.path.basename(_profile("bench_pmc_traffic.json"))
             pmc = _load_profile("bench_pmc_traffic.json")["kernels"]
             sel = [v for k, v in pmc.items() if "ntt_r16_kernel<false" in k or "ntt_passA_fwd12_multi_kernel" in k]
             if sel:
@@ -420,9 +504,12 @@ def main():
                     "traffic": traffic, "avg_ms_per_launch": e.get("avg_ms"),
                     "achieved_bytes_per_launch": (e.get("alg_GBps", 0) or 0) * 1e9 * (e.get("avg_ms", 0) or 0) * 1e-3,
                     "measured": measured,
+                    "traffic_over_algorithmic": (round(traffic / ((e.get("alg_GBps", 0) or 0) * 1e9 * (e.get("avg_ms", 0) or 0) * 1e-3), 3)
+                                                 if traffic and e.get("alg_GBps") and e.get("avg_ms") else None),
                     "note": "algorithmic bytes = 4B*(in + out) words per call / HIP-event time on the HAL stream; traffic = "
-                            "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/r02_bench_pmc_traffic.json; "
-                            "the path is VALU-issue-bound (DESIGN.md section 4), see roofline_dominant"}
+                            "FETCH_SIZE(x2)+WRITE_SIZE bytes per LDE call (both passes) from profiles/" + traffic_file + " (2.7x = the "
+                            "two-pass floor: pass A's output is written and re-read); the path is VALU-issue-bound (DESIGN.md section 4): "
+                            "see valu_view, and `dominant` for the job's dominant kernel"}
 
         # With several segments in flight the per-launch durations of the timed region include time-slicing between the
         # streams, so the kernel's own roofline comes from the isolated probe (same process, right after the timed region,
@@ -522,7 +609,16 @@ def main():
                      "cpus_allowed": len(os.sched_getaffinity(0)),
                      "note": "getrusage(RUSAGE_SELF) user+system over the timed region of rank 0 (all lane threads) / proofs; "
                              "the GPU boxes give a container 16 CPUs for 8 GPUs, i.e. 2 per GPU (profiles/r03_host_budget.json)"},
-            "roofline": roofline,
+            "roofline": {**roofline, "dominant": {"kernel": dominant.get("kernel"), "bound": "valu",
+                                                  "frac_issue": dominant.get("frac_of_mul_class_peak"), "frac_algorithmic": dominant.get("frac_algorithmic"),
+                                                  "valu_insts_per_permutation": dominant.get("valu_insts_per_permutation"),
+                                                  "ms_per_segment": dominant.get("ms_per_segment"),
+                                                  "note": "the job's dominant kernel (Poseidon2 leaf hashing) is VALU-issue-bound: frac_issue = wave-instructions/s "
+                                                          "against 1024 SIMDs x 2.4 GHz / 4 (multiply class), frac_algorithmic counts only the 1356 x 3 "
+                                                          "multiply instructions a permutation needs (SURVEY 8d)"}},
+            "single_proof_ms": single_ms,
+            "per_rank": per_rank_rows,
+            "backend": (None if dist is None else {"name": dist.get_backend(), "world_size": dist.get_world_size()}),
             "roofline_in_region": roofline_in_region,
             "roofline_dominant": dominant,
             "roofline_job": job_valu_view(proved_total / elapsed / max(world, 1)),
@@ -533,6 +629,27 @@ def main():
             "kernels_isolated": iso_k,
             "replayed_profiles": replayed_profiles(),
         }
+        if world == 1 and not args.no_pcie_extra and not args.segment_bytes and args.po2 >= 18:
+            # Untimed extra (never `value`): the same workload with every segment carrying the ~80 MB the reference's 2^20-cycle
+            # segment serializes to (executor.rs:45): pinned copy + upload on the copy stream per proof, two deep.
+            try:
+                nb = 80_000_000
+                args.two_deep = True
+                run(len(servers), len(servers), "pcie-warm", seg_bytes=nb)
+                barrier()
+                t1 = time.perf_counter()
+                n_p, _ = run(per_rank, per_rank, "pcie", seg_bytes=nb)
+                barrier()
+                dt = time.perf_counter() - t1
+                ups = [sv.last_upload() for sv in servers]
+                out["pcie_inclusive"] = {"segment_bytes": nb, "segment_proofs_per_s": n_p / dt, "ratio_to_value": round(n_p / dt / (proved_total / elapsed), 4),
+                                         "upload_ms": round(sum(u[0] for u in ups) / len(ups), 3),
+                                         "upload_GBps": round(sum(u[1] / (u[0] * 1e-3) for u in ups if u[0] > 0) / len(ups) / 1e9, 2),
+                                         "note": "every proof copies its segment into a pinned staging slot and uploads it on the prover's copy stream "
+                                                 "(bx_prover_submit_segment from a feeder thread while the previous segment is proved); `value` above is "
+                                                 "measured with inputs resident, this is the PCIe-inclusive rate"}
+            except Exception as e:  # reported, never required for the GPU number
+                out["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_po2, args.po2), widths, args.po2)

@@ -112,3 +112,17 @@ def sum_over_ranks(value, dist=None):
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(values, dist=None):
+    """Every rank contributes a fixed-length list of numbers; returns one list per rank, in rank order (a plain all-gather of a
+    small tensor: works on nccl and gloo alike, unlike all_gather_object's pickling path)."""
+    if dist is None:
+        return [[float(v) for v in values]]
+    import torch
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]

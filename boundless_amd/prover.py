@@ -237,6 +237,24 @@ class HipProverServer:
         self.lib.bx_prover_last_roots(self.handle, roots.ctypes.data)
         return SegmentReceipt(seal=self._seal[: n.value].copy(), index=index, po2=self.po2, roots=roots.reshape(4, 8))
 
+    def prove_segment_buffer(self, buf, index=0):
+        """prove_segment_bytes from a writable buffer (bytearray / numpy uint8) without the copy `bytes()` would make: what a
+        caller holding an ~80 MB segment in memory does (the C entry point takes a pointer and a length)."""
+        n = C.c_size_t(0)
+        mv = memoryview(buf)
+        arr = (C.c_char * mv.nbytes).from_buffer(buf)
+        msg = self.lib.bx_prove_segment_bytes(self.handle, arr, mv.nbytes, self._seal.ctypes.data, self._seal.size, C.byref(n))
+        if msg:
+            raise HalError(msg.decode())
+        return SegmentReceipt(seal=self._seal[: n.value].copy(), index=index, po2=self.po2)
+
+    def submit_segment_buffer(self, buf):
+        mv = memoryview(buf)
+        arr = (C.c_char * mv.nbytes).from_buffer(buf)
+        msg = self.lib.bx_prover_submit_segment(self.handle, arr, mv.nbytes)
+        if msg:
+            raise HalError(msg.decode())
+
     def submit_segment(self, blob):
         """Stage the next segment: pinned copy + upload on the copy stream (two deep, include/bx_prover.h)."""
         blob = bytes(blob)
