@@ -241,6 +241,94 @@ def native_agent_main(args, widths):
     print(json.dumps(out))
 
 
+def job_main(args, widths):
+    """`--job K`: BASELINE configs[2]/[3]'s SHAPE — K segment proofs, then the log-depth tail of joins, resolve, finalize — as the
+    planner's DAG (bx_plan_job) through the native agent's lanes on --gpus devices, ONE process.  The joins are STAND-INS (one
+    synthetic 2^--join-po2 proof seeded by the hash of the two children's seals; the recursion circuit is not available offline), so
+    the line is labelled `"join": "synthetic stand-in"`: what it measures is the scheduling shape — how long the K proves keep N
+    GPUs busy, and how long the join tail, which cannot, takes."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment
+
+    n = args.gpus
+    if args.device is None and torch.cuda.device_count() < n:
+        raise SystemExit(f"--job --gpus {n}: only {torch.cuda.device_count()} device(s) visible")
+    lanes = max(1, args.inflight)
+    devices = list(range(n)) if args.device is None else [args.device] * n
+    K = args.job
+    a = ag.Agent(prover=None, device=devices[0], devices=devices if len(devices) > 1 else None, inflight=lanes, widths=widths, poll_time=0.001,
+                 verify=True, terms=args.terms, degree=args.degree, join_po2=args.join_po2, also_streams="aux", max_shapes=2)
+    try:
+        def submit(job, k):
+            for i in range(k):
+                a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
+            return a.taskdb.plan_job(job, k)
+
+        submit("warm", 4 * lanes * n)  # every lane creates both buffer sets (segment size and join size) before the clock starts
+        a.poll_work(max_idle_polls=2)
+        ids = submit("timed", K)
+        t0 = time.perf_counter()
+        done = a.poll_work(max_idle_polls=2)
+        dt = time.perf_counter() - t0
+        if done != len(ids) or a.taskdb.job("timed")["state"] != "done":
+            raise RuntimeError(f"job: {done} of {len(ids)} tasks done, state {a.taskdb.job('timed')}")
+        rows = {t: a.taskdb.task("timed", t) for t in ids}
+        proves = [rows[t] for t in ids if t not in ("resolve", "finalize") and rows[t].output is not None and int(t) in _prove_ids(K)]
+        joins = [rows[t] for t in ids if t not in ("resolve", "finalize") and int(t) not in _prove_ids(K)]
+        t_first = min(r.started_s for r in proves)
+        t_proves = max(r.updated_s for r in proves)
+        t_end = rows["finalize"].updated_s
+        per_dev = {}
+        for d, cnt in a.lane_stats():
+            per_dev[d] = per_dev.get(d, 0) + cnt
+        out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": K / (t_proves - t_first), "unit": "segment-proofs/s", "n_gpus": n,
+               "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic", "join": "synthetic stand-in",
+               "config": {"workload": f"one job of {K} 2^{args.po2}-cycle synthetic segments planned by bx_plan_job (executor.rs:566-698): {K} Prove tasks, "
+                                      f"{K - 1} stand-in Join tasks (2^{args.join_po2}-cycle synthetic proofs seeded by their children's seals), resolve, finalize; "
+                                      f"every seal CPU-verified; trace widths {'/'.join(map(str, widths))}",
+                          "po2": args.po2, "join_po2": args.join_po2, "segments_proved": K, "segments_in_flight_per_gpu": lanes,
+                          "queue": "one in-memory task db with prerequisites (pending -> ready on update_task_done), every lane of every device claims when idle",
+                          "parallelism": f"one process, {n} device(s) x {lanes} lanes, no collective"},
+               "job": {"tasks": len(ids), "end_to_end_s": round(t_end - t_first, 4), "prove_phase_s": round(t_proves - t_first, 4),
+                       "prove_phase_proofs_per_s": round(K / (t_proves - t_first), 3),
+                       "join_tail_s": round(t_end - t_proves, 4), "joins": len(joins),
+                       "join_levels": max(1, (K - 1).bit_length()), "joins_started_before_last_prove": sum(1 for r in joins if r.started_s < t_proves),
+                       "segments_per_s_end_to_end": round(K / (t_end - t_first), 3), "wall_s_including_claims": round(dt, 4),
+                       "note": "value = K / prove phase (first claim to last Prove done); join_tail_s = last Prove done to finalize done: the part of "
+                               "the job whose parallelism halves at every level and starves N GPUs"},
+               "tasks_per_device": {str(d): int(c) for d, c in per_dev.items()}}
+        print(json.dumps(out))
+    finally:
+        a.close()
+
+
+def _prove_ids(k):
+    """Task numbers of the Segment tasks in the planner's numbering for k segments (cached)."""
+    if k not in _prove_ids.cache:
+        from boundless_amd.planner import Planner
+
+        p, ids = Planner(), set()
+        for _ in range(k):
+            p.enqueue_segment()
+        p.finish()
+        for i in range(p.task_count()):
+            t = p.get_task(i)
+            if t.command == "Segment":
+                ids.add(t.task_number)
+        _prove_ids.cache[k] = ids
+    return _prove_ids.cache[k]
+
+
+_prove_ids.cache = {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +354,9 @@ def main():
     ap.add_argument("--cpu-sample-po2", type=int, default=20, help="size of the oracle proof timed for cpu_baseline (default: the metric's 2^20, ~40 s of CPU)")
     ap.add_argument("--terms", type=int, default=0, help="synthetic circuit: product terms per constraint (0 = default)")
     ap.add_argument("--degree", type=int, default=0, help="synthetic circuit: factors per term (0 = default)")
+    ap.add_argument("--job", type=int, default=0, help="prove ONE planned job of this many segments (bx_plan_job: proves -> stand-in joins -> resolve -> finalize) through the "
+                    "native agent on --gpus devices; reports prove-phase rate, join-tail latency and end-to-end seconds, labelled \"join\": \"synthetic stand-in\"")
+    ap.add_argument("--join-po2", type=int, default=18, help="--job: size of the stand-in join proofs (18 = the reference's recursion proofs)")
     ap.add_argument("--segment-bytes", type=int, default=0, help="size of every segment's serialized form: the 28-byte stand-in header + a payload that is uploaded "
                     "(pinned staging slot -> copy stream -> HBM) and handed to witgen like a preflight trace; 0 = header only.  The reference's 2^20-cycle segment is ~80 MB (executor.rs:45)")
     ap.add_argument("--two-deep", action="store_true", help="with --segment-bytes: a feeder thread per lane submits segment k+1 (bx_prover_submit_segment) while segment k is proved")
@@ -277,6 +368,8 @@ def main():
         os.environ["BX_WAIT"] = args.wait
     if args.cpus:
         os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[: args.cpus]))
+    if args.job:
+        return job_main(args, widths)
     if args.native_agent:
         return native_agent_main(args, widths)
 
@@ -307,13 +400,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def segment_buffer(nbytes):
+    seg_bufs = {}
+
+    def segment_buffer(sv, nbytes):
+        """One host buffer per lane holding the serialized segment (built once, outside any timed region: it stands for bytes the
+        hot store already handed over)."""
         import numpy as np
 
-        b = bytearray(nbytes)
-        if nbytes > 28:
-            b[28:] = np.random.default_rng(nbytes).integers(0, 256, nbytes - 28, dtype=np.uint8).tobytes()
-        return b
+        key = (id(sv), nbytes)
+        if key not in seg_bufs:
+            b = bytearray(nbytes)
+            if nbytes > 28:
+                b[28:] = np.random.default_rng(nbytes).integers(0, 256, nbytes - 28, dtype=np.uint8).tobytes()
+            seg_bufs[key] = b
+        return seg_bufs[key]
 
     def run(total_per_rank, total_global, tag, seg_bytes=None):
         """Prove segments claimed from the queue with `inflight` provers per GPU; returns (proved by this rank, last receipt)."""
@@ -341,7 +441,7 @@ def main():
         def worker(sv):
             # the segment as the hot store hands it over: header + payload in one host buffer per lane (only the header changes from
             # one synthetic segment to the next; the payload is uploaded every time)
-            buf = segment_buffer(seg_bytes) if seg_bytes else None
+            buf = segment_buffer(sv, seg_bytes) if seg_bytes else None
             if buf is not None and args.two_deep:
                 return worker_two_deep(sv, buf)
             while True:
@@ -406,6 +506,9 @@ def main():
 
     per_rank = args.steps * len(servers)
     total_global = args.batch if args.batch else per_rank * world
+    if args.segment_bytes:
+        for sv in servers:
+            segment_buffer(sv, args.segment_bytes)
     run(args.warmup * len(servers), args.warmup * len(servers) * world, "warm")
     barrier()
     # Live per-entry-point HIP events (the durations behind `roofline_in_region` and `kernels`) on ONE lane per rank: an event
@@ -635,6 +738,8 @@ def main():
             try:
                 nb = 80_000_000
                 args.two_deep = True
+                for sv in servers:
+                    segment_buffer(sv, nb)
                 run(len(servers), len(servers), "pcie-warm", seg_bytes=nb)
                 barrier()
                 t1 = time.perf_counter()

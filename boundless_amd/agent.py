@@ -20,7 +20,7 @@ from .prover import Segment, SegmentReceipt
 RECUR_RECEIPT_PATH = "recursion_receipts"  # the reference's key (tasks/mod.rs:23): written only by an opaque (real) prover
 SYNTHETIC_RECEIPT_PATH = "synthetic_receipts"  # where seals of the synthetic circuit go (include/bx_agent.h)
 SEGMENTS_PATH = "segments"
-TASK_STATES = ("ready", "running", "done", "failed")
+TASK_STATES = ("ready", "running", "done", "failed", "pending")
 
 
 class _HotStoreOps(C.Structure):
@@ -55,7 +55,18 @@ class _ReadyTask(C.Structure):
 
 class _TaskInfo(C.Structure):
     _fields_ = [("state", C.c_int32), ("retries", C.c_int32), ("max_retries", C.c_int32), ("error", C.c_char * 1100),
-                ("output", C.c_char * 256)]
+                ("output", C.c_char * 256), ("waiting_on", C.c_int32), ("created_s", C.c_double), ("started_s", C.c_double),
+                ("updated_s", C.c_double)]
+
+
+class _JobInfo(C.Structure):
+    _fields_ = [("state", C.c_int32), ("tasks", C.c_uint64), ("pending", C.c_uint64), ("ready", C.c_uint64), ("running", C.c_uint64),
+                ("done", C.c_uint64), ("failed", C.c_uint64), ("error", C.c_char * 1100)]
+
+
+class _JobPlan(C.Structure):
+    _fields_ = [("prove_stream", C.c_char * 64), ("join_stream", C.c_char * 64), ("aux_stream", C.c_char * 64), ("prove_retries", C.c_int32),
+                ("join_retries", C.c_int32), ("resolve_retries", C.c_int32), ("finalize_retries", C.c_int32)]
 
 
 class _AgentConfig(C.Structure):
@@ -63,7 +74,7 @@ class _AgentConfig(C.Structure):
                 ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("no_verify", C.c_int32),
                 ("task_stream", C.c_char * 64), ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16), ("synthetic", C.c_int32),
                 ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32), ("po2_min", C.c_uint32), ("po2_max", C.c_uint32),
-                ("max_shapes", C.c_uint32)]
+                ("max_shapes", C.c_uint32), ("join_po2", C.c_uint32), ("also_streams", C.c_char * 128)]
 
 
 def _lib():
@@ -79,6 +90,10 @@ def _lib():
         "bx_mem_taskdb_ops": ([vp], _TaskDbOps),
         "bx_mem_taskdb_create_task": ([vp, cp, cp, cp, cp, C.c_int32], cp),
         "bx_mem_taskdb_task_info": ([vp, cp, cp, C.POINTER(_TaskInfo)], cp), "bx_mem_taskdb_count": ([vp, C.c_int32], sz),
+        "bx_mem_taskdb_create_task_with_prereqs": ([vp, cp, cp, cp, cp, C.POINTER(cp), sz, C.c_int32], cp),
+        "bx_mem_taskdb_job_info": ([vp, cp, C.POINTER(_JobInfo)], cp),
+        "bx_plan_job": ([vp, cp, C.c_uint64, C.POINTER(_JobPlan), C.POINTER(C.c_uint64)], cp),
+        "bx_join_seed": ([vp, sz, vp, sz], C.c_uint64),
         "bx_segment_encode": ([C.c_uint64, C.c_uint32, C.c_uint64, vp], None),
         "bx_segment_decode": ([vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)], cp),
         "bx_agent_create": ([C.POINTER(_AgentConfig), C.POINTER(_HotStoreOps), C.POINTER(_TaskDbOps), vp, C.POINTER(vp)], cp),
@@ -119,6 +134,20 @@ def deserialize_segment(blob: bytes) -> Segment:
     if msg:
         raise ValueError(msg.decode())
     return Segment(index=i.value, po2=p.value, seed=s.value, payload=bytes(blob[28:]))
+
+
+def serialize_receipt(r: SegmentReceipt) -> bytes:
+    """"BXSYNRCP" | index u64 | po2 u32 | seal_words u32 | seal (include/bx_agent.h)"""
+    seal = np.ascontiguousarray(r.seal, dtype="<u4")
+    return (b"BXSYNRCP" + int(r.index).to_bytes(8, "little") + int(r.po2).to_bytes(4, "little") + int(seal.size).to_bytes(4, "little")
+            + seal.tobytes())
+
+
+def join_seed(left_seal, right_seal):
+    """bx_join_seed: the seed of a stand-in join (include/bx_agent.h)."""
+    a = np.ascontiguousarray(left_seal, dtype=np.uint32)
+    b = np.ascontiguousarray(right_seal, dtype=np.uint32)
+    return _lib().bx_join_seed(a.ctypes.data, a.size, b.ctypes.data, b.size)
 
 
 def deserialize_receipt(blob: bytes) -> SegmentReceipt:
@@ -178,6 +207,8 @@ class TaskRow:
         self.state = TASK_STATES[info.state]
         self.retries, self.max_retries = info.retries, info.max_retries
         self.error, self.output = info.error.decode(), info.output.decode()
+        self.waiting_on = info.waiting_on
+        self.created_s, self.started_s, self.updated_s = info.created_s, info.started_s, info.updated_s
 
 
 class TaskDb:
@@ -191,11 +222,30 @@ class TaskDb:
         self.ops = self._lib.bx_mem_taskdb_ops(self._h)
         self._ids = []
 
-    def create_task(self, job_id, task_id, task_def, max_retries=3, stream="prove"):
+    def create_task(self, job_id, task_id, task_def, max_retries=3, stream="prove", prerequisites=()):
+        """taskdb::create_task (1_taskdb.sql:197-228): 'pending' while a prerequisite (task ids of the same job) is not done."""
         d = task_def if isinstance(task_def, str) else json.dumps(task_def)
-        _check(self._lib.bx_mem_taskdb_create_task(self._h, stream.encode(), str(job_id).encode(), str(task_id).encode(),
-                                                   d.encode(), max_retries))
+        pre = [str(p).encode() for p in prerequisites]
+        arr = (C.c_char_p * max(len(pre), 1))(*pre)
+        _check(self._lib.bx_mem_taskdb_create_task_with_prereqs(self._h, stream.encode(), str(job_id).encode(), str(task_id).encode(),
+                                                                d.encode(), arr, len(pre), max_retries))
         self._ids.append((str(job_id), str(task_id)))
+
+    def plan_job(self, job_id, n_segments, prove_stream="", join_stream="", aux_stream="", retries=3):
+        """bx_plan_job: the executor's planner loop (executor.rs:566-698) — one task row per planner task, prerequisites as the
+        planner's dependencies.  Returns the task ids created, in creation order."""
+        plan = _JobPlan(prove_stream.encode(), join_stream.encode(), aux_stream.encode(), retries, retries, retries, retries)
+        n = C.c_uint64()
+        _check(self._lib.bx_plan_job(self._h, str(job_id).encode(), n_segments, C.byref(plan), C.byref(n)))
+        ids = [str(i) for i in range(n.value - 2)] + ["resolve", "finalize"]
+        self._ids += [(str(job_id), t) for t in ids]
+        return ids
+
+    def job(self, job_id):
+        info = _JobInfo()
+        _check(self._lib.bx_mem_taskdb_job_info(self._h, str(job_id).encode(), C.byref(info)))
+        return {"state": ("running", "done", "failed")[info.state], "tasks": info.tasks, "pending": info.pending, "ready": info.ready,
+                "running": info.running, "done": info.done, "failed": info.failed, "error": info.error.decode()}
 
     def task(self, job_id, task_id):
         info = _TaskInfo()
@@ -258,7 +308,7 @@ class Agent:
 
     def __init__(self, prover=None, device=0, inflight=None, widths=(16, 256, 64), redis_ttl=8 * 60 * 60, poll_time=1.0,
                  verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20, devices=None, synthetic=True,
-                 terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None):
+                 terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None, join_po2=0, also_streams=""):
         self._lib = _lib()
         self.store = store or HotStore()
         self.taskdb = taskdb or TaskDb()
@@ -267,7 +317,8 @@ class Agent:
         cfg = _AgentConfig(device=device, inflight=inflight or (1 if injected else 3), w_code=widths[0],
                            w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, no_verify=int(not verify),
                            task_stream=task_stream.encode(), synthetic=int(bool(synthetic)), cons_terms=terms, cons_degree=degree,
-                           po2_min=po2_range[0], po2_max=po2_range[1], max_shapes=max_shapes)
+                           po2_min=po2_range[0], po2_max=po2_range[1], max_shapes=max_shapes, join_po2=join_po2,
+                           also_streams=also_streams.encode())
         if devices:
             cfg.n_devices = len(devices)
             for i, d in enumerate(devices):

@@ -396,19 +396,36 @@ struct bx_mem_taskdb {
     struct Row {
         std::string stream, job, task, def, error, output;
         int32_t max_retries = 0, retries = 0, state = BX_TASK_READY;
+        std::vector<std::string> prereqs;  // task_deps rows with this task as post_task_id
+        int32_t waiting_on = 0;            // prerequisites not yet done
+        double created = 0, started = 0, updated = 0;  // seconds since `epoch`
     };
-    std::vector<Row> rows;  // creation order = claim order
+    std::vector<Row> rows;  // creation order = claim order within a stream (tasks_by_stream: created_at ASC)
+    Clock::time_point epoch = Clock::now();
+    double now_s() const { return secs_since(epoch); }
     Row* find_locked(const char* job, const char* task) {
         for (auto& r : rows)
             if (r.job == job && r.task == task) return &r;
         return nullptr;
     }
-    // 1_taskdb.sql:308-338 (the job row is not modelled)
+    // update_task_failed, 1_taskdb.sql:316-347: ready, running and PENDING rows can fail; the job's state is derived (bx_mem_taskdb_job_info)
     int fail_locked(Row* r, const char* error) {
-        if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
+        if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING && r->state != BX_TASK_PENDING)) return 0;
         r->state = BX_TASK_FAILED;
         r->error = error;
+        r->updated = now_s();
         return 1;
+    }
+    // the second half of update_task_done (1_taskdb.sql:296-306): every task waiting on `done` loses one prerequisite and becomes
+    // ready when that was its last (failed dependants stay failed)
+    void release_dependants_locked(const Row& done) {
+        for (auto& r : rows) {
+            if (r.job != done.job || r.state == BX_TASK_FAILED) continue;
+            for (auto& pre : r.prereqs)
+                if (pre == done.task) {
+                    if (r.waiting_on > 0 && --r.waiting_on == 0 && r.state == BX_TASK_PENDING) r.state = BX_TASK_READY;
+                }
+        }
     }
 };
 
@@ -422,6 +439,7 @@ static int tdb_request_work(void* user, const char* stream, bx_ready_task* out, 
             return -1;
         }
         r.state = BX_TASK_RUNNING;
+        r.started = t->now_s();
         memset(out, 0, sizeof *out);
         memcpy(out->job_id, r.job.c_str(), r.job.size());
         memcpy(out->task_id, r.task.c_str(), r.task.size());
@@ -442,6 +460,8 @@ static int tdb_done(void* user, const char* job, const char* task, const char* o
         return -1;
     }
     r->state = BX_TASK_DONE;
+    r->updated = t->now_s();
+    t->release_dependants_locked(*r);
     return 1;
 }
 static int tdb_failed(void* user, const char* job, const char* task, const char* error, char*, size_t) {
@@ -461,6 +481,7 @@ static int tdb_retry(void* user, const char* job, const char* task, char*, size_
     if (!r || r->state != BX_TASK_RUNNING) return 0;
     r->retries += 1;
     r->state = BX_TASK_READY;
+    r->updated = t->now_s();
     r->error.clear();
     if (r->retries > r->max_retries) {
         t->fail_locked(r, "retry max hit");
@@ -498,6 +519,8 @@ struct Pending {
     uint64_t seg_index = 0;
     uint32_t po2 = 0;
     bool opaque = false;  // proved through prove_blob: `wire` already holds the receipt bytes to store
+    enum Kind { Prove, Join, HostOnly } kind = Prove;  // HostOnly: the whole task ran in the first half (resolve / finalize stand-ins)
+    std::vector<std::string> cleanup_keys;  // a join unlinks its children's receipts once its own is stored (join.rs:94-104)
     std::vector<uint32_t> seal;
     size_t words = 0;
     double prove_s = 0;
@@ -544,6 +567,45 @@ struct Finisher {
 };
 }  // namespace
 
+namespace {
+// "BXSYNRCP" | index u64 | po2 u32 | seal_words u32 | seal u32[] (bx_agent.h)
+void receipt_encode(std::vector<uint8_t>& wire, uint64_t index, uint32_t po2, const uint32_t* seal, size_t words) {
+    wire.resize(BX_RECEIPT_HEADER_BYTES + 4 * words);
+    memcpy(wire.data(), BX_RECEIPT_MAGIC, 8);
+    put_le(wire.data() + 8, index, 8);
+    put_le(wire.data() + 16, po2, 4);
+    put_le(wire.data() + 20, words, 4);
+    for (size_t i = 0; i < words; ++i) put_le(wire.data() + BX_RECEIPT_HEADER_BYTES + 4 * i, seal[i], 4);
+}
+bool receipt_decode(const uint8_t* p, size_t n, uint64_t* index, uint32_t* po2, std::vector<uint32_t>* seal) {
+    if (!p || n < BX_RECEIPT_HEADER_BYTES || memcmp(p, BX_RECEIPT_MAGIC, 8) != 0) return false;
+    const uint64_t words = get_le(p + 20, 4);
+    if (n != BX_RECEIPT_HEADER_BYTES + 4 * words) return false;
+    if (index) *index = get_le(p + 8, 8);
+    if (po2) *po2 = (uint32_t)get_le(p + 16, 4);
+    seal->resize(words);
+    for (size_t i = 0; i < words; ++i) (*seal)[i] = (uint32_t)get_le(p + BX_RECEIPT_HEADER_BYTES + 4 * i, 4);
+    return true;
+}
+}  // namespace
+
+extern "C" uint64_t bx_join_seed(const uint32_t* left, size_t nl, const uint32_t* right, size_t nr) {
+    uint64_t h = 0xCBF29CE484222325ull;  // FNV-1a, 64 bit
+    auto eat = [&h](const uint32_t* w, size_t n) {
+        for (size_t i = 0; i < n; ++i)
+            for (int b = 0; b < 4; ++b) {
+                h ^= (uint8_t)(w[i] >> (8 * b));
+                h *= 0x100000001B3ull;
+            }
+    };
+    if (left) eat(left, nl);
+    if (right) eat(right, nr);
+    uint64_t z = h + 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 struct bx_agent;
 struct bx_agent {
     bx_agent_config cfg;
@@ -554,6 +616,7 @@ struct bx_agent {
     std::vector<std::unique_ptr<Lane>> lanes;
     Metrics metrics;
     std::atomic<int> stop{0};
+    std::vector<std::string> streams;  // task_stream first, then also_streams: a lane claims from the first that has work
     std::mutex create_mu;  // device buffer allocation of a new shape is serialised across lanes
     // VerifierContext of the HIP prover's agent (`verifier_ctx`, lib.rs:241): the control ID of every buffer set a lane creates.
     // Finishers verify under the shared lock, a lane adding a new shape takes it exclusively.
@@ -728,18 +791,12 @@ struct bx_agent {
             if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
                 // the HIP prover's agent checks the code root against its own context; an injected prover's seals against the
                 // circuit's published IDs (check_code)
-                std::shared_lock<std::shared_mutex> r(vctx_mu);
-                if (const char* ve = bx_verify_segment_with_context(p->seal.data(), p->words, nullptr, hip ? vctx : nullptr))
+                if (const char* ve = verify_seal(p->seal.data(), p->words))
                     return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
             }
             // a synthetic seal is not a lifted receipt: it never goes under the key Join workers read
             output_key = p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + p->task.task_id;
-            p->wire.resize(BX_RECEIPT_HEADER_BYTES + 4 * p->words);
-            memcpy(p->wire.data(), BX_RECEIPT_MAGIC, 8);
-            put_le(p->wire.data() + 8, p->seg_index, 8);
-            put_le(p->wire.data() + 16, p->po2, 4);
-            put_le(p->wire.data() + 20, p->words, 4);
-            for (size_t i = 0; i < p->words; ++i) put_le(p->wire.data() + BX_RECEIPT_HEADER_BYTES + 4 * i, p->seal[i], 4);
+            receipt_encode(p->wire, p->seg_index, p->po2, p->seal.data(), p->words);
         }
         metrics.record_task_operation("prove", "prove_segment", "success", p->prove_s);  // helpers::record_task, prove.rs:57
 
@@ -752,6 +809,111 @@ struct bx_agent {
         return "";
     }
 
+    // verify_integrity_with_context against the agent's context (HIP prover) or the circuit's published IDs (injected prover)
+    const char* verify_seal(const uint32_t* seal, size_t words) {
+        std::shared_lock<std::shared_mutex> r(vctx_mu);
+        return bx_verify_segment_with_context(seal, words, nullptr, hip ? vctx : nullptr);
+    }
+    // a stored synthetic receipt: GET + deserialize (+ verify)
+    std::string load_receipt(const std::string& key, const char* which, const char* code_deser, const char* code_verify, uint64_t* index, uint32_t* po2,
+                             std::vector<uint32_t>* seal) {
+        StoreValue blob;
+        std::string e = store_get(key, &blob);
+        if (!e.empty()) return e;
+        if (!receipt_decode(blob.data(), blob.size(), index, po2, seal)) return std::string(code_deser) + " Failed to deserialize " + which + " receipt";
+        if (!cfg.no_verify)
+            if (const char* ve = verify_seal(seal->data(), seal->size())) return std::string(code_verify) + " Failed to verify " + which + " receipt integrity: " + ve;
+        return "";
+    }
+
+    // tasks::join::join (join.rs:18-113) with a STAND-IN for `prover.join(&left, &right)`: one synthetic segment of 2^join_po2
+    // cycles seeded by the two children's seals (bx_agent.h, "Stand-ins for the recursion tasks").  First half: fetch, verify, prove.
+    std::string join_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t idx, uint64_t left, uint64_t right, Pending* out) {
+        out->start = Clock::now();
+        out->task = task;
+        out->kind = Pending::Join;
+        out->opaque = false;
+        out->job_prefix = std::string("job:") + task.job_id;
+        const std::string prefix = out->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":";
+        const std::string lk = prefix + std::to_string(left), rk = prefix + std::to_string(right);
+        std::vector<uint32_t> ls, rs;
+        std::string e = load_receipt(lk, "left", "[BENTO-JOIN-001]", "[BENTO-JOIN-003]", nullptr, nullptr, &ls);
+        if (e.empty()) e = load_receipt(rk, "right", "[BENTO-JOIN-002]", "[BENTO-JOIN-004]", nullptr, nullptr, &rs);
+        if (!e.empty()) return e.rfind("[BENTO-JOIN", 0) == 0 ? e : "failed to get receipts for keys: " + lk + ", " + rk + ": " + e;
+        out->cleanup_keys = {lk, rk};
+        out->seg_index = idx;
+        out->po2 = cfg.join_po2;
+        uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+        bx_segment_encode(idx, cfg.join_po2, bx_join_seed(ls.data(), ls.size(), rs.data(), rs.size()), wire);
+        auto join_start = Clock::now();
+        if (!prover.prove_segment) return "Missing prover from join task";
+        size_t cap = prover.seal_words(prover.user, lane_idx, out->po2);
+        if (cap == 0) {
+            if (hip && !hip_err.empty()) return "join_receipts: " + hip_err;
+            return "join_receipts: no prover for a stand-in join of po2 " + std::to_string(out->po2);
+        }
+        if (out->seal.size() < cap) out->seal.resize(cap);
+        out->words = 0;
+        if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->po2, wire, sizeof wire, out->seal.data(), cap, &out->words)) {
+            metrics.record_task_operation("join", "join_receipts", "error", secs_since(join_start));
+            return pe;
+        }
+        out->prove_s = secs_since(join_start);
+        metrics.record_task_operation("join", "join_receipts", "success", out->prove_s);
+        return "";
+    }
+    //   second half: verify the joined receipt, store it, unlink the children
+    std::string join_finish(Pending* p) {
+        if (!cfg.no_verify)
+            if (const char* ve = verify_seal(p->seal.data(), p->words)) return std::string("[BENTO-JOIN-006] Failed to verify join receipt integrity: ") + ve;
+        receipt_encode(p->wire, p->seg_index, p->po2, p->seal.data(), p->words);
+        std::string e = store_set(p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + std::to_string(p->seg_index), p->wire, cfg.redis_ttl);
+        if (!e.empty()) return "Failed to store joined receipt: " + e;
+        for (auto& k : p->cleanup_keys) {
+            e = store_unlink(k);
+            if (!e.empty()) return "Failed to delete join receipt keys: " + e;
+        }
+        metrics.record_task_operation("join", "complete", "success", secs_since(p->start));
+        return "";
+    }
+    // tasks::resolve::resolver without assumptions (resolve.rs:18-180): the root receipt is read, checked and written back
+    std::string resolve_stage(const bx_ready_task& task, uint64_t max_idx, Pending* out) {
+        out->start = Clock::now();
+        out->task = task;
+        out->kind = Pending::HostOnly;
+        out->opaque = false;
+        const std::string key = std::string("job:") + task.job_id + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + std::to_string(max_idx);
+        uint64_t index = 0;
+        uint32_t po2 = 0;
+        std::vector<uint32_t> seal;
+        std::string e = load_receipt(key, "root", "[BENTO-RESOLVE-001]", "[BENTO-RESOLVE-001]", &index, &po2, &seal);
+        if (!e.empty()) return "segment data not found for root receipt key: " + key + ": " + e;
+        receipt_encode(out->wire, index, po2, seal.data(), seal.size());
+        e = store_set(key, out->wire, cfg.redis_ttl);
+        if (!e.empty()) return "Failed to set root receipt key with expiry: " + e;
+        metrics.record_task_operation("resolve", "complete", "success", secs_since(out->start));
+        return "";
+    }
+    // tasks::finalize::finalize (finalize.rs:21-95): the root receipt is verified and becomes the job's rollup receipt (the reference
+    // uploads receipts/stark/{job}.bincode to S3; here the hot store holds receipts/stark/{job}.synthetic)
+    std::string finalize_stage(const bx_ready_task& task, uint64_t max_idx, Pending* out) {
+        out->start = Clock::now();
+        out->task = task;
+        out->kind = Pending::HostOnly;
+        out->opaque = false;
+        const std::string key = std::string("job:") + task.job_id + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + std::to_string(max_idx);
+        uint64_t index = 0;
+        uint32_t po2 = 0;
+        std::vector<uint32_t> seal;
+        std::string e = load_receipt(key, "root", "[BENTO-FINALIZE-001]", "[BENTO-FINALIZE-001]", &index, &po2, &seal);
+        if (!e.empty()) return "failed to get the root receipt key: " + key + ": " + e;
+        receipt_encode(out->wire, index, po2, seal.data(), seal.size());
+        e = store_set(std::string(BX_SYNTHETIC_ROLLUP_PREFIX) + task.job_id + BX_SYNTHETIC_ROLLUP_SUFFIX, out->wire, cfg.redis_ttl);
+        if (!e.empty()) return "Failed to upload final receipt to obj store: " + e;
+        metrics.record_task_operation("finalize", "complete", "success", secs_since(out->start));
+        return "";
+    }
+
     // Agent::process_work (lib.rs:445-530), first half: TaskType dispatch + the device half of the prove task.
     std::string dispatch(uint32_t lane, const bx_ready_task& task, Pending* out) {
         JVal def;
@@ -759,12 +921,36 @@ struct bx_agent {
         if (!parse_json(task.task_def, &def) || def.kind != JVal::Obj || def.obj.size() != 1) return bad;
         const std::string& variant = def.obj[0].first;
         const JVal& body = def.obj[0].second;
+        auto uint_field = [&](const char* name, uint64_t* v) {
+            const JVal* f = body.kind == JVal::Obj ? body.find(name) : nullptr;
+            if (!f || f->kind != JVal::Num || !f->is_uint) return false;
+            *v = f->u;
+            return true;
+        };
         if (variant == "Prove") {
-            const JVal* idx = body.kind == JVal::Obj ? body.find("index") : nullptr;
-            if (!idx || idx->kind != JVal::Num || !idx->is_uint) return bad;
-            std::string e = prove_stage(lane, task, idx->u, out);
+            uint64_t idx = 0;
+            if (!uint_field("index", &idx)) return bad;
+            out->kind = Pending::Prove;
+            out->cleanup_keys.clear();
+            std::string e = prove_stage(lane, task, idx, out);
             if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
             return "";
+        }
+        // the recursion tasks of a planned job: served by their stand-ins in synthetic mode (bx_agent.h), refused otherwise
+        if (cfg.synthetic && !prover.prove_blob && (variant == "Join" || variant == "Resolve" || variant == "Finalize")) {
+            uint64_t idx = 0, left = 0, right = 0, max_idx = 0;
+            if (variant == "Join") {
+                if (!uint_field("idx", &idx) || !uint_field("left", &left) || !uint_field("right", &right)) return bad;
+                std::string e = join_stage(lane, task, idx, left, right, out);
+                return e.empty() ? "" : "[BENTO-WF-119] Join failed: " + e;
+            }
+            if (!uint_field("max_idx", &max_idx)) return bad;
+            if (variant == "Resolve") {
+                std::string e = resolve_stage(task, max_idx, out);
+                return e.empty() ? "" : "[BENTO-WF-123] Resolve failed: " + e;
+            }
+            std::string e = finalize_stage(task, max_idx, out);
+            return e.empty() ? "" : "[BENTO-WF-125] Finalize failed: " + e;
         }
         static const char* others[] = {"Executor", "Join", "Resolve", "Finalize", "Snark", "Keccak", "Union"};
         for (const char* o : others)
@@ -773,8 +959,13 @@ struct bx_agent {
     }
     // second half: host half of the prove task + update_task_done.  `fatal` is set when the task-db call itself failed.
     std::string complete(Pending* p, bool* fatal) {
-        std::string e = finish_stage(p);
-        if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
+        if (p->kind == Pending::Join) {
+            std::string e = join_finish(p);
+            if (!e.empty()) return "[BENTO-WF-119] Join failed: " + e;
+        } else if (p->kind == Pending::Prove) {
+            std::string e = finish_stage(p);
+            if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
+        }
         char eb[256] = {0};
         int rc = taskdb.update_task_done(taskdb.user, p->task.job_id, p->task.task_id, "null", eb, sizeof eb);  // prover returns ()
         if (rc < 0) {
@@ -885,8 +1076,12 @@ struct bx_agent {
         while (!stop.load(std::memory_order_relaxed)) {
             bx_ready_task task;
             char eb[256] = {0};
-            int rc = taskdb.request_work(taskdb.user, cfg.task_stream, &task, eb, sizeof eb);
-            metrics.record_task_claim(cfg.task_stream, rc < 0 ? "error" : rc == 0 ? "empty" : "claimed");  // lib.rs:613-623
+            int rc = 0;
+            for (const std::string& st : streams) {  // the lane's own stream first, then the ones it also serves
+                rc = taskdb.request_work(taskdb.user, st.c_str(), &task, eb, sizeof eb);
+                metrics.record_task_claim(st.c_str(), rc < 0 ? "error" : rc == 0 ? "empty" : "claimed");  // lib.rs:613-623
+                if (rc != 0) break;
+            }
             if (rc < 0) {
                 set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + eb);
                 break;
@@ -976,8 +1171,13 @@ bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t) {
 }
 const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
                                       int32_t max_retries) {
+    return bx_mem_taskdb_create_task_with_prereqs(t, stream, job, task, def, nullptr, 0, max_retries);
+}
+// taskdb::create_task, 1_taskdb.sql:197-228
+const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
+                                                   const char* const* prereqs, size_t n_prereqs, int32_t max_retries) {
     try {
-        if (!t || !stream || !job || !task || !def) return "bx_mem_taskdb_create_task: NULL argument";
+        if (!t || !stream || !job || !task || !def || (n_prereqs && !prereqs)) return "bx_mem_taskdb_create_task: NULL argument";
         std::lock_guard<std::mutex> g(t->mu);
         if (t->find_locked(job, task)) return fail(std::string("task already exists: ") + job + ":" + task);
         bx_mem_taskdb::Row r;
@@ -986,10 +1186,140 @@ const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* stream, cons
         r.task = task;
         r.def = def;
         r.max_retries = max_retries;
+        r.created = t->now_s();
+        for (size_t i = 0; i < n_prereqs; ++i) {
+            if (!prereqs[i]) return "bx_mem_taskdb_create_task: NULL prerequisite";
+            const bx_mem_taskdb::Row* pre = t->find_locked(job, prereqs[i]);
+            // task_deps has a foreign key on (job_id, pre_task_id)
+            if (!pre) return fail(std::string("prerequisite task does not exist: ") + job + ":" + prereqs[i]);
+            r.prereqs.emplace_back(prereqs[i]);
+            if (pre->state != BX_TASK_DONE) r.waiting_on += 1;
+        }
+        r.state = r.waiting_on ? BX_TASK_PENDING : BX_TASK_READY;
         t->rows.push_back(std::move(r));
         return nullptr;
     } catch (const std::exception&) {
         return "bx_mem_taskdb_create_task: out of memory";
+    }
+}
+const char* bx_mem_taskdb_job_info(bx_mem_taskdb* t, const char* job, bx_job_info* out) {
+    try {
+        if (!t || !job || !out) return "bx_mem_taskdb_job_info: NULL argument";
+        std::lock_guard<std::mutex> g(t->mu);
+        memset(out, 0, sizeof *out);
+        for (auto& r : t->rows) {
+            if (r.job != job) continue;
+            out->tasks++;
+            switch (r.state) {
+                case BX_TASK_PENDING: out->pending++; break;
+                case BX_TASK_READY: out->ready++; break;
+                case BX_TASK_RUNNING: out->running++; break;
+                case BX_TASK_DONE: out->done++; break;
+                default:
+                    if (!out->failed++) snprintf(out->error, sizeof out->error, "%s", r.error.c_str());  // the first failure is the job's error
+            }
+        }
+        if (!out->tasks) return fail(std::string("no such job: ") + job);
+        out->state = out->failed ? BX_JOB_FAILED : out->done == out->tasks ? BX_JOB_DONE : BX_JOB_RUNNING;
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_mem_taskdb_job_info: out of memory";
+    }
+}
+
+// The executor's writer task (executor.rs:566-698) + process_task (:56-250) for a job whose segments are already in the hot store.
+const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, const bx_job_plan* plan_in, uint64_t* tasks_created) {
+    if (!t || !job) return "bx_plan_job: NULL argument";
+    if (n_segments == 0) return "bx_plan_job: a job has at least one segment";
+    bx_planner* pl = nullptr;
+    try {
+        bx_job_plan plan;
+        memset(&plan, 0, sizeof plan);
+        if (plan_in) plan = *plan_in;
+        else plan.prove_retries = plan.join_retries = plan.resolve_retries = plan.finalize_retries = 3;
+        plan.prove_stream[sizeof plan.prove_stream - 1] = plan.join_stream[sizeof plan.join_stream - 1] = plan.aux_stream[sizeof plan.aux_stream - 1] = 0;
+        const std::string prove_stream = plan.prove_stream[0] ? plan.prove_stream : "prove";
+        const std::string join_stream = plan.join_stream[0] ? plan.join_stream : prove_stream;
+        const std::string aux_stream = plan.aux_stream[0] ? plan.aux_stream : "aux";
+        if (const char* e = bx_planner_create(&pl)) return e;
+        uint64_t created = 0;
+        std::string err;
+        auto process_task = [&](const bx_plan_task& tt, uint64_t segment_index) -> bool {
+            const std::string name = std::to_string(tt.task_number);
+            const char* e = nullptr;
+            switch (tt.command) {
+                case BX_PLAN_SEGMENT:  // the segment INDEX, not the planner's task number, goes into the request (executor.rs:94-104)
+                    e = bx_mem_taskdb_create_task(t, prove_stream.c_str(), job, name.c_str(),
+                                                  ("{\"Prove\":{\"index\":" + std::to_string(segment_index) + "}}").c_str(), plan.prove_retries);
+                    created += !e;
+                    break;
+                case BX_PLAN_JOIN: {
+                    const std::string l = std::to_string(tt.depends_on[0]), r = std::to_string(tt.depends_on[1]);
+                    const char* pre[2] = {l.c_str(), r.c_str()};
+                    e = bx_mem_taskdb_create_task_with_prereqs(t, join_stream.c_str(), job, name.c_str(),
+                                                               ("{\"Join\":{\"idx\":" + name + ",\"left\":" + l + ",\"right\":" + r + "}}").c_str(), pre, 2,
+                                                               plan.join_retries);
+                    created += !e;
+                    break;
+                }
+                case BX_PLAN_FINALIZE: {
+                    const std::string m = std::to_string(tt.depends_on[0]);
+                    const char* pre[1] = {m.c_str()};
+                    e = bx_mem_taskdb_create_task_with_prereqs(t, join_stream.c_str(), job, "resolve",
+                                                               ("{\"Resolve\":{\"max_idx\":" + m + ",\"union_max_idx\":null}}").c_str(), pre, 1,
+                                                               plan.resolve_retries);
+                    created += !e;
+                    if (!e) {
+                        const char* pre2[1] = {"resolve"};
+                        e = bx_mem_taskdb_create_task_with_prereqs(t, aux_stream.c_str(), job, "finalize",
+                                                                   ("{\"Finalize\":{\"max_idx\":" + m + "}}").c_str(), pre2, 1, plan.finalize_retries);
+                        created += !e;
+                    }
+                    break;
+                }
+                default: e = "bx_plan_job: the planner produced a keccak/union task for a job without coprocessor requests";
+            }
+            if (e) err = e;
+            return !e;
+        };
+        auto drain = [&](uint64_t segment_index) -> bool {
+            for (;;) {
+                bx_plan_task tt;
+                int has = 0;
+                if (const char* e = bx_planner_next_task(pl, &tt, &has)) {
+                    err = e;
+                    return false;
+                }
+                if (!has) return true;
+                if (!process_task(tt, segment_index)) return false;
+            }
+        };
+        bool ok = true;
+        for (uint64_t i = 0; ok && i < n_segments; ++i) {
+            uint64_t n = 0;
+            if (const char* e = bx_planner_enqueue_segment(pl, &n)) {
+                err = e;
+                ok = false;
+            } else {
+                ok = drain(i);
+            }
+        }
+        if (ok) {
+            uint64_t n = 0;
+            if (const char* e = bx_planner_finish(pl, &n)) {
+                err = e;
+                ok = false;
+            } else {
+                ok = drain(0);
+            }
+        }
+        bx_planner_destroy(pl);
+        pl = nullptr;
+        if (tasks_created) *tasks_created = created;
+        return ok ? nullptr : fail("bx_plan_job: " + err);
+    } catch (const std::exception& e) {
+        if (pl) bx_planner_destroy(pl);
+        return fail(std::string("bx_plan_job: ") + e.what());
     }
 }
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const char* task, bx_task_info* out) {
@@ -1001,6 +1331,10 @@ const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const cha
         out->state = r->state;
         out->retries = r->retries;
         out->max_retries = r->max_retries;
+        out->waiting_on = r->waiting_on;
+        out->created_s = r->created;
+        out->started_s = r->started;
+        out->updated_s = r->updated;
         snprintf(out->error, sizeof out->error, "%s", r->error.c_str());
         snprintf(out->output, sizeof out->output, "%s", r->output.c_str());
         return nullptr;
@@ -1072,6 +1406,19 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
             return "bx_agent_create: po2_min / po2_max must satisfy 9 <= po2_min <= po2_max <= 24";
         }
         if (!a->cfg.max_shapes) a->cfg.max_shapes = 2;
+        if (!a->cfg.join_po2) a->cfg.join_po2 = 18;
+        if (a->cfg.join_po2 < 9 || a->cfg.join_po2 > 24) {
+            delete a;
+            return "bx_agent_create: join_po2 must be in [9, 24]";
+        }
+        a->cfg.also_streams[sizeof a->cfg.also_streams - 1] = 0;
+        a->streams.emplace_back(a->cfg.task_stream);
+        for (const char* q = a->cfg.also_streams; *q;) {
+            const char* e = strchr(q, ',');
+            std::string name(q, e ? (size_t)(e - q) : strlen(q));
+            if (!name.empty() && name != a->streams[0]) a->streams.push_back(name);
+            q = e ? e + 1 : q + strlen(q);
+        }
         if (a->cfg.n_devices == 0) {
             a->cfg.n_devices = 1;
             a->cfg.devices[0] = a->cfg.device;

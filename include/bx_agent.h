@@ -104,13 +104,17 @@ size_t bx_mem_store_key_count(bx_mem_store* s);
 const char* bx_mem_store_keys(bx_mem_store* s, char* out, size_t cap);
 
 typedef struct bx_mem_taskdb bx_mem_taskdb;
-enum bx_task_state { BX_TASK_READY = 0, BX_TASK_RUNNING = 1, BX_TASK_DONE = 2, BX_TASK_FAILED = 3 };
+/* task_state, 1_taskdb.sql:12-19 (pending = waiting on the completion of prerequisites) */
+enum bx_task_state { BX_TASK_READY = 0, BX_TASK_RUNNING = 1, BX_TASK_DONE = 2, BX_TASK_FAILED = 3, BX_TASK_PENDING = 4 };
 typedef struct bx_task_info {
     int32_t state; /* enum bx_task_state */
     int32_t retries;
     int32_t max_retries;
     char error[1100];
     char output[256];
+    int32_t waiting_on;  /* prerequisites not yet done (tasks.waiting_on) */
+    double created_s, started_s, updated_s; /* seconds since the task db was created: created_at, started_at (most recent claim),
+                                             * updated_at (done | failed | retry); 0 = not yet */
 } bx_task_info;
 const char* bx_mem_taskdb_create(bx_mem_taskdb** out);
 void bx_mem_taskdb_destroy(bx_mem_taskdb* t);
@@ -118,8 +122,42 @@ bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t);
 /* taskdb::create_task for a task with no prerequisites (it is 'ready' at once). */
 const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
                                       const char* task_def_json, int32_t max_retries);
+/* taskdb::create_task (1_taskdb.sql:197-228): the task is 'pending' while any of its prerequisites (task ids of the same job,
+ * which must exist) is not 'done', 'ready' otherwise; update_task_done on a prerequisite decrements waiting_on and releases
+ * the task when it reaches zero (1_taskdb.sql:296-306); update_task_failed also applies to pending tasks (:324). */
+const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
+                                                   const char* task_def_json, const char* const* prerequisites, size_t n_prerequisites,
+                                                   int32_t max_retries);
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const char* task_id, bx_task_info* out);
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
+/* job_state (1_taskdb.sql:5-9): running until every task is done (-> done: update_task_done, :308-311) or one has failed
+ * (-> failed with that task's error: update_task_failed, :340-347). */
+enum bx_job_state { BX_JOB_RUNNING = 0, BX_JOB_DONE = 1, BX_JOB_FAILED = 2 };
+typedef struct bx_job_info {
+    int32_t state; /* enum bx_job_state */
+    uint64_t tasks, pending, ready, running, done, failed;
+    char error[1100];
+} bx_job_info;
+const char* bx_mem_taskdb_job_info(bx_mem_taskdb* t, const char* job_id, bx_job_info* out);
+
+/* ------------------------------------------------------------------------------------ the planner's DAG as tasks ---- */
+/* What the executor's writer task does with the planner (bento/crates/workflow/src/tasks/executor.rs:566-698 driving
+ * process_task, :56-250) for a job of `n_segments` segments already flushed to the hot store: enqueue_segment per segment,
+ * then finish(), creating one task row per planner task —
+ *   Segment  -> task "{n}"       {"Prove":{"index":i}}                     prove stream, no prerequisites      (:92-127)
+ *   Join     -> task "{n}"       {"Join":{"idx":n,"left":l,"right":r}}     join stream, prerequisites [l, r]   (:128-153)
+ *   Finalize -> task "resolve"   {"Resolve":{"max_idx":m,"union_max_idx":null}}  join stream, prerequisite [m] (:176-209)
+ *               task "finalize"  {"Finalize":{"max_idx":m}}                aux stream, prerequisite ["resolve"] (:211-229)
+ * (no keccak / union / snark tasks: a synthetic job has no coprocessor requests and compress = None).  join_stream "" = the
+ * prove stream, as in the reference without JOIN_STREAM (executor.rs:515-524). */
+typedef struct bx_job_plan {
+    char prove_stream[64]; /* "" = "prove" */
+    char join_stream[64];  /* "" = prove_stream */
+    char aux_stream[64];   /* "" = "aux" */
+    int32_t prove_retries, join_retries, resolve_retries, finalize_retries; /* the reference's defaults are 3 */
+} bx_job_plan;
+const char* bx_plan_job(bx_mem_taskdb* t, const char* job_id, uint64_t n_segments, const bx_job_plan* plan /* NULL = defaults */,
+                        uint64_t* tasks_created);
 
 /* ---------------------------------------------------------------------------------- segment / receipt wire ---- */
 /* The reference moves bincode(risc0_zkvm::Segment) in and bincode(receipt) out (tasks/mod.rs:40-47); both need risc0's type
@@ -135,7 +173,21 @@ size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
  * A blob without the tag (e.g. a real bincode Segment) fails the task with a message naming the mismatch. */
 #define BX_RECEIPT_HEADER_BYTES 24
 #define BX_RECEIPT_MAGIC "BXSYNRCP"
+/* Stand-ins for the recursion tasks (synthetic mode only; the recursion circuit is not available offline), so
+ * that the DAG the planner produces — K proves, a log-depth join tail, resolve, finalize — runs through the same lanes:
+ *   Join{idx,left,right}  (join.rs:18-113)  reads both child receipts, verifies both, proves ONE synthetic segment of
+ *                         2^join_po2 cycles whose seed is bx_join_seed(left seal, right seal) — a stand-in for
+ *                         `prover.join(&left, &right)`, NOT a recursion proof — verifies it, stores it under
+ *                         job:{id}:synthetic_receipts:{idx} and unlinks the children;
+ *   Resolve{max_idx}      (resolve.rs:18-180 without assumptions) reads, verifies and re-stores the root receipt;
+ *   Finalize{max_idx}     (finalize.rs:21-95) reads and verifies the root receipt and stores it under
+ *                         receipts/stark/{job}.synthetic (the reference writes receipts/stark/{job}.bincode to S3).
+ * Everything these tasks store is tagged BXSYNRCP and lives under synthetic_* keys. */
 #define BX_SYNTHETIC_RECEIPT_PATH "synthetic_receipts"
+#define BX_SYNTHETIC_ROLLUP_PREFIX "receipts/stark/"
+#define BX_SYNTHETIC_ROLLUP_SUFFIX ".synthetic"
+/* seed of a stand-in join: FNV-1a (64 bit) over the little-endian bytes of the left seal then the right seal, through splitmix64 */
+uint64_t bx_join_seed(const uint32_t* left_seal, size_t left_words, const uint32_t* right_seal, size_t right_words);
 #define BX_RECUR_RECEIPT_PATH "recursion_receipts"
 /* bx_segment_encode / bx_segment_decode and the segment's layout: bx_prover.h ("the segment on the wire"). */
 
@@ -177,6 +229,10 @@ typedef struct bx_agent_config {
     uint32_t po2_min, po2_max;        /* segment sizes the built-in prover accepts (within 9..24); 0 = 9 / 22.  Others fail the task.  A lane's buffers are 8.5 GB at 2^20, 34 GB at 2^22, 135 GB at 2^24 (16/256/64): size po2_max x inflight for the GPU */
     uint32_t max_shapes;     /* buffer sets (one per segment size, several GB at po2 20) cached per lane, least recently used
                               * evicted; 0 = 2 */
+    uint32_t join_po2;       /* size of the stand-in join proofs (see "Stand-ins for the recursion tasks"); 0 = 18, the size of
+                              * the reference's recursion proofs */
+    char also_streams[128];  /* comma-separated worker types a lane also claims from when its task_stream is empty, in order
+                              * (e.g. "aux" to serve the finalize task of a planned job from the same process); "" = none */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;

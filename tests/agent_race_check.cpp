@@ -48,7 +48,102 @@ static const char* prove(void*, uint32_t lane, uint32_t, const uint8_t* segment,
     return nullptr;
 }
 
+// Second phase: a PLANNED job (bx_plan_job: K proves -> log-depth tail of stand-in joins -> resolve -> finalize) through the same
+// 6 lanes with the same randomly failing prover: every task ends done exactly once, and no task was claimed before each of its
+// prerequisites was done (timestamps of the task db), whatever the interleaving of lanes, finishers and retries.
+static int planned_job_phase(void) {
+    bx_mem_store* store = nullptr;
+    bx_mem_taskdb* db = nullptr;
+    if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;
+    bx_hot_store_ops sops = bx_mem_store_ops(store);
+    bx_taskdb_ops tops = bx_mem_taskdb_ops(db);
+    const int K = 97;
+    for (int i = 0; i < K; ++i) {
+        uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+        bx_segment_encode((uint64_t)i, 10, 5000 + (uint64_t)i, wire);
+        std::string key = "job:dag:segments:" + std::to_string(i);
+        if (sops.set_ex(sops.user, key.c_str(), wire, sizeof wire, 0, nullptr, 0) != 0) return 1;
+    }
+    bx_job_plan plan;
+    memset(&plan, 0, sizeof plan);
+    plan.prove_retries = plan.join_retries = plan.resolve_retries = plan.finalize_retries = 50;  // the injected failures never exhaust them
+    uint64_t created = 0;
+    if (const char* e = bx_plan_job(db, "dag", K, &plan, &created)) {
+        fprintf(stderr, "plan: %s\n", e);
+        return 1;
+    }
+    if (created != (uint64_t)(2 * K - 1 + 2)) return 1;
+    bx_agent_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.inflight = 2;
+    cfg.n_devices = 3;
+    cfg.devices[0] = 0, cfg.devices[1] = 1, cfg.devices[2] = 2;
+    cfg.synthetic = 1;
+    cfg.poll_time = 0.001;
+    cfg.join_po2 = 9;
+    snprintf(cfg.also_streams, sizeof cfg.also_streams, "aux");
+    bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};
+    bx_agent* agent = nullptr;
+    if (const char* e = bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) {
+        fprintf(stderr, "create: %s\n", e);
+        return 1;
+    }
+    uint64_t done = 0;
+    if (const char* e = bx_agent_poll_work(agent, 5, &done)) {
+        fprintf(stderr, "poll: %s\n", e);
+        return 1;
+    }
+    bx_job_info job;
+    if (bx_mem_taskdb_job_info(db, "dag", &job)) return 1;
+    if (job.state != BX_JOB_DONE || job.done != created || done != created) {
+        fprintf(stderr, "planned job: state %d done %llu of %llu (agent %llu) failed %llu: %s\n", job.state, (unsigned long long)job.done,
+                (unsigned long long)created, (unsigned long long)done, (unsigned long long)job.failed, job.error);
+        return 1;
+    }
+    // dependencies in time: replay the planner and compare claim / completion times
+    bx_planner* pl = nullptr;
+    if (bx_planner_create(&pl)) return 1;
+    uint64_t n = 0;
+    for (int i = 0; i < K; ++i)
+        if (bx_planner_enqueue_segment(pl, &n)) return 1;
+    if (bx_planner_finish(pl, &n)) return 1;
+    int joins = 0;
+    for (uint64_t k = 0; k < bx_planner_task_count(pl); ++k) {
+        bx_plan_task t;
+        if (bx_planner_get_task(pl, k, &t)) return 1;
+        if (t.command != BX_PLAN_JOIN) continue;
+        ++joins;
+        bx_task_info me, pre;
+        if (bx_mem_taskdb_task_info(db, "dag", std::to_string(t.task_number).c_str(), &me)) return 1;
+        for (uint32_t d = 0; d < t.n_depends_on; ++d) {
+            if (bx_mem_taskdb_task_info(db, "dag", std::to_string(t.depends_on[d]).c_str(), &pre)) return 1;
+            if (pre.state != BX_TASK_DONE || me.started_s < pre.updated_s) {
+                fprintf(stderr, "join %llu was claimed at %.6f before its prerequisite %llu was done at %.6f\n", (unsigned long long)t.task_number,
+                        me.started_s, (unsigned long long)t.depends_on[d], pre.updated_s);
+                return 1;
+            }
+        }
+    }
+    bx_planner_destroy(pl);
+    if (joins != K - 1) return 1;
+    bx_task_info res, fin;
+    if (bx_mem_taskdb_task_info(db, "dag", "resolve", &res) || bx_mem_taskdb_task_info(db, "dag", "finalize", &fin)) return 1;
+    if (fin.started_s < res.updated_s) return 1;
+    if (bx_agent_destroy(agent)) return 1;
+    // what is left in the store: the root receipt and the rollup (every join unlinked its children, every prove its segment)
+    size_t keys = bx_mem_store_key_count(store);
+    bx_mem_taskdb_destroy(db);
+    bx_mem_store_destroy(store);
+    if (keys != 2) {
+        fprintf(stderr, "planned job: %zu keys left in the hot store\n", keys);
+        return 1;
+    }
+    printf("planned job ok: %llu tasks (%d proves, %d joins, resolve, finalize)\n", (unsigned long long)created, K, joins);
+    return 0;
+}
+
 int main() {
+    if (planned_job_phase()) return 1;
     bx_mem_store* store = nullptr;
     bx_mem_taskdb* db = nullptr;
     if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;

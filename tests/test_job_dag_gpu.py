@@ -1,0 +1,98 @@
+"""GPU: a planned job — 16 segment proofs, the log-depth tail of stand-in joins, resolve, finalize — through the HIP prover's lanes.
+
+The Join tasks are STAND-INS for the recursion proofs (include/bx_agent.h: one synthetic segment seeded by the hash of the two
+children's seals), so the rollup seal commits to every seal below it: recomputing that chain with the CPU oracle's prover checks
+every one of the 31 proofs of the job word for word.  Reference flow: executor.rs:566-698 (planner -> task rows), join.rs:18-113,
+resolve.rs, finalize.rs; prerequisites bento/crates/taskdb/migrations/1_taskdb.sql:197-228,296-306.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chain(n, seg_po2, join_po2, widths, seed_of):
+    from boundless_amd import agent as ag
+    from boundless_amd.planner import Planner
+
+    p = Planner()
+    seals, root = {}, None
+
+    def drain(i):
+        nonlocal root
+        while True:
+            t = p.next_task()
+            if t is None:
+                return
+            if t.command == "Segment":
+                seals[t.task_number] = ol.prove_segment(seg_po2, *widths, seed_of(i))[0]
+            elif t.command == "Join":
+                l, r = t.depends_on
+                seals[t.task_number] = ol.prove_segment(join_po2, *widths, ag.join_seed(seals[l], seals[r]))[0]
+            else:
+                root = t.depends_on[0]
+
+    for i in range(n):
+        p.enqueue_segment()
+        drain(i)
+    p.finish()
+    drain(None)
+    return root, seals
+
+
+@pytest.mark.parametrize("n,lanes", [(16, 3), (5, 2)])
+def test_planned_job_on_the_gpu_equals_the_oracle_chain(n, lanes):
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import Segment
+
+    widths, seg_po2, join_po2 = (4, 8, 4), 12, 10
+    a = ag.Agent(prover=None, device=0, inflight=lanes, widths=widths, poll_time=0.002, join_po2=join_po2, also_streams="aux")
+    try:
+        segs = [Segment.synthetic(i, po2=seg_po2) for i in range(n)]
+        for s in segs:
+            a.store.set_key_with_expiry(f"job:G:segments:{s.index}", ag.serialize_segment(s), 600)
+        ids = a.taskdb.plan_job("G", n)
+        assert a.poll_work(max_idle_polls=5) == len(ids) == 2 * n - 1 + 2
+        assert a.taskdb.job("G")["state"] == "done"
+        root, seals = oracle_chain(n, seg_po2, join_po2, widths, lambda i: segs[i].seed)
+        rollup = ag.deserialize_receipt(a.store.get("receipts/stark/G.synthetic"))
+        assert rollup.po2 == join_po2 and rollup.index == root
+        assert np.array_equal(rollup.seal, seals[root])  # the root of the hash chain: all 2n-1 proofs were the oracle's
+        rollup.verify_integrity()
+        assert sorted(a.store.keys()) == sorted([f"job:G:synthetic_receipts:{root}", "receipts/stark/G.synthetic"])
+        text = a.metrics_text()
+        assert f'task_operations_total{{task_name="join",operation_type="join_receipts",status="success"}} {n - 1}' in text
+        per_lane = [d for _, d in a.lane_stats()]
+        assert sum(per_lane) == len(ids)
+    finally:
+        a.close()
+
+
+def test_a_tampered_child_receipt_fails_the_join_at_verification():
+    """join.rs:44-49: both children are verified before they are joined ([BENTO-JOIN-003/004])."""
+    from boundless_amd import agent as ag
+    from boundless_amd.prover import SegmentReceipt
+
+    widths = (4, 8, 4)
+    a = ag.Agent(prover=None, device=0, inflight=1, widths=widths, poll_time=0.002, join_po2=10)
+    try:
+        good, _ = ol.prove_segment(10, *widths, 1)
+        bad = good.copy()
+        bad[-1] ^= 1
+        a.store.set_key_with_expiry("job:T:synthetic_receipts:0", ag.serialize_receipt(SegmentReceipt(seal=good, index=0, po2=10)), 600)
+        a.store.set_key_with_expiry("job:T:synthetic_receipts:1", ag.serialize_receipt(SegmentReceipt(seal=bad, index=1, po2=10)), 600)
+        a.taskdb.create_task("T", "2", {"Join": {"idx": 2, "left": 0, "right": 1}}, max_retries=0)
+        assert a.process_one("T", "2", {"Join": {"idx": 2, "left": 0, "right": 1}}) is False
+        assert a.taskdb.task("T", "2").error.startswith("[BENTO-WF-119] Join failed: [BENTO-JOIN-004] Failed to verify right receipt integrity")
+        # with both children intact the join goes through and cleans up
+        a.store.set_key_with_expiry("job:T:synthetic_receipts:1", ag.serialize_receipt(SegmentReceipt(seal=good, index=1, po2=10)), 600)
+        a.taskdb.create_task("T", "3", {"Join": {"idx": 3, "left": 0, "right": 1}}, max_retries=0)
+        assert a.process_one("T", "3", {"Join": {"idx": 3, "left": 0, "right": 1}}) is True
+        joined = ag.deserialize_receipt(a.store.get("job:T:synthetic_receipts:3"))
+        want, _ = ol.prove_segment(10, *widths, ag.join_seed(good, good))
+        assert np.array_equal(joined.seal, want)
+        assert a.store.keys() == ["job:T:synthetic_receipts:3"]
+    finally:
+        a.close()
