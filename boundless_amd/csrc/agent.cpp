@@ -521,6 +521,7 @@ struct Pending {
     bool opaque = false;  // proved through prove_blob: `wire` already holds the receipt bytes to store
     enum Kind { Prove, Join, HostOnly } kind = Prove;  // HostOnly: the whole task ran in the first half (resolve / finalize stand-ins)
     std::vector<std::string> cleanup_keys;  // a join unlinks its children's receipts once its own is stored (join.rs:94-104)
+    std::vector<uint32_t> child_seal[2];    // a join's children: verified in the host half, while the lane already proves its next task
     std::vector<uint32_t> seal;
     size_t words = 0;
     double prove_s = 0;
@@ -810,24 +811,31 @@ struct bx_agent {
     }
 
     // verify_integrity_with_context against the agent's context (HIP prover) or the circuit's published IDs (injected prover)
+    // The HIP agent's context holds the control ID of every buffer set its lanes created (each checked against the circuit's
+    // published IDs when it was added); a receipt of a size no lane has created yet — a child receipt another agent proved, the
+    // root receipt an aux agent finalizes — is checked against the published IDs themselves (check_code).
     const char* verify_seal(const uint32_t* seal, size_t words) {
         std::shared_lock<std::shared_mutex> r(vctx_mu);
-        return bx_verify_segment_with_context(seal, words, nullptr, hip ? vctx : nullptr);
+        const bool own = hip && vctx && words > 0 && bx_verifier_ctx_count(vctx, seal[0]) > 0;
+        return bx_verify_segment_with_context(seal, words, nullptr, own ? vctx : nullptr);
     }
-    // a stored synthetic receipt: GET + deserialize (+ verify)
+    // a stored synthetic receipt: GET + deserialize (+ verify when a code is given)
     std::string load_receipt(const std::string& key, const char* which, const char* code_deser, const char* code_verify, uint64_t* index, uint32_t* po2,
                              std::vector<uint32_t>* seal) {
         StoreValue blob;
         std::string e = store_get(key, &blob);
         if (!e.empty()) return e;
         if (!receipt_decode(blob.data(), blob.size(), index, po2, seal)) return std::string(code_deser) + " Failed to deserialize " + which + " receipt";
-        if (!cfg.no_verify)
+        if (code_verify && !cfg.no_verify)
             if (const char* ve = verify_seal(seal->data(), seal->size())) return std::string(code_verify) + " Failed to verify " + which + " receipt integrity: " + ve;
         return "";
     }
 
     // tasks::join::join (join.rs:18-113) with a STAND-IN for `prover.join(&left, &right)`: one synthetic segment of 2^join_po2
-    // cycles seeded by the two children's seals (bx_agent.h, "Stand-ins for the recursion tasks").  First half: fetch, verify, prove.
+    // cycles seeded by the two children's seals (bx_agent.h, "Stand-ins for the recursion tasks").  First half: fetch, deserialize,
+    // prove.  The reference verifies both children before joining (join.rs:44-49); here that check (15 ms of CPU per child at 2^20)
+    // runs in the second half, on the finisher thread, while the lane's GPU share already works on its next task: the seed needs the
+    // children's bytes, not their validity, and a join whose child does not verify fails with the same code and stores nothing.
     std::string join_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t idx, uint64_t left, uint64_t right, Pending* out) {
         out->start = Clock::now();
         out->task = task;
@@ -836,9 +844,9 @@ struct bx_agent {
         out->job_prefix = std::string("job:") + task.job_id;
         const std::string prefix = out->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":";
         const std::string lk = prefix + std::to_string(left), rk = prefix + std::to_string(right);
-        std::vector<uint32_t> ls, rs;
-        std::string e = load_receipt(lk, "left", "[BENTO-JOIN-001]", "[BENTO-JOIN-003]", nullptr, nullptr, &ls);
-        if (e.empty()) e = load_receipt(rk, "right", "[BENTO-JOIN-002]", "[BENTO-JOIN-004]", nullptr, nullptr, &rs);
+        std::vector<uint32_t>&ls = out->child_seal[0], &rs = out->child_seal[1];
+        std::string e = load_receipt(lk, "left", "[BENTO-JOIN-001]", nullptr, nullptr, nullptr, &ls);
+        if (e.empty()) e = load_receipt(rk, "right", "[BENTO-JOIN-002]", nullptr, nullptr, nullptr, &rs);
         if (!e.empty()) return e.rfind("[BENTO-JOIN", 0) == 0 ? e : "failed to get receipts for keys: " + lk + ", " + rk + ": " + e;
         out->cleanup_keys = {lk, rk};
         out->seg_index = idx;
@@ -862,10 +870,15 @@ struct bx_agent {
         metrics.record_task_operation("join", "join_receipts", "success", out->prove_s);
         return "";
     }
-    //   second half: verify the joined receipt, store it, unlink the children
+    //   second half: verify the children and the joined receipt, store it, unlink the children
     std::string join_finish(Pending* p) {
-        if (!cfg.no_verify)
+        if (!cfg.no_verify) {
+            if (const char* ve = verify_seal(p->child_seal[0].data(), p->child_seal[0].size()))
+                return std::string("[BENTO-JOIN-003] Failed to verify left receipt integrity: ") + ve;
+            if (const char* ve = verify_seal(p->child_seal[1].data(), p->child_seal[1].size()))
+                return std::string("[BENTO-JOIN-004] Failed to verify right receipt integrity: ") + ve;
             if (const char* ve = verify_seal(p->seal.data(), p->words)) return std::string("[BENTO-JOIN-006] Failed to verify join receipt integrity: ") + ve;
+        }
         receipt_encode(p->wire, p->seg_index, p->po2, p->seal.data(), p->words);
         std::string e = store_set(p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + std::to_string(p->seg_index), p->wire, cfg.redis_ttl);
         if (!e.empty()) return "Failed to store joined receipt: " + e;

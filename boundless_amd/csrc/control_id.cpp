@@ -222,6 +222,12 @@ const char* bx_verifier_ctx_add_control_id(bx_verifier_ctx* v, uint32_t po2, con
     }
 }
 size_t bx_verifier_ctx_size(const bx_verifier_ctx* v) { return v ? v->ids.size() : 0; }
+size_t bx_verifier_ctx_count(const bx_verifier_ctx* v, uint32_t po2) {
+    size_t n = 0;
+    if (v)
+        for (auto& e : v->ids) n += e.first == po2;
+    return n;
+}
 
 }  // extern "C"
 

@@ -146,6 +146,8 @@ def _declare(lib):
     lib.bx_verifier_ctx_add_control_id.restype = C.c_char_p
     lib.bx_verifier_ctx_size.argtypes = [C.c_void_p]
     lib.bx_verifier_ctx_size.restype = sz
+    lib.bx_verifier_ctx_count.argtypes = [C.c_void_p, C.c_uint32]
+    lib.bx_verifier_ctx_count.restype = sz
     lib.bx_synthetic_control_id_host.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
     lib.bx_synthetic_control_id_host.restype = C.c_char_p
     lib.bx_prover_control_id.argtypes = [C.c_void_p, C.c_void_p]

@@ -85,7 +85,7 @@ typedef struct bx_circuit_ops {
      * from the seed); tables that predate this member must zero-initialise it. */
     void (*set_noise_seed)(void* user, void* state, uint64_t noise_seed);
     /* Verifier side (host, no GPU), upstream's `check_code(po2, root)`: NULL when `root` — the Merkle root of the code group a
-     * seal of this shape committed (canonical-form digest words as they stand in the seal) — is this circuit's control ID for
+     * seal of this shape committed (the 8 digest words as they stand in the seal) — is this circuit's control ID for
      * the shape, else a message.  Without it the selectors and control words a seal's constraints are evaluated with would be
      * the prover's own choice.  Used when bx_verify_segment_with_context is given no explicit context; a table without it can
      * only be verified against an explicit bx_verifier_ctx. */
@@ -115,6 +115,8 @@ const char* bx_verifier_ctx_create(bx_verifier_ctx** out);
 void bx_verifier_ctx_destroy(bx_verifier_ctx* v);
 const char* bx_verifier_ctx_add_control_id(bx_verifier_ctx* v, uint32_t po2, const uint32_t id[8]);
 size_t bx_verifier_ctx_size(const bx_verifier_ctx* v);
+/* how many IDs the context holds for segments of 2^po2 cycles */
+size_t bx_verifier_ctx_count(const bx_verifier_ctx* v, uint32_t po2);
 /* bx_verify_segment with everything explicit.  circuit NULL = the synthetic one.  vctx non-NULL: the code root must be one of
  * the context's IDs for the seal's po2 (circuit->check_code is not consulted); vctx NULL: circuit->check_code decides, and a
  * circuit without one is refused ("no control IDs to check the code root against"). */

@@ -28,6 +28,7 @@ const bx_circuit_ops* bx_synthetic_circuit(void) { return nullptr; }
 const char* bx_verifier_ctx_create(bx_verifier_ctx**) { return "stub"; }
 void bx_verifier_ctx_destroy(bx_verifier_ctx*) {}
 const char* bx_verifier_ctx_add_control_id(bx_verifier_ctx*, uint32_t, const uint32_t*) { return "stub"; }
+size_t bx_verifier_ctx_count(const bx_verifier_ctx*, uint32_t) { return 0; }
 const char* bx_verify_segment_with_context(const uint32_t* seal, size_t words, const bx_circuit_ops*, const bx_verifier_ctx*) {
     return (words == 64 && seal[0] == 7u) ? nullptr : "bad seal";
 }
