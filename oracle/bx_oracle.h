@@ -112,6 +112,7 @@ void bxo_control_id(uint32_t po2, uint32_t w_code, uint32_t id_out[8]);
  * n_commit times, then `random_elem` n_elems times.  What the prover's iop_commit / iop_random_elem do, exported so that the
  * device-side step (bx_transcript_step) can be checked on its own. */
 void bxo_transcript_step(uint32_t state[25], const uint32_t* digests, size_t n_commit, uint32_t* out, size_t n_elems);
+uint32_t bxo_rng_random_bits(uint32_t state[25], unsigned bits);
 /* test hook: add 1 to witness cell (group, col, row) before it is committed, making the proved statement false (group < 0: off) */
 void bxo_set_witness_fault(int group, uint32_t col, uint32_t row);
 /* test hook: a dishonest prover that commits its own code group (1: `last` == 0 and a false g_1; 2: `first` == 0, zero

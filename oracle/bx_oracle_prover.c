@@ -84,6 +84,18 @@ void bxo_transcript_step(uint32_t state[25], const uint32_t* digests, size_t n_c
     state[24] = io.pool_used;
 }
 
+/* [EXT] Poseidon2Rng::random_bits on an exported state (24 cells + pool counter) */
+uint32_t bxo_rng_random_bits(uint32_t state[25], unsigned bits) {
+    iop_t io;
+    memset(&io, 0, sizeof io);
+    memcpy(io.cells, state, sizeof io.cells);
+    io.pool_used = state[24];
+    uint32_t v = iop_random_bits(&io, bits);
+    memcpy(state, io.cells, sizeof io.cells);
+    state[24] = io.pool_used;
+    return v;
+}
+
 /* ---- ext helpers on top of the oracle field ---- */
 static e4 e4mul(e4 a, e4 b) { e4 r; bxo_fp4_mul(r.c, a.c, b.c); return r; }
 static e4 e4inv(e4 a) { e4 r; bxo_fp4_inv(r.c, a.c); return r; }

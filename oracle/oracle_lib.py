@@ -75,6 +75,7 @@ def lib(path=None):
         "bxo_prove_segment_ex": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_prove_segment_zk": ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(sz), u32p], C.c_void_p),
         "bxo_transcript_step": ([u32p, u32p, sz, u32p, sz], None),
+        "bxo_rng_random_bits": ([u32p, C.c_uint], C.c_uint32),
         "bxo_set_witness_fault": ([C.c_int, C.c_uint32, C.c_uint32], None),
         "bxo_set_cheat": ([C.c_int], None),
         "bxo_control_id": ([C.c_uint32, C.c_uint32, u32p], None),

@@ -3,6 +3,11 @@
 Today parity with the Rust prover is unpinned (no vector exists in the reference tree, no network): this loader is what
 flips it to pinned the day the files are supplied, without touching any code.  The CPU half checks the C oracle (and the
 fixture manifest) on every host; the GPU half checks the HIP HAL through the C ABI.
+
+Every loader runs twice: on `supplied` = tests/golden/upstream/ (skipped while a file is absent) and on `twin` = the same files
+written by tools/upstream_vectors/twin.py from this repository's own oracle — which proves nothing about risc0 but keeps the
+loader itself (formats, encodings, call shapes) working, on the CPU and on the GPU, until `cargo run` in tools/upstream_vectors/
+produces the real ones.
 """
 import hashlib
 import json
@@ -17,8 +22,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 UP = os.path.join(ROOT, "tests", "golden", "upstream")
 
 
-def load(name):
-    p = os.path.join(UP, name)
+@pytest.fixture(scope="module", params=["supplied", "twin"])
+def updir(request, tmp_path_factory):
+    if request.param == "supplied":
+        return UP
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bx_twin", os.path.join(ROOT, "tools", "upstream_vectors", "twin.py"))
+    twin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(twin)
+    d = str(tmp_path_factory.mktemp("upstream_twin"))
+    twin.main(d)
+    return d
+
+
+def load(name, updir=UP):
+    p = os.path.join(updir, name)
     if not os.path.exists(p):
         pytest.skip(f"tests/golden/upstream/{name} not supplied (parity with risc0 unpinned)")
     return json.load(open(p))
@@ -59,16 +78,16 @@ def test_manifest_pins_every_fixture_and_the_poseidon2_table():
 
 
 # ------------------------------------------------------------------------------------------------------ CPU: oracle vs upstream
-def test_upstream_poseidon2_constants_equal_the_compiled_in_table():
-    up = load("poseidon2_consts.json")
+def test_upstream_poseidon2_constants_equal_the_compiled_in_table(updir):
+    up = load("poseidon2_consts.json", updir)
     rc, dg = np.zeros(213, np.uint32), np.zeros(24, np.uint32)
     ol.lib().bxo_poseidon2_get_params(rc, dg)
     assert up["round_constants"] == rc.tolist(), "default round constants are not upstream's"
     assert up["internal_diag"] == dg.tolist(), "default internal diagonal is not upstream's"
 
 
-def test_upstream_poseidon2_vectors_vs_oracle():
-    up = load("poseidon2_vectors.json")
+def test_upstream_poseidon2_vectors_vs_oracle(updir):
+    up = load("poseidon2_vectors.json", updir)
     L = ol.lib()
     for v in up.get("permutation", []):
         cells = ol.encode(v["in"])
@@ -85,9 +104,9 @@ def test_upstream_poseidon2_vectors_vs_oracle():
         assert ol.decode(out).tolist() == v["out"]
 
 
-def test_upstream_ntt_vectors_vs_oracle():
+def test_upstream_ntt_vectors_vs_oracle(updir):
     L = ol.lib()
-    for case in load("ntt_vectors.json")["cases"]:
+    for case in load("ntt_vectors.json", updir)["cases"]:
         n = case["size"]
         io = ol.encode(case["evals_natural"])
         L.bxo_batch_interpolate_ntt(io, 1, n)
@@ -99,29 +118,81 @@ def test_upstream_ntt_vectors_vs_oracle():
             assert ol.decode(out).tolist() == case["evaluate_out"]
 
 
-def test_upstream_fri_fold_vectors_vs_oracle():
+def test_upstream_fri_fold_vectors_vs_oracle(updir):
     L = ol.lib()
-    for case in load("fri_fold_vectors.json")["cases"]:
+    for case in load("fri_fold_vectors.json", updir)["cases"]:
         out = np.zeros(4 * case["count"], np.uint32)
         L.bxo_fri_fold(out, ol.encode(case["in_soa"]), ol.encode(case["mix"]), case["count"])
         assert ol.decode(out).tolist() == case["out_soa"]
 
 
-def test_upstream_zk_shift_vectors_vs_oracle():
+def test_upstream_zk_shift_vectors_vs_oracle(updir):
     L = ol.lib()
-    for case in load("zk_shift_vectors.json")["cases"]:
+    for case in load("zk_shift_vectors.json", updir)["cases"]:
         io = ol.encode(case["in"])
         L.bxo_zk_shift(io, 1, case["size"])
         assert ol.decode(io).tolist() == case["out"]
 
 
-def test_upstream_mix_poly_coeffs_vectors_vs_oracle():
+def test_upstream_mix_poly_coeffs_vectors_vs_oracle(updir):
     L = ol.lib()
-    for case in load("mix_poly_coeffs_vectors.json")["cases"]:
+    for case in load("mix_poly_coeffs_vectors.json", updir)["cases"]:
         out = ol.encode(case["init_ext_aos"])
         L.bxo_mix_poly_coeffs(out, ol.encode(case["mix_start"]), ol.encode(case["mix"]), ol.encode(case["in"]), c(case["combos"]),
                               case["input_size"], case["count"])
         assert ol.decode(out).tolist() == case["out_ext_aos"]
+
+
+def test_upstream_rng_script_vs_oracle(updir):
+    """Poseidon2Rng as the prover drives it: mix(digest), random_elem, random_ext_elem, random_bits.  Settles the `random_bits`
+    **choice** of oracle/README.md (canonical value vs Montgomery word) and the pool/permutation bookkeeping."""
+    up = load("poseidon2_vectors.json", updir)
+    if "rng" not in up:
+        pytest.skip("poseidon2_vectors.json has no rng script")
+    L = ol.lib()
+    state = np.zeros(25, np.uint32)
+    none = np.zeros(0, np.uint32)
+    for step in up["rng"]:
+        if step["op"] == "mix":
+            state, _ = ol.transcript_step(state, ol.encode(step["digest"]), 0)
+        elif step["op"] == "random_elem":
+            state, e = ol.transcript_step(state, none, 1)
+            assert int(ol.decode(e)[0]) == step["value"]
+        elif step["op"] == "random_ext_elem":
+            state, e = ol.transcript_step(state, none, 4)
+            assert ol.decode(e).tolist() == step["value"]
+        else:
+            assert step["op"] == "random_bits"
+            assert int(L.bxo_rng_random_bits(state, step["bits"])) == step["value"], step
+
+
+def _twin():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bx_twin", os.path.join(ROOT, "tools", "upstream_vectors", "twin.py"))
+    twin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(twin)
+    return twin
+
+
+def test_upstream_merkle_vectors_vs_oracle(updir):
+    """MerkleTreeProver: which layer `commit` writes (the top-layer rule), the root, and the words of an opening."""
+    twin = _twin()
+    L = ol.lib()
+    for case in load("merkle_vectors.json", updir)["cases"]:
+        rows, cols = case["rows"], case["cols"]
+        m = ol.encode(case["matrix"])
+        nodes, top = twin.merkle_nodes(L, m, rows, cols, case["queries"])
+        assert ol.decode(nodes[8:16]).tolist() == case["root"]
+        assert nodes[8 * top:16 * top].tolist() == case["commit_words_montgomery"], "top-layer rule"
+        for o in case["openings"]:
+            assert twin.merkle_open(nodes, m, rows, cols, top, o["idx"]) == o["words_montgomery"]
+
+
+def test_upstream_manifest_matches_the_files(updir):
+    man = load("MANIFEST.upstream.json", updir)
+    for name, digest in man["sha256"].items():
+        assert hashlib.sha256(open(os.path.join(updir, name), "rb").read()).hexdigest() == digest, name
 
 
 # ------------------------------------------------------------------------------------------------------ GPU: HIP HAL vs upstream
@@ -135,8 +206,8 @@ def hal():
 
 
 @pytest.mark.gpu
-def test_upstream_poseidon2_vectors_vs_hal(hal):
-    up = load("poseidon2_vectors.json")
+def test_upstream_poseidon2_vectors_vs_hal(hal, updir):
+    up = load("poseidon2_vectors.json", updir)
     for v in up.get("hash_elem_slice", []):
         if not v["in"]:
             continue
@@ -152,8 +223,24 @@ def test_upstream_poseidon2_vectors_vs_hal(hal):
 
 
 @pytest.mark.gpu
-def test_upstream_ntt_vectors_vs_hal(hal):
-    for case in load("ntt_vectors.json")["cases"]:
+def test_upstream_merkle_vectors_vs_hal(hal, updir):
+    """The device tree (bx_merkle_build) on the same vectors: root and the layer `commit` writes.  (The RNG script is a host-side
+    matter — transcript.hpp — and reaches the product through the seal parity tests.)"""
+    twin = _twin()
+    for case in load("merkle_vectors.json", updir)["cases"]:
+        rows, cols = case["rows"], case["cols"]
+        nodes = hal.alloc_digest(2 * rows)
+        nodes.copy_from(np.zeros(16 * rows, np.uint32))
+        hal.merkle_build(nodes, hal.copy_from(ol.encode(case["matrix"])), rows)
+        got = nodes.view()
+        _, top = twin.merkle_nodes(ol.lib(), ol.encode(case["matrix"]), rows, cols, case["queries"])
+        assert ol.decode(got[8:16]).tolist() == case["root"]
+        assert got[8 * top:16 * top].tolist() == case["commit_words_montgomery"]
+
+
+@pytest.mark.gpu
+def test_upstream_ntt_vectors_vs_hal(hal, updir):
+    for case in load("ntt_vectors.json", updir)["cases"]:
         n = case["size"]
         io = hal.copy_from(ol.encode(case["evals_natural"]))
         hal.batch_interpolate_ntt(io, 1)
@@ -166,12 +253,12 @@ def test_upstream_ntt_vectors_vs_hal(hal):
 
 
 @pytest.mark.gpu
-def test_upstream_fri_fold_and_zk_shift_vectors_vs_hal(hal):
-    for case in load("fri_fold_vectors.json")["cases"]:
+def test_upstream_fri_fold_and_zk_shift_vectors_vs_hal(hal, updir):
+    for case in load("fri_fold_vectors.json", updir)["cases"]:
         out = hal.alloc(4 * case["count"])
         hal.fri_fold(out, hal.copy_from(ol.encode(case["in_soa"])), ol.encode(case["mix"]))
         assert ol.decode(out.view()).tolist() == case["out_soa"]
-    for case in load("zk_shift_vectors.json")["cases"]:
+    for case in load("zk_shift_vectors.json", updir)["cases"]:
         io = hal.copy_from(ol.encode(case["in"]))
         hal.zk_shift(io, 1)
         assert ol.decode(io.view()).tolist() == case["out"]
