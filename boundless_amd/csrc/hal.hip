@@ -47,12 +47,12 @@ void trace_push(const char* name) { (void)g_trace.push(name); }
 void trace_pop() { (void)g_trace.pop(); }
 TraceRange::~TraceRange() {
     if (!on) return;
-    if (trace_level() >= 2 && c) (void)hipStreamSynchronize(c->stream);
+    if (trace_level() >= 2 && c) (void)stream_wait(c);
     trace_pop();
 }
 void TraceStages::close() {
     if (!open) return;
-    if (trace_level() >= 2 && c) (void)hipStreamSynchronize(c->stream);
+    if (trace_level() >= 2 && c) (void)stream_wait(c);
     trace_pop();
     open = false;
 }
@@ -100,7 +100,7 @@ OpScope::~OpScope() {
 
 static void drain_profile(bx_ctx* c) {
     if (c->prof_pending.empty()) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_wait(c);
     for (auto& r : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -250,12 +250,15 @@ hipError_t stream_wait(bx_ctx* c) {
     while ((e = hipEventQuery(c->wait_ev)) == hipErrorNotReady) usleep((useconds_t)c->wait_poll_us);
     return e;
 }
-// Apply bx_ctx::wait_blocking to the device (see ctx.hpp).  The flag is per device and process, not per ctx.
+// Apply bx_ctx::wait_blocking (see ctx.hpp).  The schedule flag is per DEVICE AND PROCESS, not per ctx: it is touched only for the one
+// policy that needs it ("block"); "poll" (the default) and "spin" leave the process's setting alone — a ctx in the default mode must
+// not force Spin on torch's, RCCL's or another ctx's streams, nor undo a Blocking flag an earlier ctx asked for.
 void apply_wait_policy(bx_ctx* c) {
     c->wait_poll = false;
-    if (hipSetDeviceFlags(c->wait_blocking == 1 ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin) != hipSuccess) {
+    if (c->wait_blocking != 1) return;
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) {
         (void)hipGetLastError();
-        c->wait_poll = c->wait_blocking == 1;
+        c->wait_poll = true;  // the runtime refused (streams already exist): sleep-poll an event instead
     }
 }
 const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
@@ -295,7 +298,7 @@ const char* sync_and_check_flag(bx_ctx* c) {
 extern "C" const char* bx_free(bx_ctx* c) try {
     if (!c) return nullptr;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_wait(c);
     drain_profile(c);
     ntt_free_tables(c);
     if (c->d_p2) (void)hipFree(c->d_p2);
@@ -329,7 +332,7 @@ extern "C" int bx_has_unified_memory(bx_ctx*) { return 0; }
 
 extern "C" const char* bx_set_stream(bx_ctx* c, void* s) try {
     if (!c) return "bx_set_stream: null ctx";
-    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_HIP(c, stream_wait(c));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return nullptr;
 } BX_ABI_CATCH(c, "bx_set_stream")
@@ -349,7 +352,7 @@ extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;
     BX_HIP(c, hipSetDevice(c->device));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_HIP(c, stream_wait(c));
     BX_HIP(c, hipFree(b.dptr));
     return nullptr;
 } BX_ABI_CATCH(c, "bx_release")

@@ -63,9 +63,10 @@ extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, si
 // [0, n) page digests | [n] the zero page | per level its parents then its zero subtree | the given digests; a level's fold reads
 // any earlier entry of the pool through absolute indices, so given digests enter at whatever level they belong to.
 static const char* image_node(bx_ctx* c, const bx_image* im, uint32_t top, uint32_t out[8]) {
+    // node 0 does not exist (0 << k never reaches the leaf layer: the loop below would not end) and nothing lies beyond the leaves
+    BX_REQUIRE(c, top >= 1 && top < (2u << BX_MERKLE_DEPTH), "image: node index outside the tree");
     int top_level = 0;  // levels above the leaves
-    while ((top << top_level) < (1u << BX_MERKLE_DEPTH)) ++top_level;
-    BX_REQUIRE(c, top >= 1 && (top << top_level) < (2u << BX_MERKLE_DEPTH), "image: node index outside the tree");
+    while (top_level < BX_MERKLE_DEPTH && (top << top_level) < (1u << BX_MERKLE_DEPTH)) ++top_level;
     const uint32_t leaf_lo = top << top_level, leaf_hi = leaf_lo + (1u << top_level);  // node indices of the leaves below `top`
     // the given digests at or below `top`, by level (0 = leaves); one AT an ancestor of `top` would hide it
     std::vector<std::vector<std::pair<uint32_t, const uint32_t*>>> given(top_level + 1);

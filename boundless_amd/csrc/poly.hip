@@ -590,7 +590,7 @@ __global__ void scatter_kernel(uint32_t* __restrict__ into, const uint32_t* __re
 const char* ensure_scratch(bx_ctx* c, size_t words) {
     if (c->scratch_words >= words) return nullptr;
     if (c->d_scratch) {
-        BX_HIP(c, hipStreamSynchronize(c->stream));
+        BX_HIP(c, stream_wait(c));
         BX_HIP(c, hipFree(c->d_scratch));
         c->d_scratch = nullptr;
         c->scratch_words = 0;

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // hash_fold with an indirection: out[j] = H(in[sel[2j]] || in[sel[2j+1]]).  The levels of a SPARSE Merkle tree (the zkVM
 // memory image, bx_image.h: 2^22 leaves of which a few hundred exist) are folded with it: the host lists, per level, which
 // two digests of the level below (or that level's all-zero digest) feed each surviving parent.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_indexed_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_fold_indexed_kernel(uint32_t* out, const uint32_t* in,  // out may be a range of the pool `in` names (no sel entry inside it): not __restrict__
                                                                 const uint32_t* __restrict__ sel, const uint32_t* __restrict__ prm,
-                                                                uint32_t count) {
+                                                                uint32_t count, uint32_t n_in) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    const uint2 pr = reinterpret_cast<const uint2*>(sel)[j];
+    uint2 pr = reinterpret_cast<const uint2*>(sel)[j];
+    pr.x = pr.x < n_in ? pr.x : n_in - 1;  // sel comes from the caller: an entry beyond the pool must not become an out-of-bounds read
+    pr.y = pr.y < n_in ? pr.y : n_in - 1;
     const uint4* a = reinterpret_cast<const uint4*>(in + (size_t)pr.x * 8);
     const uint4* b = reinterpret_cast<const uint4*>(in + (size_t)pr.y * 8);
     uint32_t s[CELLS];
@@ -483,7 +485,7 @@ const char* poseidon2_upload_params(bx_ctx* c) {
     for (int i = 0; i < 24; ++i) h[DIAG_OFF + i] = fp_encode(c->h_diag[i]);
     if (!c->d_p2) BX_HIP(c, hipMalloc(&c->d_p2, sizeof h));
     BX_HIP(c, hipMemcpyAsync(c->d_p2, h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    BX_HIP(c, hipStreamSynchronize(c->stream));
+    BX_HIP(c, stream_wait(c));
     return nullptr;
 }
 
@@ -551,11 +553,11 @@ extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx
     BX_REQUIRE(c, out.len >= 8 * count && sel.len >= 2 * count, "hash_fold_indexed: out or sel too small");
     BX_REQUIRE(c, count <= 0xffffffffu && in.len / 8 <= 0xffffffffu, "hash_fold_indexed: too many digests");
     if (count == 0) return nullptr;
-    BX_REQUIRE(c, out.dptr && in.dptr && sel.dptr, "hash_fold_indexed: null buffer");
+    BX_REQUIRE(c, out.dptr && in.dptr && sel.dptr && in.len >= 8, "hash_fold_indexed: null or empty buffer");
     BX_HIP(c, hipSetDevice(c->device));
     OpScope op(c, "hash_fold_indexed", 104.0 * (double)count);
     hipLaunchKernelGGL(hash_fold_indexed_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
-                       (const uint32_t*)in.dptr, (const uint32_t*)sel.dptr, c->d_p2, (uint32_t)count);
+                       (const uint32_t*)in.dptr, (const uint32_t*)sel.dptr, c->d_p2, (uint32_t)count, (uint32_t)(in.len / 8));
     BX_LAUNCH_CHECK(c);
     return nullptr;
 } BX_ABI_CATCH(c, "bx_hash_fold_indexed")

@@ -395,7 +395,7 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
 extern "C" const char* bx_prover_destroy(bx_prover* p) try {
     if (!p) return nullptr;
     (void)hipSetDevice(p->c->device);
-    (void)hipStreamSynchronize(p->c->stream);
+    (void)stream_wait(p->c);
     p->c->live_provers -= 1;
     delete p;
     return nullptr;

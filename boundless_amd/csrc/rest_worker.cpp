@@ -366,26 +366,38 @@ std::string exchange(int fd, const std::string& head, const uint8_t* body, size_
                      bool* dead_before_answer) {
     *reusable = false;
     *dead_before_answer = false;
+    // "the idle connection was gone" means exactly that: the send hit a closed socket, or the peer's FIN / RST is all that came back.
+    // A receive TIMEOUT (EAGAIN from SO_RCVTIMEO) is this request's own failure: re-sending a non-idempotent POST (the long-poll claim)
+    // on a fresh socket would double the effective timeout and could claim a task twice.
+    auto closed = [](int e) { return e == 0 || e == ECONNRESET || e == EPIPE || e == ENOTCONN; };
     if (!send_all(fd, head.data(), head.size()) || (body_len && !send_all(fd, (const char*)body, body_len))) {
-        *dead_before_answer = true;
-        return std::string("send: ") + strerror(errno);
+        const int se = errno;
+        *dead_before_answer = closed(se) && se != 0;
+        return std::string("send: ") + strerror(se);
     }
     Reader rd(fd);
     std::string ln;
-    if (!rd.line(&ln, MAX_HEADER_BYTES)) {
-        *dead_before_answer = !rd.any;
-        return rd.any ? "malformed HTTP response" : std::string("receive: ") + (rd.err ? strerror(rd.err) : "connection closed");
-    }
-    if (ln.compare(0, 5, "HTTP/") != 0) return "malformed HTTP response";
-    bool keep = ln.compare(0, 8, "HTTP/1.1") == 0;
-    size_t sp = ln.find(' ');
     int status = 0;
-    if (sp != std::string::npos)
+    bool keep = false, chunked = false, have_len = false;
+    size_t content_len = 0;
+    for (int interim = 0;; ++interim) {  // 1xx responses (100 Continue, 103 Early Hints) precede the final one on the same connection
+      if (!rd.line(&ln, MAX_HEADER_BYTES)) {
+        *dead_before_answer = !rd.any && closed(rd.err);
+        if (rd.any) return "malformed HTTP response";
+        if (rd.err == EAGAIN || rd.err == EWOULDBLOCK || rd.err == ETIMEDOUT) return "receive: timed out waiting for the response";
+        return std::string("receive: ") + (rd.err ? strerror(rd.err) : "connection closed");
+      }
+      if (ln.compare(0, 5, "HTTP/") != 0) return "malformed HTTP response";
+      keep = ln.compare(0, 8, "HTTP/1.1") == 0;
+      size_t sp = ln.find(' ');
+      status = 0;
+      if (sp != std::string::npos)
         for (size_t k = sp + 1; k < ln.size() && k < sp + 10 && ln[k] >= '0' && ln[k] <= '9'; ++k) status = status * 10 + (ln[k] - '0');
-    out->status = status;
-    bool chunked = false, have_len = false;
-    size_t content_len = 0, head_bytes = ln.size();
-    for (;;) {
+      out->status = status;
+      chunked = have_len = false;
+      content_len = 0;
+      size_t head_bytes = ln.size();
+      for (;;) {
         if (!rd.line(&ln, MAX_HEADER_BYTES)) return "malformed HTTP response";
         if (ln.empty()) break;
         if ((head_bytes += ln.size() + 2) > MAX_HEADER_BYTES) return "response header larger than 64 KiB";
@@ -404,10 +416,17 @@ std::string exchange(int fd, const std::string& head, const uint8_t* body, size_
             if (value.find("close") != std::string::npos) keep = false;
             else if (value.find("keep-alive") != std::string::npos) keep = true;
         }
+      }
+      if (status >= 100 && status < 200 && status != 101) {  // interim: the real answer follows
+        if (interim >= 8) return "too many interim (1xx) responses";
+        continue;
+      }
+      break;
     }
     const std::string too_large = "response larger than " + std::to_string(MAX_RESPONSE_BYTES >> 20) + " MiB";
-    if (status == 204 || status == 304 || (status >= 100 && status < 200)) {
+    if (status == 204 || status == 304 || status == 101) {
         // no body by definition
+        if (status == 101) keep = false;  // a protocol switch this client never asked for: do not reuse the socket
     } else if (chunked) {
         for (;;) {
             if (!rd.line(&ln, 1024)) return "malformed chunked body";
@@ -416,8 +435,13 @@ std::string exchange(int fd, const std::string& head, const uint8_t* body, size_
             if (!all_digits(num, 16)) return "malformed chunked body";  // no hex digits where a chunk size belongs
             if (num.size() > 15) return "truncated chunked body";       // a size no body of this client can have
             size_t n = strtoull(num.c_str(), nullptr, 16);
-            if (n == 0) {
-                while (rd.line(&ln, MAX_HEADER_BYTES) && !ln.empty()) {}  // trailers
+            if (n == 0) {  // trailers: bounded like the header they belong to
+                size_t trailer_bytes = 0;
+                for (;;) {
+                    if (!rd.line(&ln, MAX_HEADER_BYTES)) return "malformed chunked body";
+                    if (ln.empty()) break;
+                    if ((trailer_bytes += ln.size() + 2) > MAX_HEADER_BYTES) return "chunked trailers larger than 64 KiB";
+                }
                 break;
             }
             if (n > MAX_RESPONSE_BYTES - out->len) return too_large;

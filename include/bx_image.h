@@ -70,7 +70,9 @@ const char* bx_compute_image_id(bx_ctx* ctx, const uint8_t* blob, size_t len, ui
 
 /* The indexed fold the tree levels use, exposed because a sparse Merkle update is also what MemoryImage::update_digests
  * does after a segment dirties pages: out[j] = H(in[sel[2j]] | in[sel[2j+1]]), j < count; sel indexes digests of `in`.
- * out and in must not overlap. */
+ * `out` may be a range of the same pool as `in` (the tree levels are built that way), but no sel entry may name a digest inside
+ * `out`: a level reads only what earlier launches wrote.  Every sel entry must be < in.len / 8; the entry point checks the
+ * host-visible sizes, the kernel clamps an entry beyond the pool to its last digest instead of reading out of bounds. */
 const char* bx_hash_fold_indexed(bx_ctx* ctx, bx_buf out_digests, bx_buf in_digests, bx_buf sel_u32, size_t count);
 /* pages (n x 256 raw u32 words, row-major as in memory) -> the (n x 512) column-major matrix of Montgomery cells that
  * bx_hash_rows hashes into page digests. */

@@ -118,6 +118,11 @@ int main() {
         "HTTP/1.1 204 No Content\r\nContent-Length: 50\r\n\r\n",
         "HTTP/1.1 200 OK\nContent-Length: 4\n\nnull",
         "HTTP/1.1 200 OK\r\nContent-Length: 4\r\nContent-Length: 99999999999999999999\r\n\r\nnull",
+        // interim responses: none followed by a final one, an endless run of them, a 101 nobody asked for; trailers without end
+        "HTTP/1.1 100 Continue\r\n\r\n",
+        [] { std::string h; for (int i = 0; i < 64; ++i) h += "HTTP/1.1 100 Continue\r\n\r\n"; return h + "HTTP/1.1 200 OK\r\nContent-Length: 4\r\n\r\nnull"; }(),
+        "HTTP/1.1 101 Switching Protocols\r\nUpgrade: h2c\r\n\r\nnull",
+        "HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\n4\r\nnull\r\n0\r\n" + [] { std::string h; for (int i = 0; i < 20000; ++i) h += "T-" + std::to_string(i) + ": y\r\n"; return h; }() + "\r\n",
     };
     char eb[256];
     long calls = 0;
@@ -174,6 +179,10 @@ int main() {
         if (v2) hot.free_value(hot.user, v2);
     }
     if (bx_rest_client_connects(c) >= bx_rest_client_requests(c) + 1 || bx_rest_client_connects(c) == 0) bad |= 8192;
+
+    // interim 1xx responses precede the answer and are not it
+    current = "HTTP/1.1 100 Continue\r\n\r\nHTTP/1.1 103 Early Hints\r\nLink: </x>\r\n\r\n" + ok_json("{\"updated\":true}");
+    if (db.update_task_retry(db.user, "job", "task", eb, sizeof eb) != 1) bad |= 16384;
 
     // serde would refuse these: a string or an out-of-range number where an i32 belongs is a decode error, not a zero
     int32_t rr = 7;

@@ -24,6 +24,8 @@ class State:
         self.drop_every = 0      # close the connection after every n-th response ...
         self.drop_silently = False  # ... without announcing it ("Connection: close" left out)
         self.served = 0
+        self.stall_next = 0.0    # the next request is read and logged, then the handler sleeps this long before answering (a hung upstream)
+        self.interim_next = 0    # answer the next request with this many "100 Continue" interim responses before the real one
 
     def create_task(self, stream, job_id, task_id, task_def, max_retries=0):
         with self.mu:
@@ -73,6 +75,14 @@ def make_handler(st):
             body = self._body()
             with st.mu:
                 st.log.append((method, path))
+                stall, st.stall_next = st.stall_next, 0.0
+                interim, st.interim_next = st.interim_next, 0
+            if stall:
+                time.sleep(stall)
+            for _ in range(interim):
+                self.wfile.write(b"HTTP/1.1 100 Continue\r\nX-Interim: 1\r\n\r\n")
+                self.wfile.flush()
+            with st.mu:
                 if st.fail_next > 0:
                     st.fail_next -= 1
                     return self._send(500, b'{"type":"InternalErr","msg":"injected"}')

@@ -97,6 +97,20 @@ def test_indexed_fold_and_page_cells_against_the_oracle(hal, oracle):
             want = np.zeros(8, np.uint32)
             oracle.bxo_hash_pair(want, np.ascontiguousarray(digs[sel[j, 0]]), np.ascontiguousarray(digs[sel[j, 1]]))
             assert np.array_equal(got[j], want), (n, j)
+    # a sel entry beyond the pool is clamped to the last digest by the kernel (never an out-of-bounds read), and `out` may be a range of
+    # the pool `in` names as long as no sel entry points into it — how the image tree builds its levels
+    digs = ol.random_elems(rng, (10, 8))
+    pool = hal.copy_from(np.concatenate([digs.reshape(-1), np.zeros(16, np.uint32)]))  # 10 digests + room for 2 outputs
+    sel = np.array([[1, 2], [9, 0xFFFFFFF0]], np.uint32)
+    BxB = type(pool.raw)
+    out_view = BxB(pool.raw.dptr + 4 * 80, 16)
+    in_view = BxB(pool.raw.dptr, 80)
+    hal._check(L.bx_hash_fold_indexed(hal.ctx, out_view, in_view, hal.copy_from(sel.reshape(-1)).raw, 2))
+    got = pool.view()[80:96].reshape(2, 8)
+    for j, (a, b) in enumerate(((1, 2), (9, 9))):
+        want = np.zeros(8, np.uint32)
+        oracle.bxo_hash_pair(want, np.ascontiguousarray(digs[a]), np.ascontiguousarray(digs[b]))
+        assert np.array_equal(got[j], want)
     for n in (1, 63, 64, 65, 300):
         raw = rng.integers(0, 1 << 32, (n, 256), dtype=np.uint32)
         d_raw, d_mat = hal.copy_from(raw.reshape(-1)), hal.alloc(n * 512)
@@ -185,3 +199,9 @@ def test_partial_images_pruned_subtrees_as_digests_give_the_same_root(hal):
         two.set_digest(3, np.full(8, ol.P, np.uint32))  # not a field element
     with pytest.raises(HalError, match="only given by its digest"):
         two.node_digest(hal, 7)  # inside node 3, which is only a digest here
+    # node indices outside the tree are errors, not a hang: node 0 does not exist (0 << k never reaches the leaf layer — the level
+    # search used to spin on it), and nothing lies beyond the 2^22 leaves
+    for bad in (0, 2 << 22, 0xFFFFFFFF):
+        with pytest.raises(HalError, match="outside the tree"):
+            full.node_digest(hal, bad)
+    assert np.array_equal(full.node_digest(hal, 1), root)

@@ -234,3 +234,50 @@ def test_an_idle_connection_dropped_by_the_server_is_replaced_transparently(serv
     assert [t["state"] for t in st.tasks] == ["done"] * 8
     assert 1 < w.connects < w.requests
     w.close()
+
+
+def test_a_receive_timeout_on_a_pooled_connection_is_not_retried(server):
+    """only a connection the server really CLOSED is replaced.  A request that times out on a pooled connection
+    (SO_RCVTIMEO -> EAGAIN) is that request's failure: re-sending the claim POST on a fresh socket would double the timeout and could
+    claim a task twice — the first claim may still complete server-side."""
+    import ctypes as C
+    import time
+
+    st = server.state
+    w = ag.RestWorker(server.url, io_timeout_secs=1)
+    ops = w.taskdb.ops
+    req = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(ag._ReadyTask), C.c_char_p, C.c_size_t)(ops.request_work)
+    t, eb = ag._ReadyTask(), C.create_string_buffer(256)
+    assert req(ops.user, b"prove", C.byref(t), eb, 256) == 0  # opens the connection that goes back to the pool
+    assert w.connects == 1
+    st.log.clear()
+    st.stall_next = 2.5  # the pooled connection is alive; the server just does not answer within the client's 1 s
+    t0 = time.time()
+    assert req(ops.user, b"prove", C.byref(t), eb, 256) == -1
+    dt = time.time() - t0
+    assert b"timed out" in eb.value, eb.value
+    assert dt < 1.9, dt  # one timeout, not two
+    time.sleep(2.0)  # let the stalled handler finish
+    assert len([m for m in st.log if m[0] == "POST"]) == 1, st.log  # the request was sent ONCE
+    assert w.connects == 1
+    w.close()
+
+
+def test_interim_1xx_responses_are_skipped_and_do_not_desync_the_pooled_connection(server):
+    """a `100 Continue` is not the answer.  The real response that follows is the one returned, and the next request
+    on the same pooled connection reads ITS OWN answer, not a leftover."""
+    import ctypes as C
+
+    st = server.state
+    st.create_task("prove", JOB, "i-1", {"Prove": {"index": 4}}, max_retries=2)
+    w = ag.RestWorker(server.url)
+    ops = w.taskdb.ops
+    req = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(ag._ReadyTask), C.c_char_p, C.c_size_t)(ops.request_work)
+    cur = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t)(ops.current_retries)
+    t, eb = ag._ReadyTask(), C.create_string_buffer(256)
+    st.interim_next = 2
+    assert req(ops.user, b"prove", C.byref(t), eb, 256) == 1 and t.task_id == b"i-1" and t.max_retries == 2
+    n = C.c_int32(-1)
+    assert cur(ops.user, JOB.encode(), b"i-1", C.byref(n), eb, 256) == 1 and n.value == 0  # same connection, its own answer
+    assert w.connects == 1
+    w.close()
