@@ -2,7 +2,7 @@
 overlap the kernels: size, duration and rate of the large host-to-device copies, and the share of their time during which at
 least one kernel was running on the device.
 
-    python tools/copy_overlap.py <memory_copy_trace.csv> <kernel_trace.csv> profiles/r04_h2d_overlap.json
+    python tools/copy_overlap.py <memory_copy_trace.csv> <kernel_trace.csv> profiles/r04_h2d_overlap.json [bytes per segment]
 """
 import csv
 import json
@@ -20,7 +20,8 @@ def col(row, *names):
     raise KeyError(names)
 
 
-def main(copies_csv, kernels_csv, dst):
+def main(copies_csv, kernels_csv, dst, bytes_each=0):
+    bytes_each = int(bytes_each)
     copies = list(csv.DictReader(open(copies_csv)))
     kernels = list(csv.DictReader(open(kernels_csv)))
     cs, ce = col(copies[0], "start"), col(copies[0], "end")
@@ -54,9 +55,10 @@ def main(copies_csv, kernels_csv, dst):
     out = {"csrc_sha": csrc_hash(),
            "note": "rocprofv3 --kernel-trace --memory-copy-trace of bench.py --segment-bytes 80000000 --two-deep: host-to-device copies of at least "
                    "1 MB (the segments' uploads on the provers' copy streams) and the kernels running meanwhile",
-           "uploads": len(big), "bytes_each": (sorted(n for _, _, n in big)[len(big) // 2] if big else 0),
+           "uploads": len(big), "bytes_each": ((sorted(n for _, _, n in big)[len(big) // 2] or bytes_each) if big else 0),
+           "bytes_from": "the trace" if any(n for _, _, n in big) else "the command line (this rocprofv3's CSV has no size column)",
            "avg_ms": round(dur_total / max(len(big), 1) / 1e6, 4),
-           "GBps": round(sum(n for _, _, n in big) / max(dur_total, 1), 2),
+           "GBps": round(sum((n or bytes_each) for _, _, n in big) / max(dur_total, 1), 2),
            "share_of_upload_time_with_a_kernel_running": round(covered_total / max(dur_total, 1), 4),
            "kernels_in_trace": len(kernels)}
     json.dump(out, open(dst, "w"), indent=1)
@@ -64,4 +66,4 @@ def main(copies_csv, kernels_csv, dst):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

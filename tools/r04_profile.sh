@@ -30,7 +30,8 @@ for l in 3 1; do for m in "" "--segment-bytes 80000000" "--segment-bytes 8000000
     python -c "import json,sys; j=json.loads(sys.stdin.read()); print(json.dumps({'inflight':$l,'mode':'$m' or 'resident','segment_proofs_per_s':round(j['value'],3),'host_cpu_s_per_proof':j['host_cpu_s_per_proof']}))"
 done; done > $O/r04_segment_bytes.jsonl
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/ktm -o kt -- $B --segment-bytes 80000000 --two-deep --no-live-profile > /dev/null 2>&1
-python tools/copy_overlap.py "$(find $O/ktm -name '*memory_copy_trace.csv' | head -1)" "$(find $O/ktm -name '*kernel_trace.csv' | head -1)" $O/r04_h2d_overlap.json
+python tools/copy_overlap.py "$(find $O/ktm -name '*memory_copy_trace.csv' | head -1)" "$(find $O/ktm -name '*kernel_trace.csv' | head -1)" $O/r04_h2d_overlap.json 80000000
+head -2 "$(find $O/ktm -name '*memory_copy_trace.csv' | head -1)" > $O/r04_memory_copy_trace_head.csv
 rm -rf $O/ktm
 # 5. one planned job of 64 segments: proves -> stand-in joins -> resolve -> finalize
 for l in 3 1; do python bench.py --job 64 --inflight $l 2>/dev/null | tail -1; done > $O/r04_job64.jsonl
