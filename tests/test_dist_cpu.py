@@ -40,9 +40,11 @@ def run_world(script, world=2, timeout=180):
 
 WORKER = """
 import json, time
-from boundless_amd.dist import init_distributed, SegmentQueue, timed_region
+from boundless_amd.dist import init_distributed, SegmentQueue, timed_region, gather_over_ranks
 rank, world, local_rank, dist = init_distributed(backend="gloo")
-out = {"rank": rank, "world": world}
+out = {"rank": rank, "world": world, "backend_world": dist.get_world_size()}
+# the per-rank rows of the bench line: every rank ends up with every rank's (rank, device, proofs, seconds)
+out["rows"] = gather_over_ranks([rank, 10 + rank, 3 * rank + 1, 0.5 + rank], dist)
 for mode in ("static", "steal"):
     q = SegmentQueue(total=23, rank=rank, world=world, dist=dist, mode=mode, name=mode)
     mine = []
@@ -66,6 +68,8 @@ def test_two_ranks_shard_every_segment_exactly_once():
     res = run_world(WORKER, world=2)
     assert sorted(r["rank"] for r in res) == [0, 1]
     by_rank = {r["rank"]: r for r in res}
+    for r in res:  # bench.py's `per_rank` / `backend.world_size`: identical on both ranks, in rank order
+        assert r["backend_world"] == 2 and r["rows"] == [[0.0, 10.0, 1.0, 0.5], [1.0, 11.0, 4.0, 1.5]]
     # static: rank r gets r, r+2, ...
     assert by_rank[0]["static"]["mine"] == list(range(0, 23, 2))
     assert by_rank[1]["static"]["mine"] == list(range(1, 23, 2))
@@ -91,3 +95,6 @@ def test_single_process_queue():
         assert got == [0, 1, 2, 3, 4]
     elapsed, r = timed_region(lambda: 7)
     assert r == 7 and elapsed >= 0
+    from boundless_amd.dist import gather_over_ranks
+
+    assert gather_over_ranks([0, 3, 60, 2.5]) == [[0.0, 3.0, 60.0, 2.5]]
