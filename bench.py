@@ -20,8 +20,19 @@ By default three segments are in flight per GPU (one prover, stream and host thr
 latency-bound tails (small Merkle layers, Fiat-Shamir round trips) of the first, +15 % throughput; a step is then one
 batch of `--inflight` segments per GPU and `value` counts segments.
 
+Other modes (never the default line): `--segment-bytes N [--two-deep]` makes every segment arrive as N host bytes (28-byte header +
+payload) that are copied into a pinned staging slot and uploaded on the prover's copy stream inside the timed region (the
+reference's 2^20-cycle segment is ~80 MB, executor.rs:45; `--two-deep` = a feeder thread per lane submits segment k+1 while segment
+k is proved); `--job K` proves ONE planned job of K segments through the native agent — K Prove tasks, the log-depth tail of Join
+tasks (labelled synthetic stand-ins), resolve, finalize — and reports prove-phase rate, join-tail latency and end-to-end seconds;
+`--native-agent` = the one-process multi-GPU design.
+
 The JSON line also carries
-  roofline      the NTT/LDE entry point named by BASELINE's metric: algorithmic bytes / HIP-event time on the HAL
+  single_proof_ms   wall clock of a lone proof (the reference's agent proves one segment at a time per process), no HIP events around it;
+  pcie_inclusive    untimed extra at N=1: the same workload with 80 MB per segment over PCIe, two deep (`value` stays inputs-resident);
+  per_rank, backend one row per rank (rank, device, proofs, seconds) and the backend's world size: whether RCCL saw N ranks, and balance;
+  roofline      the NTT/LDE entry point named by BASELINE's metric (`roofline.dominant` = the job's dominant kernel, hash_rows, against
+                the VALU issue peak; `roofline.traffic_over_algorithmic` = PMC bytes / algorithmic bytes of the LDE): algorithmic bytes / HIP-event time on the HAL
                 stream over the timed region, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is
                 VALU-issue-bound); measured by an isolated probe (one segment alone) because concurrent streams stretch the
                 in-region durations; `roofline_in_region` is the concurrent figure;
@@ -179,9 +190,13 @@ def _agent_run(args, widths, devices, lanes, verify, segments):
     a = ag.Agent(prover=None, device=devices[0], devices=devices if len(devices) > 1 else None, inflight=lanes, widths=widths,
                  poll_time=0.001, verify=verify, terms=args.terms, degree=args.degree)
     try:
+        pad = bytes(max(0, args.segment_bytes - 28))  # --segment-bytes: every stored segment carries this payload (uploaded per proof)
+
         def enqueue(job, n):
             for i in range(n):
-                a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
+                seg = Segment.synthetic(i, po2=args.po2)
+                seg.payload = pad
+                a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(seg), 600)
                 a.taskdb.create_task(job, f"prove-{i}", {"Prove": {"index": i}})
 
         enqueue("warm", max(1, args.warmup) * lanes * len(devices))
@@ -231,7 +246,7 @@ def native_agent_main(args, widths):
            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic",
            "config": {"workload": f"2^{args.po2}-cycle synthetic segments through the native prove agent (claim -> hot-store GET -> prove on the GPU -> "
                                   f"CPU verify -> SETEX -> UNLINK -> done), trace widths {'/'.join(map(str, widths))}", "po2": args.po2,
-                      "segments_proved": segments, "segments_in_flight_per_gpu": lanes,
+                      "segments_proved": segments, "segments_in_flight_per_gpu": lanes, "segment_bytes": max(28, args.segment_bytes),
                       "queue": "one in-memory task db shared by every lane of every device (claim-when-idle)",
                       "parallelism": f"one process, {n} device(s) x {lanes} lanes, no collective, no torch.distributed"},
            "host_cpu_s_per_proof": r["host_cpu_s_per_proof"],

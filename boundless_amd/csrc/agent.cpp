@@ -342,12 +342,16 @@ uint64_t get_le(const uint8_t* p, int n) {
 // ------------------------------------------------------------------------------------------------ in-memory stores ----
 struct bx_mem_store {
     std::mutex mu;
+    // a value is immutable once set: GET hands out the stored bytes themselves (no copy of an ~80 MB segment), kept alive by a
+    // reference until free_value even when the key is overwritten or unlinked meanwhile
+    using Bytes = std::shared_ptr<const std::vector<uint8_t>>;
     struct Val {
-        std::vector<uint8_t> bytes;
+        Bytes bytes;
         bool expires = false;
         Clock::time_point deadline;
     };
     std::map<std::string, Val> kv;
+    std::multimap<const uint8_t*, Bytes> lent;  // values handed out by get and not yet given back
     void sweep_locked() {
         auto now = Clock::now();
         for (auto it = kv.begin(); it != kv.end();) it = (it->second.expires && it->second.deadline < now) ? kv.erase(it) : ++it;
@@ -363,19 +367,31 @@ static int mem_get(void* user, const char* key, uint8_t** value, size_t* len, ch
         s->kv.erase(it);
         return 1;
     }
-    *len = it->second.bytes.size();
-    *value = (uint8_t*)malloc(*len ? *len : 1);
-    if (!*value) return -1;
-    memcpy(*value, it->second.bytes.data(), *len);
-    return 0;
+    try {
+        const bx_mem_store::Bytes& b = it->second.bytes;
+        *len = b->size();
+        *value = const_cast<uint8_t*>(b->data());  // read-only by contract (bx_hot_store_ops::get)
+        s->lent.emplace(b->data(), b);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
 }
-static void mem_free_value(void*, uint8_t* v) { free(v); }
+static void mem_free_value(void* user, uint8_t* v) {
+    auto* s = (bx_mem_store*)user;
+    std::lock_guard<std::mutex> g(s->mu);
+    auto it = s->lent.find(v);
+    if (it != s->lent.end()) s->lent.erase(it);
+}
 static int mem_set_ex(void* user, const char* key, const uint8_t* value, size_t len, uint64_t ttl, char*, size_t) {
     auto* s = (bx_mem_store*)user;
     try {  // these tables are a C interface: an allocation failure is a transport error, not an exception
         std::lock_guard<std::mutex> g(s->mu);
         bx_mem_store::Val v;
-        v.bytes.assign(value, value + len);
+        auto owned = std::make_shared<std::vector<uint8_t>>(len ? len : 1);  // never an empty vector: data() is the key of `lent`
+        owned->resize(len);
+        if (len) memcpy(owned->data(), value, len);
+        v.bytes = std::move(owned);
         v.expires = ttl != 0;
         if (ttl) v.deadline = Clock::now() + std::chrono::seconds(ttl);
         s->kv[key] = std::move(v);

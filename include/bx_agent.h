@@ -62,7 +62,9 @@ const char* bx_planner_get_task(bx_planner* p, uint64_t task_number, bx_plan_tas
 
 /* ------------------------------------------------------------------------------------- stores (callbacks) ---- */
 /* Hot store = the three Redis operations the prove task issues.  Return 0 = ok, 1 = key not found (get only),
- * negative = transport error; on error `errbuf` (cap bytes) may be filled with a message. */
+ * negative = transport error; on error `errbuf` (cap bytes) may be filled with a message.  A value handed out by `get` is
+ * read-only and stays valid until `free_value` (the in-memory store lends its own copy of the bytes: an ~80 MB segment is not
+ * duplicated on its way to the prover). */
 typedef struct bx_hot_store_ops {
     void* user;
     int (*get)(void* user, const char* key, uint8_t** value, size_t* len, char* errbuf, size_t cap);

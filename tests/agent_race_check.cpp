@@ -41,7 +41,7 @@ static const char* prove(void*, uint32_t lane, uint32_t, const uint8_t* segment,
     if (bx_segment_decode(segment, len, &index, nullptr, &seed)) return "not a segment";
     uint64_t n = g_calls.fetch_add(1);
     if (cap < 64) return "cap";
-    std::this_thread::sleep_for(std::chrono::microseconds(lane / 2 == 1 ? 5000 : 100));  // device 1 is the slow GPU
+    std::this_thread::sleep_for(std::chrono::microseconds(lane / 2 == 1 ? 10000 : 100));  // device 1 is the slow GPU
     if ((n * 2654435761u >> 7) % 5 == 0) return "hipErrorLaunchFailure (injected)";
     for (uint32_t i = 0; i < 64; ++i) seal[i] = (uint32_t)(seed + index + i + lane * 0);
     seal[0] = ((n >> 3) % 7 == 0) ? 9u : 7u;  // some seals fail verification -> retried from the finisher thread
