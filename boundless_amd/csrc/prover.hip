@@ -89,16 +89,12 @@ struct Group {
 // One of the prover's two staging slots for a segment's bytes (bx_prover_submit_segment): pinned host copy -> HBM copy on the
 // prover's copy stream; `up` is recorded behind the upload and the compute stream waits on it, never the host.
 struct SegSlot {
-    uint8_t* host = nullptr;  // pinned staging copy (bx_prover_submit_segment)
+    uint8_t* host = nullptr;
     size_t host_cap = 0;
     uint32_t* dev = nullptr;
     size_t dev_cap = 0;  // bytes
     size_t len = 0;
     hipEvent_t up0 = nullptr, up = nullptr;
-    // bx_prove_segment_bytes blocks until the proof is done, so the caller's buffer can be page-locked IN PLACE for the duration of the
-    // call and uploaded from where it lies (0.4 ms of host time for 80 MB against 2.3 ms for the staging copy, tools/stagebench.hip)
-    const uint8_t* view = nullptr;  // what witgen reads on the host: `host`, or the caller's registered buffer
-    void* registered = nullptr;     // non-null: hipHostUnregister this when the proof returns
 };
 
 struct FriRound {
@@ -414,11 +410,7 @@ extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_o
 static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
 
 // ---- the segment's bytes: pinned staging + upload on the copy stream (two slots) ----
-static const char* submit_segment_impl(bx_prover* p, const uint8_t* segment, size_t len, bool in_place);
 extern "C" const char* bx_prover_submit_segment(bx_prover* p, const uint8_t* segment, size_t len) try {
-    return submit_segment_impl(p, segment, len, false);
-} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_submit_segment")
-static const char* submit_segment_impl(bx_prover* p, const uint8_t* segment, size_t len, bool in_place) {
     if (!p) return "bx_prover_submit_segment: null prover";
     if (!segment || len == 0) return perr(p, "bx_prover_submit_segment: empty segment");
     if (len > ((size_t)1 << 32) - 4) return perr(p, "bx_prover_submit_segment: segment larger than 4 GiB");
@@ -428,50 +420,25 @@ static const char* submit_segment_impl(bx_prover* p, const uint8_t* segment, siz
     if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prover_submit_segment: hipSetDevice failed");
     SegSlot& sl = p->seg[(p->seg_head + p->seg_count) & 1];
     const size_t padded = (len + 3) & ~(size_t)3;
-    if (sl.dev_cap < padded) {  // grown on demand, kept for the prover's lifetime (a free slot has no copy in flight)
+    if (sl.host_cap < padded) {  // grown on demand, kept for the prover's lifetime (a free slot has no copy in flight)
+        if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);
-        sl.dev = nullptr, sl.dev_cap = 0;
+        sl.host = nullptr, sl.dev = nullptr, sl.host_cap = sl.dev_cap = 0;
         const size_t cap = padded + padded / 8;
+        if (hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of pinned host memory");
+        sl.host_cap = cap;
         if (hipMalloc((void**)&sl.dev, cap) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of device memory");
         sl.dev_cap = cap;
     }
-    // a large buffer that outlives the call is page-locked where it lies; small ones (and any the runtime refuses to register) are
-    // copied: below ~1 MB the copy is cheaper than the two driver calls
-    sl.registered = nullptr;
-    if (in_place && len >= ((size_t)1 << 20) && hipHostRegister((void*)segment, len, hipHostRegisterDefault) == hipSuccess) sl.registered = (void*)segment;
-    else (void)hipGetLastError();
-    const uint8_t* src = segment;
-    size_t up_bytes = len;  // the 0-3 pad bytes of the last word are only defined in the staged copy; a registered upload leaves them as they are
-    if (!sl.registered) {
-        if (sl.host_cap < padded) {
-            if (sl.host) (void)hipHostFree(sl.host);
-            sl.host = nullptr, sl.host_cap = 0;
-            const size_t cap = padded + padded / 8;
-            if (hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of pinned host memory");
-            sl.host_cap = cap;
-        }
-        memcpy(sl.host, segment, len);
-        if (padded > len) memset(sl.host + len, 0, padded - len);
-        src = sl.host;
-        up_bytes = padded;
-    } else if (padded > len) {
-        if (hipMemsetAsync((uint8_t*)sl.dev + (len & ~(size_t)3), 0, 4, p->copy_stream) != hipSuccess) {  // zero the last word before the bytes land in it
-            (void)hipHostUnregister(sl.registered);
-            sl.registered = nullptr;
-            return perr(p, "bx_prover_submit_segment: upload failed");
-        }
-    }
-    sl.view = src;
+    memcpy(sl.host, segment, len);
+    if (padded > len) memset(sl.host + len, 0, padded - len);
     sl.len = len;
-    if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess || hipMemcpyAsync(sl.dev, src, up_bytes, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess ||
-        hipEventRecord(sl.up, p->copy_stream) != hipSuccess) {
-        if (sl.registered) (void)hipHostUnregister(sl.registered);
-        sl.registered = nullptr;
+    if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess || hipMemcpyAsync(sl.dev, sl.host, padded, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess ||
+        hipEventRecord(sl.up, p->copy_stream) != hipSuccess)
         return perr(p, "bx_prover_submit_segment: upload failed");
-    }
     p->seg_count += 1;
     return nullptr;
-}
+} BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_submit_segment")
 
 extern "C" const char* bx_prove_submitted(bx_prover* p, uint32_t* seal_out, size_t seal_cap, size_t* seal_words) try {
     if (!p) return "bx_prove_submitted: null prover";
@@ -488,10 +455,6 @@ extern "C" const char* bx_prove_submitted(bx_prover* p, uint32_t* seal_out, size
     // a proof ends with a blocking read-back of the whole stream, so the upload is over: its duration is on the two events
     if (!r && hipEventElapsedTime(&p->last_upload_ms, sl->up0, sl->up) == hipSuccess) p->last_upload_bytes = sl->len;
     if (r) (void)hipEventSynchronize(sl->up);  // failed before the stream got there: the slot must be idle before it is reused
-    if (sl->registered) {  // the caller's buffer was page-locked for this call only
-        (void)hipHostUnregister(sl->registered);
-        sl->registered = nullptr;
-    }
     std::lock_guard<std::mutex> g(p->seg_mu);
     p->seg_head ^= 1;
     p->seg_count -= 1;
@@ -504,7 +467,7 @@ extern "C" const char* bx_prove_segment_bytes(bx_prover* p, const uint8_t* segme
         std::lock_guard<std::mutex> g(p->seg_mu);
         if (p->seg_count != 0) return perr(p, "bx_prove_segment_bytes: segments submitted earlier are still outstanding (use bx_prove_submitted)");
     }
-    if (const char* e = submit_segment_impl(p, segment, len, true)) return e;  // the call blocks: the caller's buffer is uploaded from where it lies
+    if (const char* e = bx_prover_submit_segment(p, segment, len)) return e;
     return bx_prove_submitted(p, seal_out, seal_cap, seal_words);
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment_bytes")
 
@@ -576,7 +539,7 @@ static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t
     {
         TraceRange tr(c, "bx:witgen");
         PV(circ->code_group(circ->user, p->circ_state, c, p->groups[0].coeffs.b));
-        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seg.view, seg.len,
+        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seg.host, seg.len,
                         bx_buf{seg.dev, (seg.len + 3) / 4}, globals));
     }
     if (p->n_globals) {  // the statement's public words: in the seal and in the transcript before any commitment

@@ -107,10 +107,11 @@ void bx_segment_encode(uint64_t index, uint32_t po2, uint64_t seed, uint8_t out[
 const char* bx_segment_decode(const uint8_t* blob, size_t len, uint64_t* index, uint32_t* po2, uint64_t* seed);
 
 /* `ProverServer::prove_segment(&ctx, &segment)`: prove the segment whose serialized bytes are given (for the built-in circuit:
- * the stand-in above; a plug-in circuit defines its own).  The bytes are uploaded on the prover's copy stream and handed to the
- * circuit's witgen on the host and in HBM; the seal (u32 words) and its length are written.  Blocks — so a large buffer is
- * page-locked where it lies for the duration of the call (hipHostRegister: 0.4 ms of host time for 80 MB) instead of being copied to
- * the pinned staging slot (2.3 ms; what small buffers, buffers the runtime refuses to lock, and bx_prover_submit_segment get). */
+ * the stand-in above; a plug-in circuit defines its own).  The bytes are copied to pinned staging memory (2.3 ms for 80 MB),
+ * uploaded on the prover's copy stream (1.4 ms) and handed to the circuit's witgen on the host and in HBM; the seal (u32 words) and
+ * its length are written.  Blocks.  (Page-locking the caller's buffer in place instead of copying it — hipHostRegister — is cheaper
+ * in isolation, 0.4 ms, and was tried: with fresh buffers and three lanes it stalls every lane of the process for the duration of
+ * the driver call, 24.5 -> 18.6 proofs/s through the agent) */
 const char* bx_prove_segment_bytes(bx_prover* prover, const uint8_t* segment, size_t segment_len, uint32_t* seal_out, size_t seal_cap,
                                    size_t* seal_words);
 /* The same in two steps, two deep ("H2D of next segment overlapped with compute"): submit copies the bytes
