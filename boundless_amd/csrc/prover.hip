@@ -125,6 +125,7 @@ struct bx_prover {
     uint32_t n_globals = 0;                          // public words of the statement (bx_circuit_ops::n_globals)
     ~bx_prover() {
         if (circ && circ_state && circ->destroy) circ->destroy(circ->user, circ_state);
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);  // a segment submitted and never proved may still be on its way up
         for (SegSlot& sl : seg) {
             if (sl.host) (void)hipHostFree(sl.host);
             if (sl.dev) (void)hipFree(sl.dev);
@@ -139,6 +140,7 @@ struct bx_prover {
     uint32_t last_roots[32];
     size_t seal_bound = 0;
     char err[512];
+    char seg_err[256];  // bx_prover_submit_segment may run on another thread than the proof: its own message buffer
     // segment staging: two slots, oldest first (submit may run on another thread than prove_submitted)
     SegSlot seg[2];
     int seg_head = 0, seg_count = 0;
@@ -410,24 +412,28 @@ extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_o
 static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
 
 // ---- the segment's bytes: pinned staging + upload on the copy stream (two slots) ----
+static const char* serr(bx_prover* p, const char* m) {
+    snprintf(p->seg_err, sizeof p->seg_err, "%s", m);
+    return p->seg_err;
+}
 extern "C" const char* bx_prover_submit_segment(bx_prover* p, const uint8_t* segment, size_t len) try {
     if (!p) return "bx_prover_submit_segment: null prover";
-    if (!segment || len == 0) return perr(p, "bx_prover_submit_segment: empty segment");
-    if (len > ((size_t)1 << 32) - 4) return perr(p, "bx_prover_submit_segment: segment larger than 4 GiB");
+    if (!segment || len == 0) return serr(p, "bx_prover_submit_segment: empty segment");
+    if (len > ((size_t)1 << 32) - 4) return serr(p, "bx_prover_submit_segment: segment larger than 4 GiB");
     bx_ctx* c = p->c;
     std::lock_guard<std::mutex> g(p->seg_mu);
-    if (p->seg_count == 2) return perr(p, "bx_prover_submit_segment: staging slots busy (two segments are already outstanding)");
-    if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prover_submit_segment: hipSetDevice failed");
+    if (p->seg_count == 2) return serr(p, "bx_prover_submit_segment: staging slots busy (two segments are already outstanding)");
+    if (hipSetDevice(c->device) != hipSuccess) return serr(p, "bx_prover_submit_segment: hipSetDevice failed");
     SegSlot& sl = p->seg[(p->seg_head + p->seg_count) & 1];
     const size_t padded = (len + 3) & ~(size_t)3;
-    if (sl.host_cap < padded) {  // grown on demand, kept for the prover's lifetime (a free slot has no copy in flight)
+    if (sl.host_cap < padded || sl.dev_cap < padded) {  // grown on demand, kept for the prover's lifetime (a free slot has no copy in flight)
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);
         sl.host = nullptr, sl.dev = nullptr, sl.host_cap = sl.dev_cap = 0;
         const size_t cap = padded + padded / 8;
-        if (hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of pinned host memory");
+        if (hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) != hipSuccess) return serr(p, "bx_prover_submit_segment: out of pinned host memory");
         sl.host_cap = cap;
-        if (hipMalloc((void**)&sl.dev, cap) != hipSuccess) return perr(p, "bx_prover_submit_segment: out of device memory");
+        if (hipMalloc((void**)&sl.dev, cap) != hipSuccess) return serr(p, "bx_prover_submit_segment: out of device memory");
         sl.dev_cap = cap;
     }
     memcpy(sl.host, segment, len);
@@ -435,7 +441,7 @@ extern "C" const char* bx_prover_submit_segment(bx_prover* p, const uint8_t* seg
     sl.len = len;
     if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess || hipMemcpyAsync(sl.dev, sl.host, padded, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess ||
         hipEventRecord(sl.up, p->copy_stream) != hipSuccess)
-        return perr(p, "bx_prover_submit_segment: upload failed");
+        return serr(p, "bx_prover_submit_segment: upload failed");
     p->seg_count += 1;
     return nullptr;
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_submit_segment")

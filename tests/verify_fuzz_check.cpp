@@ -52,6 +52,23 @@ int main(int argc, char** argv) {
         printf("empty seal accepted\n");
         return 1;
     }
+    // the explicit VerifierContext path: a context that holds the circuit's control ID for this seal's shape accepts it, one that
+    // holds another ID (or the right ID under another po2) does not
+    bx_verifier_ctx *good = nullptr, *bad = nullptr;
+    uint32_t id[8];
+    if (bx_verifier_ctx_create(&good) || bx_verifier_ctx_create(&bad) || bx_synthetic_control_id_host(seal[0], seal[1], id)) return 2;
+    if (bx_verifier_ctx_add_control_id(good, seal[0], id) || bx_verifier_ctx_add_control_id(bad, seal[0] == 9 ? 10 : 9, id)) return 2;
+    id[3] ^= 1u;
+    if (bx_verifier_ctx_add_control_id(bad, seal[0], id)) return 2;
+    if (const char* e = bx_verify_segment_with_context(seal.data(), seal.size(), nullptr, good)) {
+        printf("honest seal rejected against its own control ID: %s\n", e);
+        return 1;
+    }
+    if (bx_verify_segment_with_context(seal.data(), seal.size(), nullptr, bad) == nullptr || bx_verifier_ctx_size(bad) != 2 ||
+        bx_verifier_ctx_count(bad, seal[0]) != 1) {
+        printf("a context without the seal's control ID accepted it\n");
+        return 1;
+    }
     const uint32_t P = 2013265921u;
     long accepted = 0;
     for (long it = 0; it < iters; ++it) {
@@ -87,13 +104,15 @@ int main(int argc, char** argv) {
         // exact-size heap copy so that a read one word past the end is an ASan report
         uint32_t* heap = (uint32_t*)malloc(m.size() * 4 + (m.empty() ? 1 : 0));
         memcpy(heap, m.data(), m.size() * 4);
-        const char* e = bx_verify_segment(heap, m.size());
+        const char* e = (it & 1) ? bx_verify_segment(heap, m.size()) : bx_verify_segment_with_context(heap, m.size(), nullptr, good);
         free(heap);
         if (!e) {
             ++accepted;
             printf("mutation %ld accepted\n", it);
         }
     }
+    bx_verifier_ctx_destroy(good);
+    bx_verifier_ctx_destroy(bad);
     if (accepted) return 1;
     printf("verify_fuzz_check ok (%ld mutations rejected)\n", iters);
     return 0;
