@@ -117,6 +117,8 @@ struct bx_prover {
     HostPoseidon2 h2;
     Group groups[4];  // code, data, accum, check
     DevBuf combos, final_poly, which, xs, evals, rems, positions, qout;
+    DevBuf code_w;  // the code group's WITNESS (what witgen reads); groups[0].coeffs is interpolated in place by the commit, which is
+                    // enqueued before the segment's bytes have arrived (prove_prologue)
     DevBuf tap_ptrs, tap_flags;  // per tap evaluation: the device address of its coefficient column and its storage order (N >= 2^15)
     std::vector<std::vector<uint32_t>> combo_backs;  // trace combos in order of first appearance; the check combo comes after them
     std::vector<uint32_t> tap_which;                 // polynomial index of every tap evaluation (fixed per shape)
@@ -140,6 +142,7 @@ struct bx_prover {
     uint32_t last_roots[32];
     size_t seal_bound = 0;
     char err[512];
+    bool prologue_done = false;  // prove_prologue was already enqueued for the next bx_prove_submitted
     char seg_err[256];  // bx_prover_submit_segment may run on another thread than the proof: its own message buffer
     // segment staging: two slots, oldest first (submit may run on another thread than prove_submitted)
     SegSlot seg[2];
@@ -327,6 +330,7 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
         if (const char* e = circuit->create(circuit->user, c, &p->shape, &p->circ_state)) return e == c->err ? e : set_msg(c, e);
     p->n_globals = circuit->n_globals ? circuit->n_globals(circuit->user, &p->shape) : 0;
     BX_REQUIRE(c, p->n_globals <= BX_MAX_GLOBALS, "bx_prover_create: too many public words");
+    BX_TRY(p->code_w.alloc(c, (size_t)shape->w_code * N));
     BX_TRY(p->combos.alloc(c, n_combos * 4 * N));
     BX_TRY(p->final_poly.alloc(c, 4 * N));
     // tap evaluations of all four groups go up, run and come back as one batch (one host round trip instead of twelve)
@@ -411,6 +415,19 @@ extern "C" const char* bx_prover_last_roots(const bx_prover* p, uint32_t roots_o
 
 static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t* seal_out, size_t seal_cap, size_t* seal_words);
 
+// What a proof can start before its segment has arrived: the code group (a function of the shape) and its whole commitment —
+// 2.2 ms of device work at 2^20 that the upload of the segment's bytes hides behind.  The witness of the code group is kept in
+// code_w for witgen (the commit interpolates groups[0].coeffs in place).  Enqueues only.
+static const char* prove_prologue(bx_prover* p) {
+    bx_ctx* c = p->c;
+    const bx_circuit_ops* circ = p->circ;
+    TraceRange tr(c, "bx:commit_code");
+    PV(circ->code_group(circ->user, p->circ_state, c, p->code_w.b));
+    PV(bx_eltwise_copy_elem(c, p->groups[0].coeffs.b, p->code_w.b));
+    PV(commit_group_work(p, p->groups[0]));
+    return nullptr;
+}
+
 // ---- the segment's bytes: pinned staging + upload on the copy stream (two slots) ----
 static const char* serr(bx_prover* p, const char* m) {
     snprintf(p->seg_err, sizeof p->seg_err, "%s", m);
@@ -436,12 +453,19 @@ extern "C" const char* bx_prover_submit_segment(bx_prover* p, const uint8_t* seg
         if (hipMalloc((void**)&sl.dev, cap) != hipSuccess) return serr(p, "bx_prover_submit_segment: out of device memory");
         sl.dev_cap = cap;
     }
-    memcpy(sl.host, segment, len);
-    if (padded > len) memset(sl.host + len, 0, padded - len);
+    // copy and upload in 8 MB pieces: the DMA of piece i runs while piece i+1 is copied into the slot (host copy ~34 GB/s, PCIe ~57 GB/s:
+    // an 80 MB segment is in HBM ~0.2 ms after its last byte was copied instead of 1.4 ms)
     sl.len = len;
-    if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess || hipMemcpyAsync(sl.dev, sl.host, padded, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess ||
-        hipEventRecord(sl.up, p->copy_stream) != hipSuccess)
-        return serr(p, "bx_prover_submit_segment: upload failed");
+    if (hipEventRecord(sl.up0, p->copy_stream) != hipSuccess) return serr(p, "bx_prover_submit_segment: upload failed");
+    constexpr size_t PIECE = (size_t)8 << 20;
+    for (size_t off = 0; off < padded; off += PIECE) {
+        const size_t n = padded - off < PIECE ? padded - off : PIECE, have = off + n <= len ? n : (len > off ? len - off : 0);
+        if (have) memcpy(sl.host + off, segment + off, have);
+        if (have < n) memset(sl.host + off + have, 0, n - have);
+        if (hipMemcpyAsync((uint8_t*)sl.dev + off, sl.host + off, n, hipMemcpyHostToDevice, p->copy_stream) != hipSuccess)
+            return serr(p, "bx_prover_submit_segment: upload failed");
+    }
+    if (hipEventRecord(sl.up, p->copy_stream) != hipSuccess) return serr(p, "bx_prover_submit_segment: upload failed");
     p->seg_count += 1;
     return nullptr;
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prover_submit_segment")
@@ -455,9 +479,13 @@ extern "C" const char* bx_prove_submitted(bx_prover* p, uint32_t* seal_out, size
         sl = &p->seg[p->seg_head];
     }
     const char* r = nullptr;
+    // the code group's commitment is enqueued first (bx_prove_segment_bytes did that before it even staged the bytes); everything from
+    // witgen on waits for the upload's event — on the stream, not on the host
     if (hipSetDevice(p->c->device) != hipSuccess) r = perr(p, "bx_prove_segment: hipSetDevice failed");
-    else if (hipStreamWaitEvent(p->c->stream, sl->up, 0) != hipSuccess) r = perr(p, "bx_prove_segment: could not order the proof behind the segment's upload");
+    else if (!p->prologue_done && (r = prove_prologue(p)) != nullptr) {
+    } else if (hipStreamWaitEvent(p->c->stream, sl->up, 0) != hipSuccess) r = perr(p, "bx_prove_segment: could not order the proof behind the segment's upload");
     else r = prove_segment_impl(p, *sl, seal_out, seal_cap, seal_words);
+    p->prologue_done = false;
     // a proof ends with a blocking read-back of the whole stream, so the upload is over: its duration is on the two events
     if (!r && hipEventElapsedTime(&p->last_upload_ms, sl->up0, sl->up) == hipSuccess) p->last_upload_bytes = sl->len;
     if (r) (void)hipEventSynchronize(sl->up);  // failed before the stream got there: the slot must be idle before it is reused
@@ -473,7 +501,14 @@ extern "C" const char* bx_prove_segment_bytes(bx_prover* p, const uint8_t* segme
         std::lock_guard<std::mutex> g(p->seg_mu);
         if (p->seg_count != 0) return perr(p, "bx_prove_segment_bytes: segments submitted earlier are still outstanding (use bx_prove_submitted)");
     }
-    if (const char* e = bx_prover_submit_segment(p, segment, len)) return e;
+    // start what does not need the bytes, then stage and upload them while the device works on it
+    if (hipSetDevice(p->c->device) != hipSuccess) return perr(p, "bx_prove_segment: hipSetDevice failed");
+    if (const char* e = prove_prologue(p)) return e;
+    p->prologue_done = true;
+    if (const char* e = bx_prover_submit_segment(p, segment, len)) {
+        p->prologue_done = false;  // the code commitment just enqueued is simply redone by the next proof
+        return e;
+    }
     return bx_prove_submitted(p, seal_out, seal_cap, seal_words);
 } BX_ABI_CATCH((p ? p->c : nullptr), "bx_prove_segment_bytes")
 
@@ -508,8 +543,7 @@ extern "C" const char* bx_prover_control_id(bx_prover* p, uint32_t id_out[8]) tr
     bx_ctx* c = p->c;
     if (hipSetDevice(c->device) != hipSuccess) return perr(p, "bx_prover_control_id: hipSetDevice failed");
     Group& G = p->groups[0];
-    PV(p->circ->code_group(p->circ->user, p->circ_state, c, G.coeffs.b));
-    PV(commit_group_work(p, G));
+    PV(prove_prologue(p));
     size_t used = 0;
     const uint32_t* host = nullptr;
     PV(tree_fetch(p, G.tree, &used, &host));
@@ -543,9 +577,8 @@ static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t
     uint32_t globals[BX_MAX_GLOBALS];
     memset(globals, 0, sizeof globals);
     {
-        TraceRange tr(c, "bx:witgen");
-        PV(circ->code_group(circ->user, p->circ_state, c, p->groups[0].coeffs.b));
-        PV(circ->witgen(circ->user, p->circ_state, c, p->groups[0].coeffs.b, p->groups[1].coeffs.b, seg.host, seg.len,
+        TraceRange tr(c, "bx:witgen");  // the code group and its commitment are already enqueued (prove_prologue)
+        PV(circ->witgen(circ->user, p->circ_state, c, p->code_w.b, p->groups[1].coeffs.b, seg.host, seg.len,
                         bx_buf{seg.dev, (seg.len + 3) / 4}, globals));
     }
     if (p->n_globals) {  // the statement's public words: in the seal and in the transcript before any commitment
@@ -560,10 +593,6 @@ static const char* prove_segment_impl(bx_prover* p, const SegSlot& seg, uint32_t
         // roots and top layers; the transcript absorbs them in order (code, then data) and only then is beta drawn
         size_t used = 0;
         const uint32_t* host[2] = {nullptr, nullptr};
-        {
-            TraceRange tr(c, "bx:commit_code");
-            PV(commit_group_work(p, p->groups[0]));
-        }
         TraceRange tr(c, "bx:commit_data");
         PV(commit_group_work(p, p->groups[1]));
         PV(tree_fetch(p, p->groups[0].tree, &used, &host[0]));
