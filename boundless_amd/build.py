@@ -21,18 +21,21 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 
 
 def csrc_hash():
-    """SHA-256 (first 16 hex digits) over the kernel and host sources of the library, in name order.  Profile summaries under
-    profiles/ are stamped with it by the tools that write them, and bench.py reports `profile_stale` when the library it runs
-    was built from different sources than the ones a replayed PMC figure was collected on.  (A content hash rather than a git
-    tree hash: the GPU box receives a snapshot without .git.)"""
+    """SHA-256 (first 16 hex digits) over the CODE of the kernel and host sources of the library, in name order: comments are
+    stripped and runs of white space collapsed first, so that editing the prose of a header does not make every committed profile
+    look stale.  Profile summaries under profiles/ are stamped with it by the tools that write them, and bench.py reports
+    `profile_stale` when the library it runs was built from different sources than the ones a replayed PMC figure was collected
+    on.  (A content hash rather than a git tree hash: the GPU box receives a snapshot without .git.)"""
     import hashlib
+    import re
 
+    strip = re.compile(rb"//[^\n]*|/\*.*?\*/", re.S)
     h = hashlib.sha256()
     for d in (CSRC, INC):
         for f in sorted(os.listdir(d)):
             if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")):
                 h.update(f.encode() + b"\0")
-                h.update(open(os.path.join(d, f), "rb").read())
+                h.update(b" ".join(strip.sub(b" ", open(os.path.join(d, f), "rb").read()).split()))
     return h.hexdigest()[:16]
 
 

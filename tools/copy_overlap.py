@@ -31,11 +31,19 @@ def main(copies_csv, kernels_csv, dst, bytes_each=0):
         cb = None
     ks, ke = col(kernels[0], "start"), col(kernels[0], "end")
     kiv = sorted((int(k[ks]), int(k[ke])) for k in kernels)
+    # the segments go up in 8 MiB pieces (bx_prover_submit_segment): host-to-device copies that take longer than 50 us are those pieces
+    # (the prover's own small uploads — tap points, query positions — take microseconds)
+    try:
+        cd = col(copies[0], "direction")
+    except KeyError:
+        cd = None
     big = []
     for c in copies:
+        if cd and "HOST_TO_DEVICE" not in c[cd].upper():
+            continue
         s, e = int(c[cs]), int(c[ce])
         n = int(c[cb]) if cb and c[cb] else 0
-        if n >= 1_000_000 or (not cb and e - s > 500_000):
+        if n >= 1_000_000 or (not cb and e - s > 50_000):
             big.append((s, e, n))
     covered_total, dur_total = 0, 0
     for s, e, _ in big:
@@ -53,12 +61,13 @@ def main(copies_csv, kernels_csv, dst, bytes_each=0):
         covered_total += cov
         dur_total += e - s
     out = {"csrc_sha": csrc_hash(),
-           "note": "rocprofv3 --kernel-trace --memory-copy-trace of bench.py --segment-bytes 80000000 --two-deep: host-to-device copies of at least "
-                   "1 MB (the segments' uploads on the provers' copy streams) and the kernels running meanwhile",
-           "uploads": len(big), "bytes_each": ((sorted(n for _, _, n in big)[len(big) // 2] or bytes_each) if big else 0),
-           "bytes_from": "the trace" if any(n for _, _, n in big) else "the command line (this rocprofv3's CSV has no size column)",
-           "avg_ms": round(dur_total / max(len(big), 1) / 1e6, 4),
-           "GBps": round(sum((n or bytes_each) for _, _, n in big) / max(dur_total, 1), 2),
+           "note": "rocprofv3 --kernel-trace --memory-copy-trace of bench.py --segment-bytes 80000000: the 8 MiB pieces of the segments' uploads "
+                   "(host-to-device copies longer than 50 us, on the provers' copy streams) and the kernels running meanwhile",
+           "pieces": len(big), "piece_bytes": 8 << 20, "pieces_per_segment": (-(-bytes_each // (8 << 20)) if bytes_each else None),
+           "segments_uploaded": (round(len(big) / -(-bytes_each // (8 << 20)), 1) if bytes_each else None),
+           "segment_bytes": bytes_each, "bytes_from": "the command line (this rocprofv3's CSV has no size column)",
+           "dma_ms_per_segment": (round(dur_total / 1e6 / (len(big) / -(-bytes_each // (8 << 20))), 4) if bytes_each and big else None),
+           "GBps": (round(bytes_each * (len(big) / -(-bytes_each // (8 << 20))) / max(dur_total, 1), 2) if bytes_each else None),
            "share_of_upload_time_with_a_kernel_running": round(covered_total / max(dur_total, 1), 4),
            "kernels_in_trace": len(kernels)}
     json.dump(out, open(dst, "w"), indent=1)
