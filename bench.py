@@ -285,7 +285,9 @@ def job_main(args, widths):
                 a.store.set_key_with_expiry(f"job:{job}:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=args.po2)), 600)
             return a.taskdb.plan_job(job, k)
 
-        submit("warm", 4 * lanes * n)  # every lane creates both buffer sets (segment size and join size) before the clock starts
+        a.prewarm(args.po2)       # every lane creates both buffer sets (segment size and join size) before the clock starts,
+        a.prewarm(args.join_po2)  # as a deployment that knows its --segment-po2 does at start-up
+        submit("warm", 2 * lanes * n)
         a.poll_work(max_idle_polls=2)
         ids = submit("timed", K)
         t0 = time.perf_counter()

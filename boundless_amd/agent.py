@@ -100,6 +100,7 @@ def _lib():
         "bx_agent_destroy": ([vp], cp), "bx_agent_poll_work": ([vp, C.c_int64, C.POINTER(C.c_uint64)], cp),
         "bx_agent_stop": ([vp], None), "bx_agent_process_one": ([vp, C.POINTER(_ReadyTask), C.POINTER(C.c_int)], cp),
         "bx_agent_metrics": ([vp, cp, sz], sz),
+        "bx_agent_prewarm": ([vp, C.c_uint32], cp),
         "bx_rest_client_create": ([cp, C.c_uint64, C.c_uint64, C.POINTER(vp)], cp), "bx_rest_client_destroy": ([vp], None),
         "bx_rest_taskdb_ops": ([vp], _TaskDbOps), "bx_rest_hot_store_ops": ([vp], _HotStoreOps),
         "bx_rest_client_requests": ([vp], C.c_uint64),
@@ -366,6 +367,10 @@ class Agent:
         self._h = C.c_void_p()
         _check(self._lib.bx_agent_create(C.byref(cfg), C.byref(self.store.ops), C.byref(self.taskdb.ops), ops_ptr,
                                          C.byref(self._h)))
+
+    def prewarm(self, po2):
+        """bx_agent_prewarm: every lane creates its buffer set for 2^po2-cycle segments now (HIP prover only)."""
+        _check(self._lib.bx_agent_prewarm(self._h, po2))
 
     def lane_stats(self):
         """[(device, tasks completed)] per lane: which GPU's lanes claimed how much of the shared queue."""

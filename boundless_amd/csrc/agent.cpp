@@ -1516,6 +1516,21 @@ void bx_agent_stop(bx_agent* a) {
     if (a) a->stop.store(1, std::memory_order_relaxed);
 }
 
+const char* bx_agent_prewarm(bx_agent* a, uint32_t po2) {
+    if (!a) return "bx_agent_prewarm: NULL agent";
+    if (!a->hip) return nullptr;
+    try {
+        for (uint32_t l = 0; l < a->lanes.size(); ++l) {
+            bx_prover* p = nullptr;
+            std::string err;
+            if (a->hip_prover_for(l, po2, &p, &err)) return fail("bx_agent_prewarm: lane " + std::to_string(l) + ": " + err);
+        }
+        return nullptr;
+    } catch (const std::exception& e) {
+        return fail(std::string("bx_agent_prewarm: ") + e.what());
+    }
+}
+
 const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* tasks_done) {
     if (!a) return "bx_agent_poll_work: NULL agent";
     std::atomic<uint64_t> done{0};

@@ -241,6 +241,11 @@ typedef struct bx_agent bx_agent;
 const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* store, const bx_taskdb_ops* taskdb,
                             const bx_segment_prover_ops* prover /* NULL = HIP */, bx_agent** out);
 const char* bx_agent_destroy(bx_agent* a);
+/* Create, on EVERY lane, the buffer set (and the verifier-context entry) for segments of 2^po2 cycles now instead of at the lane's
+ * first such task: a deployment that knows its segment size (`--segment-po2`, lib.rs:61-63) and its join size pays the allocations and
+ * the control-ID computation at start-up, like Agent::new creates its prover up front (lib.rs:241-252).  HIP prover only (an injected
+ * prover has nothing to create: returns NULL). */
+const char* bx_agent_prewarm(bx_agent* a, uint32_t po2);
 /* Agent::poll_work: runs the lanes until bx_agent_stop, or until every lane has seen `max_idle_polls` consecutive empty
  * claims (max_idle_polls < 0 = run until stopped).  Blocks.  Task failures are reported to the task db and never end
  * the loop; a failing task-db call does (the reference `?`-returns there: WF-107, WF-109..112, WF-133). */

@@ -42,14 +42,20 @@ def oracle_chain(n, seg_po2, join_po2, widths, seed_of):
     return root, seals
 
 
-@pytest.mark.parametrize("n,lanes", [(16, 3), (5, 2)])
-def test_planned_job_on_the_gpu_equals_the_oracle_chain(n, lanes):
+@pytest.mark.parametrize("n,lanes,devices", [(16, 3, None), (5, 2, None), (11, 2, [0, 0])])
+def test_planned_job_on_the_gpu_equals_the_oracle_chain(n, lanes, devices):
+    """devices = [0, 0]: one agent over two device slots (both on the one GPU of the test box) = the `--gpus N` form of bench.py --job:
+    the lanes of every device claim proves and joins from the one task db."""
     from boundless_amd import agent as ag
     from boundless_amd.prover import Segment
 
     widths, seg_po2, join_po2 = (4, 8, 4), 12, 10
-    a = ag.Agent(prover=None, device=0, inflight=lanes, widths=widths, poll_time=0.002, join_po2=join_po2, also_streams="aux")
+    a = ag.Agent(prover=None, device=0, devices=devices, inflight=lanes, widths=widths, poll_time=0.002, join_po2=join_po2, also_streams="aux")
     try:
+        a.prewarm(seg_po2)  # buffer sets (and verifier-context entries) created up front on every lane
+        a.prewarm(join_po2)
+        with pytest.raises(Exception, match="outside the sizes this agent accepts"):
+            a.prewarm(8)
         segs = [Segment.synthetic(i, po2=seg_po2) for i in range(n)]
         for s in segs:
             a.store.set_key_with_expiry(f"job:G:segments:{s.index}", ag.serialize_segment(s), 600)
@@ -65,7 +71,7 @@ def test_planned_job_on_the_gpu_equals_the_oracle_chain(n, lanes):
         text = a.metrics_text()
         assert f'task_operations_total{{task_name="join",operation_type="join_receipts",status="success"}} {n - 1}' in text
         per_lane = [d for _, d in a.lane_stats()]
-        assert sum(per_lane) == len(ids)
+        assert sum(per_lane) == len(ids) and len(per_lane) == lanes * (len(devices) if devices else 1)
     finally:
         a.close()
 
