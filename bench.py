@@ -289,6 +289,9 @@ def job_main(args, widths):
         a.prewarm(args.join_po2)  # as a deployment that knows its --segment-po2 does at start-up
         submit("warm", 2 * lanes * n)
         a.poll_work(max_idle_polls=2)
+        base = {}
+        for d, cnt in a.lane_stats():
+            base[d] = base.get(d, 0) + cnt
         ids = submit("timed", K)
         t0 = time.perf_counter()
         done = a.poll_work(max_idle_polls=2)
@@ -301,7 +304,7 @@ def job_main(args, widths):
         t_first = min(r.started_s for r in proves)
         t_proves = max(r.updated_s for r in proves)
         t_end = rows["finalize"].updated_s
-        per_dev = {}
+        per_dev = {d: -c0 for d, c0 in base.items()}
         for d, cnt in a.lane_stats():
             per_dev[d] = per_dev.get(d, 0) + cnt
         out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": K / (t_proves - t_first), "unit": "segment-proofs/s", "n_gpus": n,
