@@ -262,8 +262,8 @@ def job_main(args, widths):
     synthetic 2^--join-po2 proof seeded by the hash of the two children's seals; the recursion circuit is not available offline), so
     the line is labelled `"join": "synthetic stand-in"`: what it measures is the scheduling shape — how long the K proves keep N
     GPUs busy, and how long the join tail, which cannot, takes."""
-    if int(os.environ.get("RANK", "0")) != 0:
-        return
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return job_dist_main(args, widths)
     import torch
 
     if not torch.cuda.is_available():
@@ -304,6 +304,12 @@ def job_main(args, widths):
         t_first = min(r.started_s for r in proves)
         t_proves = max(r.updated_s for r in proves)
         t_end = rows["finalize"].updated_s
+        if args.dump:
+            import numpy as np
+
+            rollup = ag.deserialize_receipt(a.store.get("receipts/stark/timed.synthetic"))
+            os.makedirs(args.dump, exist_ok=True)
+            np.savez(os.path.join(args.dump, "rollup.npz"), seal=rollup.seal, po2=rollup.po2)
         per_dev = {d: -c0 for d, c0 in base.items()}
         for d, cnt in a.lane_stats():
             per_dev[d] = per_dev.get(d, 0) + cnt
@@ -327,6 +333,64 @@ def job_main(args, widths):
         print(json.dumps(out))
     finally:
         a.close()
+
+
+def job_dist_main(args, widths):
+    """`--job K` under torchrun: ONE PROCESS PER GPU.  Rank r proves its K/N segments and joins them to one subtree root on its own GPU;
+    the N roots — a receipt each, the only bytes that cross GPUs — are all-gathered (RCCL over xGMI under nccl) and rank 0 joins them,
+    resolves and finalizes (boundless_amd/dist.py: distributed_job).  north_star: "RCCL over xGMI only for the final recursion join"."""
+    import torch
+
+    from boundless_amd import agent as ag
+    from boundless_amd.dist import distributed_job, gather_over_ranks, init_distributed, max_over_ranks
+    from boundless_amd.prover import Segment
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
+    rank, world, local_rank, dist = init_distributed(args.dist_backend)
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
+    lanes = max(1, args.inflight)
+    a = ag.Agent(prover=None, device=device, inflight=lanes, widths=widths, poll_time=0.001, verify=True, terms=args.terms, degree=args.degree,
+                 join_po2=args.join_po2, also_streams="aux", max_shapes=2)
+    try:
+        a.prewarm(args.po2)
+        a.prewarm(args.join_po2)
+        distributed_job(a, 2 * lanes * world, lambda i: Segment.synthetic(10**6 + i, po2=args.po2), rank=rank, world=world, dist=dist, job="warm")
+        res = distributed_job(a, args.job, lambda i: Segment.synthetic(i, po2=args.po2), rank=rank, world=world, dist=dist, job="timed")
+        rows = gather_over_ranks([rank, device, res["segments"], res["sub_job_s"], res["prove_phase_s"], res["gather_s"], res["end_to_end_s"]], dist)
+        prove_phase = max(r[4] for r in rows)
+        if rank == 0:
+            rollup = res["rollup"]
+            rollup.verify_integrity()
+            if args.dump:
+                import numpy as np
+
+                os.makedirs(args.dump, exist_ok=True)
+                np.savez(os.path.join(args.dump, "rollup.npz"), seal=rollup.seal, po2=rollup.po2)
+            out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": args.job / prove_phase, "unit": "segment-proofs/s", "n_gpus": world,
+                   "steps": 1, "warmup": 1, "ms_per_step": 1e3 * max(r[6] for r in rows), "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic", "join": "synthetic stand-in",
+                   "config": {"workload": f"one job of {args.job} 2^{args.po2}-cycle synthetic segments sharded over {world} one-GPU agents (one process per GPU): "
+                                          f"every rank proves {args.job // world} segments and joins them to one subtree root (stand-in joins, 2^{args.join_po2} cycles), "
+                                          f"the {world} roots are all-gathered, rank 0 joins them, resolves and finalizes; every seal CPU-verified; "
+                                          f"trace widths {'/'.join(map(str, widths))}",
+                              "po2": args.po2, "join_po2": args.join_po2, "segments_proved": args.job, "segments_in_flight_per_gpu": lanes,
+                              "parallelism": f"{world} processes x {lanes} lanes; ONE collective: all_gather of {world} root receipts "
+                                             f"({res['root_receipt_bytes']} bytes each) over torch.distributed/{dist.get_backend()}"},
+                   "collective": {"op": "all_gather", "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "bytes_per_rank": res["root_receipt_bytes"], "seconds_max_over_ranks": round(max(r[5] for r in rows), 5),
+                                  "note": "includes the wait for the slowest rank's subtree"},
+                   "job": {"end_to_end_s": round(max(r[6] for r in rows), 4), "prove_phase_s_max_over_ranks": round(prove_phase, 4),
+                           "sub_job_s_max_over_ranks": round(max(r[3] for r in rows), 4), "top_of_tree_s": round(res["top_s"], 4),
+                           "top_joins": res["top_joins"], "segments_per_s_end_to_end": round(args.job / max(r[6] for r in rows), 3),
+                           "rollup_seal_words": int(rollup.seal.size)},
+                   "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "segments": int(r[2]), "sub_job_s": round(r[3], 4),
+                                 "prove_phase_s": round(r[4], 4)} for r in rows]}
+            print(json.dumps(out))
+    finally:
+        a.close()
+        dist.destroy_process_group()
 
 
 def _prove_ids(k):

@@ -66,7 +66,7 @@ class _JobInfo(C.Structure):
 
 class _JobPlan(C.Structure):
     _fields_ = [("prove_stream", C.c_char * 64), ("join_stream", C.c_char * 64), ("aux_stream", C.c_char * 64), ("prove_retries", C.c_int32),
-                ("join_retries", C.c_int32), ("resolve_retries", C.c_int32), ("finalize_retries", C.c_int32)]
+                ("join_retries", C.c_int32), ("resolve_retries", C.c_int32), ("finalize_retries", C.c_int32), ("subtree_only", C.c_int32)]
 
 
 class _AgentConfig(C.Structure):
@@ -92,7 +92,7 @@ def _lib():
         "bx_mem_taskdb_task_info": ([vp, cp, cp, C.POINTER(_TaskInfo)], cp), "bx_mem_taskdb_count": ([vp, C.c_int32], sz),
         "bx_mem_taskdb_create_task_with_prereqs": ([vp, cp, cp, cp, cp, C.POINTER(cp), sz, C.c_int32], cp),
         "bx_mem_taskdb_job_info": ([vp, cp, C.POINTER(_JobInfo)], cp),
-        "bx_plan_job": ([vp, cp, C.c_uint64, C.POINTER(_JobPlan), C.POINTER(C.c_uint64)], cp),
+        "bx_plan_job": ([vp, cp, C.c_uint64, C.POINTER(_JobPlan), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], cp),
         "bx_join_seed": ([vp, sz, vp, sz], C.c_uint64),
         "bx_segment_encode": ([C.c_uint64, C.c_uint32, C.c_uint64, vp], None),
         "bx_segment_decode": ([vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)], cp),
@@ -232,15 +232,22 @@ class TaskDb:
                                                                 d.encode(), arr, len(pre), max_retries))
         self._ids.append((str(job_id), str(task_id)))
 
-    def plan_job(self, job_id, n_segments, prove_stream="", join_stream="", aux_stream="", retries=3):
+    def plan_job(self, job_id, n_segments, prove_stream="", join_stream="", aux_stream="", retries=3, subtree_only=False):
         """bx_plan_job: the executor's planner loop (executor.rs:566-698) — one task row per planner task, prerequisites as the
-        planner's dependencies.  Returns the task ids created, in creation order."""
-        plan = _JobPlan(prove_stream.encode(), join_stream.encode(), aux_stream.encode(), retries, retries, retries, retries)
-        n = C.c_uint64()
-        _check(self._lib.bx_plan_job(self._h, str(job_id).encode(), n_segments, C.byref(plan), C.byref(n)))
-        ids = [str(i) for i in range(n.value - 2)] + ["resolve", "finalize"]
+        planner's dependencies.  Returns the task ids created, in creation order; `self.root_task` = the task whose receipt is the
+        job's root.  subtree_only: stop at the root join (no resolve / finalize): one GPU's share of a larger job."""
+        plan = _JobPlan(prove_stream.encode(), join_stream.encode(), aux_stream.encode(), retries, retries, retries, retries, int(subtree_only))
+        n, root = C.c_uint64(), C.c_uint64()
+        _check(self._lib.bx_plan_job(self._h, str(job_id).encode(), n_segments, C.byref(plan), C.byref(n), C.byref(root)))
+        self.root_task = root.value
+        ids = [str(i) for i in range(n.value)] if subtree_only else [str(i) for i in range(n.value - 2)] + ["resolve", "finalize"]
         self._ids += [(str(job_id), t) for t in ids]
         return ids
+
+    def update_task_done(self, job_id, task_id, output="null"):
+        """taskdb::update_task_done (1_taskdb.sql:278-314): marks the task done and releases what waited on it."""
+        fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t)(self.ops.update_task_done)
+        return fn(self.ops.user, str(job_id).encode(), str(task_id).encode(), output.encode(), None, 0) == 1
 
     def job(self, job_id):
         info = _JobInfo()

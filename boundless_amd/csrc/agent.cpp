@@ -1257,7 +1257,8 @@ const char* bx_mem_taskdb_job_info(bx_mem_taskdb* t, const char* job, bx_job_inf
 }
 
 // The executor's writer task (executor.rs:566-698) + process_task (:56-250) for a job whose segments are already in the hot store.
-const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, const bx_job_plan* plan_in, uint64_t* tasks_created) {
+const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, const bx_job_plan* plan_in, uint64_t* tasks_created,
+                        uint64_t* root_task) {
     if (!t || !job) return "bx_plan_job: NULL argument";
     if (n_segments == 0) return "bx_plan_job: a job has at least one segment";
     bx_planner* pl = nullptr;
@@ -1292,6 +1293,8 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
                     break;
                 }
                 case BX_PLAN_FINALIZE: {
+                    if (root_task) *root_task = tt.depends_on[0];
+                    if (plan.subtree_only) break;  // the root receipt is handed to whoever joins the subtrees
                     const std::string m = std::to_string(tt.depends_on[0]);
                     const char* pre[1] = {m.c_str()};
                     e = bx_mem_taskdb_create_task_with_prereqs(t, join_stream.c_str(), job, "resolve",

@@ -157,9 +157,13 @@ typedef struct bx_job_plan {
     char join_stream[64];  /* "" = prove_stream */
     char aux_stream[64];   /* "" = "aux" */
     int32_t prove_retries, join_retries, resolve_retries, finalize_retries; /* the reference's defaults are 3 */
+    int32_t subtree_only; /* 1 = stop at the root join: no resolve / finalize tasks.  The job is one GPU's share of a larger job whose
+                           * top levels another agent joins from the subtree roots (one process per GPU: the roots cross GPUs, the
+                           * segments never do) */
 } bx_job_plan;
+/* root_task (may be NULL) receives the task number whose receipt is the job's root: the last join, or task 0 for a single segment. */
 const char* bx_plan_job(bx_mem_taskdb* t, const char* job_id, uint64_t n_segments, const bx_job_plan* plan /* NULL = defaults */,
-                        uint64_t* tasks_created);
+                        uint64_t* tasks_created, uint64_t* root_task);
 
 /* ---------------------------------------------------------------------------------- segment / receipt wire ---- */
 /* The reference moves bincode(risc0_zkvm::Segment) in and bincode(receipt) out (tasks/mod.rs:40-47); both need risc0's type

@@ -69,11 +69,12 @@ static int planned_job_phase(void) {
     memset(&plan, 0, sizeof plan);
     plan.prove_retries = plan.join_retries = plan.resolve_retries = plan.finalize_retries = 50;  // the injected failures never exhaust them
     uint64_t created = 0;
-    if (const char* e = bx_plan_job(db, "dag", K, &plan, &created)) {
+    uint64_t root = 0;
+    if (const char* e = bx_plan_job(db, "dag", K, &plan, &created, &root)) {
         fprintf(stderr, "plan: %s\n", e);
         return 1;
     }
-    if (created != (uint64_t)(2 * K - 1 + 2)) return 1;
+    if (created != (uint64_t)(2 * K - 1 + 2) || root != (uint64_t)(2 * K - 2)) return 1;
     bx_agent_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.inflight = 2;

@@ -98,3 +98,74 @@ def test_single_process_queue():
     from boundless_amd.dist import gather_over_ranks
 
     assert gather_over_ranks([0, 3, 60, 2.5]) == [[0.0, 3.0, 60.0, 2.5]]
+
+
+JOB_WORKER = """
+import json, os
+import numpy as np
+from boundless_amd import agent as ag
+from boundless_amd.dist import init_distributed, distributed_job
+from boundless_amd.prover import Segment, SegmentReceipt
+
+def fake_seal(po2, seed):
+    return (np.arange(16, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(seed & 0xFFFFFFFF) + np.uint32(po2)).astype(np.uint32)
+
+class FakeProver:
+    def prove_segment(self, seg):
+        return SegmentReceipt(seal=fake_seal(seg.po2, seg.seed), index=seg.index, po2=seg.po2)
+
+rank, world, local_rank, dist = init_distributed(backend="gloo")
+a = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.002, inflight=2, join_po2=11, also_streams="aux")
+res = distributed_job(a, 8, lambda i: Segment.synthetic(i, po2=13), rank=rank, world=world, dist=dist)
+out = {k: v for k, v in res.items() if k != "rollup"}
+if rank == 0:
+    out["rollup_seal"] = res["rollup"].seal.tolist()
+    out["rollup_po2"] = res["rollup"].po2
+    out["keys_left"] = sorted(a.store.keys())
+else:
+    out["keys_left"] = sorted(a.store.keys())
+a.close()
+json.dump(out, open(os.path.join(os.environ["BX_TEST_OUT"], f"rank{rank}.json"), "w"))
+dist.destroy_process_group()
+"""
+
+
+def test_a_job_sharded_over_two_ranks_joins_its_subtree_roots_after_one_all_gather():
+    """north_star's only collective: segments shard over the ranks (one process per GPU), every rank joins its own subtree, the
+    subtree ROOTS are all-gathered (gloo here, RCCL on GPUs) and rank 0 joins them, resolves and finalizes.  With power-of-two shares
+    the tree is the single-process planner's, so the rollup seal is the same chain of stand-in joins."""
+    import numpy as np
+
+    from boundless_amd import agent as ag
+    from boundless_amd.planner import Planner
+
+    def fake_seal(po2, seed):
+        return (np.arange(16, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(seed & 0xFFFFFFFF) + np.uint32(po2)).astype(np.uint32)
+
+    res = run_world(JOB_WORKER, world=2)
+    by_rank = {r["rank"]: r for r in res}
+    assert by_rank[0]["segments"] == by_rank[1]["segments"] == 4 and by_rank[0]["tasks"] == 7  # 4 proves + 3 joins per rank, no finalize
+    assert by_rank[0]["top_joins"] == 1 and by_rank[0]["top_tasks"] == 3  # the top join, resolve, finalize (the two leaves were handed over done)
+    # the chain of the single-process plan over the same 8 segments
+    p, seals, root = Planner(), {}, None
+    base = 0xB0D1E550000
+    for i in range(8):
+        p.enqueue_segment()
+    p.finish()
+    leaf = 0
+    for k in range(p.task_count()):
+        t = p.get_task(k)
+        if t.command == "Segment":
+            seals[t.task_number] = fake_seal(13, base + leaf)
+            leaf += 1
+    for k in range(p.task_count()):
+        t = p.get_task(k)
+        if t.command == "Join":
+            seals[t.task_number] = fake_seal(11, ag.join_seed(seals[t.depends_on[0]], seals[t.depends_on[1]]))
+        elif t.command == "Finalize":
+            root = t.depends_on[0]
+    assert by_rank[0]["rollup_seal"] == seals[root].tolist() and by_rank[0]["rollup_po2"] == 11
+    # what each rank's store is left with: its own subtree root; rank 0 also the top job's root and the rollup
+    assert by_rank[1]["keys_left"] == ["job:dj-r1:synthetic_receipts:6"]
+    assert sorted(by_rank[0]["keys_left"]) == sorted(["job:dj-r0:synthetic_receipts:6", "job:dj-top:synthetic_receipts:2", "receipts/stark/dj-top.synthetic"])
+    assert by_rank[0]["root_receipt_bytes"] == 4 * (3 + 16)

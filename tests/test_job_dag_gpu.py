@@ -102,3 +102,47 @@ def test_a_tampered_child_receipt_fails_the_join_at_verification():
         assert a.store.keys() == ["job:T:synthetic_receipts:3"]
     finally:
         a.close()
+
+
+def _bench_job(extra, dump, ranks=None, timeout=900):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(root, "bench.py"), "--po2", "12", "--widths", "4,8,4", "--join-po2", "10", "--inflight", "2", "--dump", dump] + extra
+    if ranks:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + base
+    else:
+        cmd = [sys.executable] + base
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    return out, np.load(os.path.join(dump, "rollup.npz"))["seal"]
+
+
+def test_bench_job_one_process_and_process_per_gpu_give_the_oracles_rollup(tmp_path):
+    """`bench.py --job 8` three ways on the one GPU of the test box: one process (the native agent over its lanes); two ranks under
+    torchrun (gloo, both on device 0) = one process per GPU, every rank joining its own subtree, ONE all_gather of the two subtree
+    roots, rank 0 joining them; and one forced rank under the default backend (nccl = RCCL: two ranks cannot share a GPU under it),
+    which runs the same all_gather on the device.  8 and 2 are powers of two, so all three build the planner's tree: the same rollup
+    seal, equal to the oracle's chain of 15 proofs."""
+    from boundless_amd.prover import Segment
+
+    root, seals = oracle_chain(8, 12, 10, (4, 8, 4), lambda i: Segment.synthetic(i, po2=12).seed)
+    one, seal_one = _bench_job(["--job", "8"], str(tmp_path / "one"))
+    assert one["join"] == "synthetic stand-in" and one["job"]["tasks"] == 17 and one["job"]["joins"] == 7
+    assert np.array_equal(seal_one, seals[root])
+    two, seal_two = _bench_job(["--job", "8", "--gpus", "2", "--dist-backend", "gloo", "--device", "0"], str(tmp_path / "two"), ranks=2)
+    assert two["n_gpus"] == 2 and two["join"] == "synthetic stand-in" and two["collective"]["op"] == "all_gather"
+    assert two["collective"]["world_size"] == 2 and two["job"]["top_joins"] == 1
+    assert [r["segments"] for r in two["per_rank"]] == [4, 4] and [r["rank"] for r in two["per_rank"]] == [0, 1]
+    assert np.array_equal(seal_two, seals[root])
