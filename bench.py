@@ -262,7 +262,7 @@ def job_main(args, widths):
     synthetic 2^--join-po2 proof seeded by the hash of the two children's seals; the recursion circuit is not available offline), so
     the line is labelled `"join": "synthetic stand-in"`: what it measures is the scheduling shape — how long the K proves keep N
     GPUs busy, and how long the join tail, which cannot, takes."""
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.force_dist and "MASTER_PORT" in os.environ):
         return job_dist_main(args, widths)
     import torch
 
@@ -347,7 +347,7 @@ def job_dist_main(args, widths):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP HAL has no CPU fallback")
-    rank, world, local_rank, dist = init_distributed(args.dist_backend)
+    rank, world, local_rank, dist = init_distributed(args.dist_backend, force=args.force_dist)
     device = local_rank if args.device is None else args.device
     torch.cuda.set_device(device)
     lanes = max(1, args.inflight)

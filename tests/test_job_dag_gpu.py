@@ -146,3 +146,6 @@ def test_bench_job_one_process_and_process_per_gpu_give_the_oracles_rollup(tmp_p
     assert two["collective"]["world_size"] == 2 and two["job"]["top_joins"] == 1
     assert [r["segments"] for r in two["per_rank"]] == [4, 4] and [r["rank"] for r in two["per_rank"]] == [0, 1]
     assert np.array_equal(seal_two, seals[root])
+    rccl, seal_rccl = _bench_job(["--job", "8", "--gpus", "1", "--force-dist"], str(tmp_path / "rccl"), ranks=1)
+    assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["world_size"] == 1 and rccl["job"]["top_joins"] == 0
+    assert np.array_equal(seal_rccl, seals[root])
