@@ -35,6 +35,8 @@ head -2 "$(find $O/ktm -name '*memory_copy_trace.csv' | head -1)" > $O/r04_memor
 rm -rf $O/ktm
 # 5. one planned job of 64 segments: proves -> stand-in joins -> resolve -> finalize
 for l in 3 1; do python bench.py --job 64 --inflight $l 2>/dev/null | tail -1; done > $O/r04_job64.jsonl
+#    ... and the same job as two processes (gloo: two ranks cannot share a GPU under RCCL) sharing the one GPU: subtree per rank, one all_gather
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29641 bench.py --job 64 --gpus 2 --dist-backend gloo --device 0 2>/dev/null | grep '^{' | tail -1 > $O/r04_job64_2ranks_1gpu.json
 # 6. the helper entry points alone
 python tools/helperbench.py > $O/r04_helperbench.jsonl
 head -14 $O/r04_bench_kernel_stats_default_cmd.csv | cut -c1-150
