@@ -24,7 +24,9 @@ Other modes (never the default line): `--segment-bytes N [--two-deep]` makes eve
 payload) that are copied into a pinned staging slot and uploaded on the prover's copy stream inside the timed region (the
 reference's 2^20-cycle segment is ~80 MB, executor.rs:45; `--two-deep` = a feeder thread per lane submits segment k+1 while segment
 k is proved); `--job K` proves ONE planned job of K segments through the native agent — K Prove tasks, the log-depth tail of Join
-tasks (labelled synthetic stand-ins), resolve, finalize — and reports prove-phase rate, join-tail latency and end-to-end seconds;
+tasks (labelled synthetic stand-ins), resolve, finalize — and reports prove-phase rate, join-tail latency and end-to-end seconds
+(under torchrun: one process per GPU, every rank joins its own subtree, ONE all_gather of the subtree roots — RCCL under nccl — and
+rank 0 joins them: the job's only collective);
 `--native-agent` = the one-process multi-GPU design.
 
 The JSON line also carries
