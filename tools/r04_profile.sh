@@ -4,8 +4,6 @@ set -u
 O=gpurun_out/r4p; mkdir -p $O
 export TMPDIR=/tmp
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra"
-# 0. the bench line of the driver's command
-python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/r04_bench_steps20_warmup5.json
 # 1. per-kernel time: the default command (3 segments in flight) and one segment in flight
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -o kt -- $B --no-live-profile > $O/bench_kt3.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -o kt -- $B --inflight 1 --no-live-profile > $O/bench_kt1.json 2>/dev/null
@@ -39,5 +37,9 @@ for l in 3 1; do python bench.py --job 64 --inflight $l 2>/dev/null | tail -1; d
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29641 bench.py --job 64 --gpus 2 --dist-backend gloo --device 0 2>/dev/null | grep '^{' | tail -1 > $O/r04_job64_2ranks_1gpu.json
 # 6. the helper entry points alone
 python tools/helperbench.py > $O/r04_helperbench.jsonl
+# 7. LAST: the bench line of the driver's command, replaying the PMC summaries just collected (so that its `profile_stale` is about the
+#    sources, not about the order of this script)
+cp $O/r04_bench_pmc_traffic.json $O/r04_job_valu_insts.json profiles/
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/r04_bench_steps20_warmup5.json
 head -14 $O/r04_bench_kernel_stats_default_cmd.csv | cut -c1-150
 cat $O/r04_segment_bytes.jsonl
