@@ -99,8 +99,54 @@ def main():
     dump("fri_vectors.json", {
         "fp4": {"x": x, "y": y, "xy": npo.f4_mul(x, y), "x_inv": npo.f4_inv(x)},
         "fold": {"coeffs_natural": f, "mix": mix, "out_natural": npo.fri_fold(f, mix)}})
+    control_ids()
     print("golden fixtures written to", HERE)
 
 
+def _splitmix64(x):
+    m = (1 << 64) - 1
+    z = (x + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def control_ids():
+    """Control IDs of the synthetic circuit (include/bx_prover.h, "code"; include/bx_circuit.h) from the DEFINITION: the code columns
+    as Montgomery words, the interpolating polynomial of each (O(n^2) sums), its values on the coset 3<w_4N> (Horner per point), the
+    row sponge and the tree — big-int Python only (oracle/np_oracle.py).  A fifth implementation next to the HIP prover, the C oracle,
+    the library's host path and the generated table; small shapes only (a case costs minutes here)."""
+    code_seed = 0x434F4E54524F4C21  # "CONTROL!"
+    r_mont = (1 << 32) % P
+
+    def word(col, row):  # the Montgomery WORD of a code cell; the field element it stands for is word * R^-1
+        v = _splitmix64(code_seed ^ ((col << 32) | row)) >> 33
+        return v - P if v >= P else v
+
+    cases = []
+    for po2, wc in ((9, 1), (9, 3), (10, 2)):
+        n = 1 << po2
+        act = n - min(1994, n // 4)
+        rows = [[] for _ in range(4 * n)]
+        for c in range(wc):
+            if c == 0:
+                col_words = [r_mont if r == 0 else 0 for r in range(n)]
+            elif c == 1:
+                col_words = [r_mont if r == act - 1 else 0 for r in range(n)]
+            else:
+                col_words = [word(c, r) for r in range(n)]
+            evals = [npo.from_mont(w) for w in col_words]          # canonical field elements
+            ev4 = npo.expand_evaluate(npo.zk_shift(npo.interpolate(evals)), 2)
+            for r in range(4 * n):
+                rows[r].append(ev4[r])
+        root = npo.merkle_root([npo.hash_elems(row) for row in rows])
+        cases.append({"po2": po2, "w_code": wc, "control_id": root})  # canonical digest elements
+        print("control id", po2, wc, root, flush=True)
+    dump("control_ids.json", {"what": "Merkle root of the committed code group of the synthetic circuit, canonical elements", "cases": cases})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "control_ids":
+        control_ids()
+    else:
+        main()

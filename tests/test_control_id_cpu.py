@@ -76,6 +76,20 @@ def test_host_control_id_equals_the_oracles(po2, w_code):
     assert np.array_equal(synthetic_control_id_host(po2, w_code), ol.control_id(po2, w_code))
 
 
+def test_definition_level_golden_control_ids(golden_dir):
+    """tests/golden/control_ids.json: the IDs from the mathematical definition in big-int Python (tests/golden/make_golden.py
+    control_ids: O(n^2) interpolation, Horner evaluation on the coset, the sponge, the tree — oracle/np_oracle.py).  The C oracle's
+    commit_group and the library's host path reproduce them; the HIP prover does in tests/test_control_id_gpu.py."""
+    import json
+
+    cases = json.load(open(os.path.join(golden_dir, "control_ids.json")))["cases"]
+    assert len(cases) >= 3
+    for c in cases:
+        want = ol.encode(c["control_id"])
+        assert np.array_equal(ol.control_id(c["po2"], c["w_code"]), want), c
+        assert np.array_equal(synthetic_control_id_host(c["po2"], c["w_code"]), want), c
+
+
 def test_the_generated_table_equals_the_oracle_and_the_host_path():
     """control_ids_w16.inc (tools/gen_control_ids.py) for w_code = 16: every entry up to po2 16 against the oracle here (po2 20
     on the GPU box, tests/test_control_id_gpu.py), po2 9..14 also against a fresh host computation."""

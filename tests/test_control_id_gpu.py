@@ -49,6 +49,18 @@ def test_device_control_id_equals_the_oracles(hal, po2, widths):
         srv.close()
 
 
+def test_device_control_ids_equal_the_definition_level_golden(hal, golden_dir):
+    import json
+    import os
+
+    for c in json.load(open(os.path.join(golden_dir, "control_ids.json")))["cases"]:
+        srv = _server(hal, c["po2"], (c["w_code"], 2, 4))
+        try:
+            assert np.array_equal(srv.control_id(), ol.encode(c["control_id"])), c
+        finally:
+            srv.close()
+
+
 def test_device_control_ids_equal_the_generated_table_up_to_the_largest_segment(hal):
     """w_code = 16, po2 9..24: the table bx_verify_segment consults (csrc/control_ids_w16.inc, generated on the host) against the
     device, entry by entry.  The other groups are one column wide here: the control ID depends on (po2, w_code) only."""
