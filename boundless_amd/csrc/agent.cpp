@@ -1261,6 +1261,7 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
                         uint64_t* root_task) {
     if (!t || !job) return "bx_plan_job: NULL argument";
     if (n_segments == 0) return "bx_plan_job: a job has at least one segment";
+    if (n_segments > ((uint64_t)1 << 20)) return "bx_plan_job: more than 2^20 segments in one job";  // 2^40 cycles at po2 20: a typo, not a job
     bx_planner* pl = nullptr;
     try {
         bx_job_plan plan;

@@ -7,8 +7,9 @@ table one level up is contracts/src/blake3-groth16/ControlID.sol:13.  VERDICT r0
 constraint for any claimed g_1.  profiles/r04_soundness_at_head_872f07d.log records both forgeries being ACCEPTED by the
 verifier of round 3; here they must be refused, for the right reason.
 
-Three independent computations of a control ID agree: the oracle's commit_group (recursive NTTs), the library's host path
-(iterative natural-order DFTs, csrc/control_id.cpp) and its generated table; the HIP path joins them in test_control_id_gpu.py.
+Independent computations of a control ID agree: the oracle's commit_group (recursive NTTs), big-int Python from the definition
+(tests/golden/control_ids.json), the library's host path (iterative natural-order DFTs, csrc/control_id.cpp) and its generated
+table; the HIP path joins them in test_control_id_gpu.py.
 """
 import os
 import re

@@ -70,6 +70,10 @@ def test_pending_ready_transitions_follow_the_reference_sql():
         db.create_task("j", "f", {"Prove": {"index": 1}}, prerequisites=["nope"])
     with pytest.raises(HalError, match="no such job"):
         db.job("other")
+    with pytest.raises(HalError, match="at least one segment"):
+        db.plan_job("empty", 0)
+    with pytest.raises(HalError, match="2\\^20 segments"):
+        db.plan_job("typo", 1 << 40)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 37])
