@@ -15,6 +15,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -537,7 +538,8 @@ struct Pending {
     bool opaque = false;  // proved through prove_blob: `wire` already holds the receipt bytes to store
     enum Kind { Prove, Join, HostOnly } kind = Prove;  // HostOnly: the whole task ran in the first half (resolve / finalize stand-ins)
     std::vector<std::string> cleanup_keys;  // a join unlinks its children's receipts once its own is stored (join.rs:94-104)
-    std::vector<uint32_t> child_seal[2];    // a join's children: verified in the host half, while the lane already proves its next task
+    std::vector<uint32_t> child_seal[2];    // a join's children ...
+    std::future<std::string> child_check[2];  // ... verified on helper threads WHILE the join is proved; collected in the host half
     std::vector<uint32_t> seal;
     size_t words = 0;
     double prove_s = 0;
@@ -849,9 +851,15 @@ struct bx_agent {
 
     // tasks::join::join (join.rs:18-113) with a STAND-IN for `prover.join(&left, &right)`: one synthetic segment of 2^join_po2
     // cycles seeded by the two children's seals (bx_agent.h, "Stand-ins for the recursion tasks").  First half: fetch, deserialize,
-    // prove.  The reference verifies both children before joining (join.rs:44-49); here that check (15 ms of CPU per child at 2^20)
-    // runs in the second half, on the finisher thread, while the lane's GPU share already works on its next task: the seed needs the
-    // children's bytes, not their validity, and a join whose child does not verify fails with the same code and stores nothing.
+    // prove.  The reference verifies both children before joining (join.rs:44-49); here those two checks (5-15 ms of CPU each) start
+    // on helper threads before the proof is launched and run beside it — the seed needs the children's bytes, not their validity —
+    // and the second half collects their verdicts: a join whose child does not verify fails with the same code and stores nothing.
+    // On the critical path of a job's join tail (log2 K levels, each a join whose parent is released by update_task_done) that
+    // leaves one proof + one verification per level instead of one proof + three verifications.
+    static void drain_children(Pending* p) {
+        for (auto& f : p->child_check)
+            if (f.valid()) (void)f.get();
+    }
     std::string join_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t idx, uint64_t left, uint64_t right, Pending* out) {
         out->start = Clock::now();
         out->task = task;
@@ -878,9 +886,20 @@ struct bx_agent {
         }
         if (out->seal.size() < cap) out->seal.resize(cap);
         out->words = 0;
+        if (!cfg.no_verify) {  // the children's checks run beside the proof; child_seal[] stays untouched until they are collected
+            static const char* const codes[2] = {"[BENTO-JOIN-003] Failed to verify left receipt integrity: ",
+                                                 "[BENTO-JOIN-004] Failed to verify right receipt integrity: "};
+            for (int k = 0; k < 2; ++k)
+                out->child_check[k] = std::async(std::launch::async, [this, out, k]() -> std::string {
+                    const char* ve = verify_seal(out->child_seal[k].data(), out->child_seal[k].size());
+                    return ve ? std::string(codes[k]) + ve : std::string();
+                });
+        }
         if (const char* pe = prover.prove_segment(prover.user, lane_idx, out->po2, wire, sizeof wire, out->seal.data(), cap, &out->words)) {
             metrics.record_task_operation("join", "join_receipts", "error", secs_since(join_start));
-            return pe;
+            std::string msg = pe;
+            drain_children(out);  // the slot is reused by the lane's next task: nothing may still be reading it
+            return msg;
         }
         out->prove_s = secs_since(join_start);
         metrics.record_task_operation("join", "join_receipts", "success", out->prove_s);
@@ -889,11 +908,15 @@ struct bx_agent {
     //   second half: verify the children and the joined receipt, store it, unlink the children
     std::string join_finish(Pending* p) {
         if (!cfg.no_verify) {
-            if (const char* ve = verify_seal(p->child_seal[0].data(), p->child_seal[0].size()))
-                return std::string("[BENTO-JOIN-003] Failed to verify left receipt integrity: ") + ve;
-            if (const char* ve = verify_seal(p->child_seal[1].data(), p->child_seal[1].size()))
-                return std::string("[BENTO-JOIN-004] Failed to verify right receipt integrity: ") + ve;
-            if (const char* ve = verify_seal(p->seal.data(), p->words)) return std::string("[BENTO-JOIN-006] Failed to verify join receipt integrity: ") + ve;
+            // the joined receipt is checked here while the children's checks (started before the proof) finish; both verdicts first,
+            // so that no helper is left running when this slot is handed back
+            std::string own;
+            if (const char* ve = verify_seal(p->seal.data(), p->words)) own = std::string("[BENTO-JOIN-006] Failed to verify join receipt integrity: ") + ve;
+            std::string left = p->child_check[0].valid() ? p->child_check[0].get() : std::string();
+            std::string right = p->child_check[1].valid() ? p->child_check[1].get() : std::string();
+            if (!left.empty()) return left;
+            if (!right.empty()) return right;
+            if (!own.empty()) return own;
         }
         receipt_encode(p->wire, p->seg_index, p->po2, p->seal.data(), p->words);
         std::string e = store_set(p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + std::to_string(p->seg_index), p->wire, cfg.redis_ttl);
@@ -945,6 +968,7 @@ struct bx_agent {
 
     // Agent::process_work (lib.rs:445-530), first half: TaskType dispatch + the device half of the prove task.
     std::string dispatch(uint32_t lane, const bx_ready_task& task, Pending* out) {
+        drain_children(out);  // a slot that was abandoned on an exception may still have helpers reading it
         JVal def;
         std::string bad = std::string("Invalid task_def: ") + task.job_id + ":" + task.task_id;
         if (!parse_json(task.task_def, &def) || def.kind != JVal::Obj || def.obj.size() != 1) return bad;
