@@ -87,10 +87,11 @@ def replayed_profiles():
     from boundless_amd.build import csrc_hash
 
     cur = csrc_hash()
-    return {"csrc_sha": cur, "files": dict(_replayed),
+    return {"csrc_sha": cur, "library_sha": csrc_hash(device_only=False), "files": dict(_replayed),
             "profile_stale": any(v != cur for v in _replayed.values()) if _replayed else False,
             "note": "roofline.traffic, valu_view and roofline_job replay rocprofv3 --pmc passes committed under profiles/ (counters cannot be "
-                    "collected inside a timed run); profile_stale = at least one of them was collected on other kernel sources than the ones that just ran"}
+                    "collected inside a timed run); profile_stale = at least one of them was collected on other DEVICE sources (*.hip, headers, tables) than "
+                    "the ones that just ran; library_sha covers the host-only sources too"}
 
 
 def _valu_per_wave():

@@ -20,20 +20,24 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
 
 
-def csrc_hash():
-    """SHA-256 (first 16 hex digits) over the CODE of the kernel and host sources of the library, in name order: comments are
-    stripped and runs of white space collapsed first, so that editing the prose of a header does not make every committed profile
-    look stale.  Profile summaries under profiles/ are stamped with it by the tools that write them, and bench.py reports
-    `profile_stale` when the library it runs was built from different sources than the ones a replayed PMC figure was collected
-    on.  (A content hash rather than a git tree hash: the GPU box receives a snapshot without .git.)"""
+def csrc_hash(device_only=True):
+    """SHA-256 (first 16 hex digits) over the CODE of the library's sources, in name order: comments are stripped and runs of white
+    space collapsed first, so that editing the prose of a header does not make every committed profile look stale.
+    device_only (the stamp of the profile summaries): the translation units that contain device code (*.hip) and every header and
+    table they can include — what a replayed PMC figure (bytes, VALU instructions per kernel) depends on; the host-only *.cpp files
+    (agent, REST client, planner, verifier, control IDs, ELF loader) cannot change a kernel.  device_only=False: every source of the
+    library = the identity of the binary.  Profile summaries under profiles/ are stamped with the former by the tools that write
+    them, and bench.py reports `profile_stale` when the library it runs was built from different device sources than the ones a
+    replayed figure was collected on.  (A content hash rather than a git tree hash: the GPU box receives a snapshot without .git.)"""
     import hashlib
     import re
 
     strip = re.compile(rb"//[^\n]*|/\*.*?\*/", re.S)
     h = hashlib.sha256()
+    kinds = (".hip", ".hpp", ".h", ".inc") if device_only else (".hip", ".cpp", ".hpp", ".h", ".inc")
     for d in (CSRC, INC):
         for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")):
+            if f.endswith(kinds):
                 h.update(f.encode() + b"\0")
                 h.update(b" ".join(strip.sub(b" ", open(os.path.join(d, f), "rb").read()).split()))
     return h.hexdigest()[:16]
