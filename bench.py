@@ -281,7 +281,8 @@ def job_main(args, widths):
     devices = list(range(n)) if args.device is None else [args.device] * n
     K = args.job
     a = ag.Agent(prover=None, device=devices[0], devices=devices if len(devices) > 1 else None, inflight=lanes, widths=widths, poll_time=0.001,
-                 verify=True, terms=args.terms, degree=args.degree, join_po2=args.join_po2, also_streams="aux", max_shapes=2)
+                 verify=True, terms=args.terms, degree=args.degree, join_po2=args.join_po2, also_streams="aux", max_shapes=2,
+                 lift_po2=args.join_po2 if args.lift else 0)
     try:
         def submit(job, k):
             for i in range(k):
@@ -319,6 +320,7 @@ def job_main(args, widths):
         out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": K / (t_proves - t_first), "unit": "segment-proofs/s", "n_gpus": n,
                "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic", "join": "synthetic stand-in",
+               "lift": ("synthetic stand-in (one more 2^%d-cycle proof per Prove task)" % args.join_po2) if args.lift else "none (the segment's own seal is stored)",
                "config": {"workload": f"one job of {K} 2^{args.po2}-cycle synthetic segments planned by bx_plan_job (executor.rs:566-698): {K} Prove tasks, "
                                       f"{K - 1} stand-in Join tasks (2^{args.join_po2}-cycle synthetic proofs seeded by their children's seals), resolve, finalize; "
                                       f"every seal CPU-verified; trace widths {'/'.join(map(str, widths))}",
@@ -444,6 +446,8 @@ def main():
     ap.add_argument("--job", type=int, default=0, help="prove ONE planned job of this many segments (bx_plan_job: proves -> stand-in joins -> resolve -> finalize) through the "
                     "native agent on --gpus devices; reports prove-phase rate, join-tail latency and end-to-end seconds, labelled \"join\": \"synthetic stand-in\"")
     ap.add_argument("--join-po2", type=int, default=18, help="--job: size of the stand-in join proofs (18 = the reference's recursion proofs)")
+    ap.add_argument("--lift", action="store_true", help="--job: every Prove task also runs the stand-in `lift` leg (prove.rs:60-113): a second synthetic proof of 2^--join-po2 "
+                    "cycles seeded by the segment seal; the joins consume the lifted receipts")
     ap.add_argument("--segment-bytes", type=int, default=0, help="size of every segment's serialized form: the 28-byte stand-in header + a payload that is uploaded "
                     "(pinned staging slot -> copy stream -> HBM) and handed to witgen like a preflight trace; 0 = header only.  The reference's 2^20-cycle segment is ~80 MB (executor.rs:45)")
     ap.add_argument("--two-deep", action="store_true", help="with --segment-bytes: a feeder thread per lane submits segment k+1 (bx_prover_submit_segment) while segment k is proved")

@@ -536,6 +536,7 @@ struct Pending {
     uint64_t seg_index = 0;
     uint32_t po2 = 0;
     bool opaque = false;  // proved through prove_blob: `wire` already holds the receipt bytes to store
+    bool lifted = false;  // `seal` holds the stand-in lift of the segment seal kept in child_seal[0] (cfg.lift_po2)
     enum Kind { Prove, Join, HostOnly } kind = Prove;  // HostOnly: the whole task ran in the first half (resolve / finalize stand-ins)
     std::vector<std::string> cleanup_keys;  // a join unlinks its children's receipts once its own is stored (join.rs:94-104)
     std::vector<uint32_t> child_seal[2];    // a join's children ...
@@ -798,6 +799,36 @@ struct bx_agent {
             return pe;
         out->prove_s = secs_since(prove_start);
         metrics.record_task_operation("prove", "prove_segment", "success", out->prove_s);
+        out->lifted = false;
+        if (cfg.lift_po2) {
+            // the `lift` leg (prove.rs:60-113), as a labelled stand-in: the segment seal is set aside — its verification (BENTO-PROVE-004)
+            // runs on a helper thread beside the second proof, as for a join's children — and a synthetic proof of 2^lift_po2 cycles
+            // seeded by it takes its place
+            out->child_seal[0].assign(out->seal.begin(), out->seal.begin() + (long)out->words);
+            if (!cfg.no_verify)
+                out->child_check[0] = std::async(std::launch::async, [this, out]() -> std::string {
+                    const char* ve = verify_seal(out->child_seal[0].data(), out->child_seal[0].size());
+                    return ve ? std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve : std::string();
+                });
+            uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+            bx_segment_encode(out->seg_index, cfg.lift_po2, bx_join_seed(out->child_seal[0].data(), out->child_seal[0].size(), nullptr, 0), wire);
+            auto lift_start = Clock::now();
+            size_t cap2 = prover.seal_words(prover.user, lane_idx, cfg.lift_po2);
+            std::string err;
+            if (cap2 == 0) err = hip && !hip_err.empty() ? "lift: " + hip_err : "lift: no prover for a stand-in lift of po2 " + std::to_string(cfg.lift_po2);
+            if (err.empty()) {
+                if (out->seal.size() < cap2) out->seal.resize(cap2);
+                out->words = 0;
+                if (const char* pe = prover.prove_segment(prover.user, lane_idx, cfg.lift_po2, wire, sizeof wire, out->seal.data(), cap2, &out->words)) err = pe;
+            }
+            if (!err.empty()) {
+                drain_children(out);
+                return err;
+            }
+            out->po2 = cfg.lift_po2;
+            out->lifted = true;
+            metrics.record_task_operation("prove", "lift", "success", secs_since(lift_start));
+        }
         return "";
     }
     //   second half: verify -> store under the recursion-receipt key -> unlink the segment
@@ -810,8 +841,15 @@ struct bx_agent {
             if (!cfg.no_verify) {  // segment_receipt.verify_integrity_with_context (prove.rs:53-55)
                 // the HIP prover's agent checks the code root against its own context; an injected prover's seals against the
                 // circuit's published IDs (check_code)
-                if (const char* ve = verify_seal(p->seal.data(), p->words))
-                    return std::string("[BENTO-PROVE-004] Failed to verify segment receipt integrity: ") + ve;
+                const char* ve = verify_seal(p->seal.data(), p->words);
+                std::string own = ve ? ve : "";
+                if (p->lifted) {  // the segment seal's verdict first (it was checked beside the lift), then the lifted receipt's
+                    std::string seg = p->child_check[0].valid() ? p->child_check[0].get() : std::string();
+                    if (!seg.empty()) return seg;
+                    if (!own.empty()) return "[BENTO-PROVE-010] Failed to verify lift receipt integrity: " + own;
+                } else if (!own.empty()) {
+                    return "[BENTO-PROVE-004] Failed to verify segment receipt integrity: " + own;
+                }
             }
             // a synthetic seal is not a lifted receipt: it never goes under the key Join workers read
             output_key = p->job_prefix + ":" BX_SYNTHETIC_RECEIPT_PATH ":" + p->task.task_id;
@@ -1463,6 +1501,10 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
             return "bx_agent_create: po2_min / po2_max must satisfy 9 <= po2_min <= po2_max <= 24";
         }
         if (!a->cfg.max_shapes) a->cfg.max_shapes = 2;
+        if (a->cfg.lift_po2 && (a->cfg.lift_po2 < 9 || a->cfg.lift_po2 > 24)) {
+            delete a;
+            return "bx_agent_create: lift_po2 must be 0 or in [9, 24]";
+        }
         if (!a->cfg.join_po2) a->cfg.join_po2 = 18;
         if (a->cfg.join_po2 < 9 || a->cfg.join_po2 > 24) {
             delete a;

@@ -239,6 +239,11 @@ typedef struct bx_agent_config {
                               * the reference's recursion proofs */
     char also_streams[128];  /* comma-separated worker types a lane also claims from when its task_stream is empty, in order
                               * (e.g. "aux" to serve the finalize task of a planned job from the same process); "" = none */
+    uint32_t lift_po2;       /* 0 = a Prove task stores the segment's own seal (default).  N = the task also runs a STAND-IN for the
+                              * `lift` leg of the reference's prove task (prove.rs:60-113: prove_segment -> verify -> lift -> verify ->
+                              * store the lifted receipt): one more synthetic proof of 2^N cycles seeded by bx_join_seed(segment seal),
+                              * and THAT is what is stored under synthetic_receipts:{task} for the joins to consume.  Like the join
+                              * stand-in it is not a recursion proof; it gives a Prove task its real anatomy (two proofs) */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;

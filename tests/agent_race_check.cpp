@@ -83,6 +83,7 @@ static int planned_job_phase(void) {
     cfg.synthetic = 1;
     cfg.poll_time = 0.001;
     cfg.join_po2 = 9;
+    cfg.lift_po2 = 9;  // every Prove task also runs the stand-in lift: the segment seal is verified on a helper thread beside it
     snprintf(cfg.also_streams, sizeof cfg.also_streams, "aux");
     bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};
     bx_agent* agent = nullptr;

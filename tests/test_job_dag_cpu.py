@@ -249,3 +249,41 @@ def test_recursion_tasks_are_refused_outside_synthetic_mode():
     assert a.process_one("R", "5", {"Join": {"idx": 5, "left": 1, "right": 2}}) is False
     assert "task type Join reached a prove-stream agent" in a.taskdb.task("R", "5").error
     a.close()
+
+
+def test_the_lift_leg_of_the_prove_task_as_a_stand_in():
+    """prove.rs:41-113: prove_segment -> verify -> lift -> verify -> store the LIFTED receipt.  With cfg.lift_po2 a Prove task runs a
+    second (stand-in) proof seeded by the segment seal and stores that; the joins consume the lifted receipts."""
+    n, base = 7, 0xB0D1E550000
+    prover = FakeProver(fail_once={(12, 3)})  # the lift of segment 3 fails once: the whole Prove task is retried
+    a = ag.Agent(prover=prover, verify=False, poll_time=0.002, inflight=3, join_po2=11, lift_po2=12, also_streams="aux")
+    try:
+        for i in range(n):
+            a.store.set_key_with_expiry(f"job:L:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=13)), 600)
+        ids = a.taskdb.plan_job("L", n)
+        assert a.poll_work(max_idle_polls=3) == len(ids) and a.taskdb.job("L")["state"] == "done"
+        proves = sorted(c[1] for c in prover.calls if c[0] == 13)
+        lifts = sorted(c[1] for c in prover.calls if c[0] == 12)
+        joins = [c for c in prover.calls if c[0] == 11]
+        assert proves == sorted(list(range(n)) + [3]) and lifts == sorted(list(range(n)) + [3]) and len(joins) == n - 1
+        # the chain over LIFTED leaves
+        p, seals, root, leaf = Planner(), {}, None, 0
+        for _ in range(n):
+            p.enqueue_segment()
+        p.finish()
+        for k in range(p.task_count()):
+            t = p.get_task(k)
+            if t.command == "Segment":
+                seals[t.task_number] = fake_seal(12, ag.join_seed(fake_seal(13, base + leaf), np.zeros(0, np.uint32)))
+                leaf += 1
+        for k in range(p.task_count()):
+            t = p.get_task(k)
+            if t.command == "Join":
+                seals[t.task_number] = fake_seal(11, ag.join_seed(seals[t.depends_on[0]], seals[t.depends_on[1]]))
+            elif t.command == "Finalize":
+                root = t.depends_on[0]
+        rollup = ag.deserialize_receipt(a.store.get("receipts/stark/L.synthetic"))
+        assert np.array_equal(rollup.seal, seals[root])
+        assert f'task_operations_total{{task_name="prove",operation_type="lift",status="success"}} {n}' in a.metrics_text()
+    finally:
+        a.close()

@@ -149,3 +149,42 @@ def test_bench_job_one_process_and_process_per_gpu_give_the_oracles_rollup(tmp_p
     rccl, seal_rccl = _bench_job(["--job", "8", "--gpus", "1", "--force-dist"], str(tmp_path / "rccl"), ranks=1)
     assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["world_size"] == 1 and rccl["job"]["top_joins"] == 0
     assert np.array_equal(seal_rccl, seals[root])
+
+
+def test_prove_tasks_with_the_stand_in_lift_leg_on_the_gpu():
+    """cfg.lift_po2: prove_segment -> (verify beside) lift -> verify -> store the lifted receipt (prove.rs:41-113, the lift a labelled
+    stand-in).  Five segments: the rollup is the oracle's chain over the LIFTED leaves — 5 + 5 + 4 proofs."""
+    from boundless_amd import agent as ag
+    from boundless_amd.planner import Planner
+    from boundless_amd.prover import Segment
+
+    widths, seg_po2, small = (4, 8, 4), 12, 10
+    a = ag.Agent(prover=None, device=0, inflight=2, widths=widths, poll_time=0.002, join_po2=small, lift_po2=small, also_streams="aux")
+    try:
+        n = 5
+        segs = [Segment.synthetic(i, po2=seg_po2) for i in range(n)]
+        for s in segs:
+            a.store.set_key_with_expiry(f"job:LG:segments:{s.index}", ag.serialize_segment(s), 600)
+        ids = a.taskdb.plan_job("LG", n)
+        assert a.poll_work(max_idle_polls=5) == len(ids) and a.taskdb.job("LG")["state"] == "done"
+        p, seals, root, leaf = Planner(), {}, None, 0
+        for _ in range(n):
+            p.enqueue_segment()
+        p.finish()
+        for k in range(p.task_count()):
+            t = p.get_task(k)
+            if t.command == "Segment":
+                seg_seal = ol.prove_segment(seg_po2, *widths, segs[leaf].seed)[0]
+                seals[t.task_number] = ol.prove_segment(small, *widths, ag.join_seed(seg_seal, np.zeros(0, np.uint32)))[0]
+                leaf += 1
+        for k in range(p.task_count()):
+            t = p.get_task(k)
+            if t.command == "Join":
+                seals[t.task_number] = ol.prove_segment(small, *widths, ag.join_seed(seals[t.depends_on[0]], seals[t.depends_on[1]]))[0]
+            elif t.command == "Finalize":
+                root = t.depends_on[0]
+        rollup = ag.deserialize_receipt(a.store.get("receipts/stark/LG.synthetic"))
+        assert np.array_equal(rollup.seal, seals[root])
+        assert f'task_operations_total{{task_name="prove",operation_type="lift",status="success"}} {n}' in a.metrics_text()
+    finally:
+        a.close()
