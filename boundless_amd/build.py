@@ -20,26 +20,49 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
 
 
+def _device_sources():
+    """The *.hip translation units and every local header / table they include, transitively (paths, sorted by name)."""
+    import re
+
+    inc = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    seen, todo = {}, [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")]
+    while todo:
+        path = os.path.normpath(todo.pop())
+        if path in seen or not os.path.isfile(path):
+            continue
+        text = open(path, "r", errors="replace").read()
+        seen[path] = True
+        for name in inc.findall(text):
+            for base in (os.path.dirname(path), INC, CSRC):
+                cand = os.path.normpath(os.path.join(base, name))
+                if os.path.isfile(cand):
+                    todo.append(cand)
+                    break
+    return sorted(seen, key=lambda q: os.path.basename(q))
+
+
 def csrc_hash(device_only=True):
     """SHA-256 (first 16 hex digits) over the CODE of the library's sources, in name order: comments are stripped and runs of white
     space collapsed first, so that editing the prose of a header does not make every committed profile look stale.
-    device_only (the stamp of the profile summaries): the translation units that contain device code (*.hip) and every header and
-    table they can include — what a replayed PMC figure (bytes, VALU instructions per kernel) depends on; the host-only *.cpp files
-    (agent, REST client, planner, verifier, control IDs, ELF loader) cannot change a kernel.  device_only=False: every source of the
-    library = the identity of the binary.  Profile summaries under profiles/ are stamped with the former by the tools that write
-    them, and bench.py reports `profile_stale` when the library it runs was built from different device sources than the ones a
-    replayed figure was collected on.  (A content hash rather than a git tree hash: the GPU box receives a snapshot without .git.)"""
+    device_only (the stamp of the profile summaries): the translation units that contain device code (*.hip) and the headers and
+    tables they include, transitively — what a replayed PMC figure (bytes, VALU instructions per kernel) depends on; the host-only
+    sources (agent, REST client, planner, verifier, control IDs, ELF loader and their headers) cannot change a kernel.
+    device_only=False: every source of the library = the identity of the binary.  Profile summaries under profiles/ are stamped with
+    the former by the tools that write them, and bench.py reports `profile_stale` when the library it runs was built from different
+    device sources than the ones a replayed figure was collected on.  (A content hash rather than a git tree hash: the GPU box
+    receives a snapshot without .git.)"""
     import hashlib
     import re
 
     strip = re.compile(rb"//[^\n]*|/\*.*?\*/", re.S)
     h = hashlib.sha256()
-    kinds = (".hip", ".hpp", ".h", ".inc") if device_only else (".hip", ".cpp", ".hpp", ".h", ".inc")
-    for d in (CSRC, INC):
-        for f in sorted(os.listdir(d)):
-            if f.endswith(kinds):
-                h.update(f.encode() + b"\0")
-                h.update(b" ".join(strip.sub(b" ", open(os.path.join(d, f), "rb").read()).split()))
+    if device_only:
+        paths = _device_sources()
+    else:
+        paths = [os.path.join(d, f) for d in (CSRC, INC) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc"))]
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(b" ".join(strip.sub(b" ", open(path, "rb").read()).split()))
     return h.hexdigest()[:16]
 
 
