@@ -357,7 +357,7 @@ def job_dist_main(args, widths):
     torch.cuda.set_device(device)
     lanes = max(1, args.inflight)
     a = ag.Agent(prover=None, device=device, inflight=lanes, widths=widths, poll_time=0.001, verify=True, terms=args.terms, degree=args.degree,
-                 join_po2=args.join_po2, also_streams="aux", max_shapes=2)
+                 join_po2=args.join_po2, also_streams="aux", max_shapes=2, lift_po2=args.join_po2 if args.lift else 0)
     try:
         a.prewarm(args.po2)
         a.prewarm(args.join_po2)
@@ -376,6 +376,7 @@ def job_dist_main(args, widths):
             out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": args.job / prove_phase, "unit": "segment-proofs/s", "n_gpus": world,
                    "steps": 1, "warmup": 1, "ms_per_step": 1e3 * max(r[6] for r in rows), "higher_is_better": True, "scaling": "strong",
                    "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)", "data": "synthetic", "join": "synthetic stand-in",
+                   "lift": ("synthetic stand-in (one more 2^%d-cycle proof per Prove task)" % args.join_po2) if args.lift else "none (the segment's own seal is stored)",
                    "config": {"workload": f"one job of {args.job} 2^{args.po2}-cycle synthetic segments sharded over {world} one-GPU agents (one process per GPU): "
                                           f"every rank proves {args.job // world} segments and joins them to one subtree root (stand-in joins, 2^{args.join_po2} cycles), "
                                           f"the {world} roots are all-gathered, rank 0 joins them, resolves and finalizes; every seal CPU-verified; "
