@@ -332,6 +332,9 @@ def job_main(args, widths):
                        "join_tail_s": round(t_end - t_proves, 4), "joins": len(joins),
                        "join_levels": max(1, (K - 1).bit_length()), "joins_started_before_last_prove": sum(1 for r in joins if r.started_s < t_proves),
                        "segments_per_s_end_to_end": round(K / (t_end - t_first), 3), "wall_s_including_claims": round(dt, 4),
+                       # the reference's own figure of merit for a job (crates/boundless-cli/src/commands/prover/benchmark.rs:213:
+                       # effective_khz = total_cycles / elapsed_secs / 1000) — of THIS job: synthetic circuit, stand-in recursion proofs
+                       "effective_khz_synthetic": round(K * (1 << args.po2) / (t_end - t_first) / 1000.0, 1),
                        "note": "value = K / prove phase (first claim to last Prove done); join_tail_s = last Prove done to finalize done: the part of "
                                "the job whose parallelism halves at every level and starves N GPUs"},
                "tasks_per_device": {str(d): int(c) for d, c in per_dev.items()}}
@@ -390,6 +393,7 @@ def job_dist_main(args, widths):
                    "job": {"end_to_end_s": round(max(r[6] for r in rows), 4), "prove_phase_s_max_over_ranks": round(prove_phase, 4),
                            "sub_job_s_max_over_ranks": round(max(r[3] for r in rows), 4), "top_of_tree_s": round(res["top_s"], 4),
                            "top_joins": res["top_joins"], "segments_per_s_end_to_end": round(args.job / max(r[6] for r in rows), 3),
+                           "effective_khz_synthetic": round(args.job * (1 << args.po2) / max(r[6] for r in rows) / 1000.0, 1),
                            "rollup_seal_words": int(rollup.seal.size)},
                    "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "segments": int(r[2]), "sub_job_s": round(r[3], 4),
                                  "prove_phase_s": round(r[4], 4)} for r in rows]}
