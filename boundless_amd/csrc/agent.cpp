@@ -729,6 +729,73 @@ struct bx_agent {
         const uint8_t* data() const { return p; }
         size_t size() const { return n; }
     };
+    // A claimed task on its way to the lane, with its segment already fetched when it is a Prove task and cfg.prefetch is on.
+    struct Fetched {
+        bx_ready_task task;
+        int rc = 0;  // request_work: 1 claimed, 0 nothing ready, < 0 error (eb)
+        char eb[256] = {0};
+        Clock::time_point claimed;
+        bool fetched = false;  // a GET of the segment was attempted: blob / blob_err hold its outcome
+        uint64_t index = 0;
+        StoreValue blob;
+        std::string blob_err;
+    };
+    // one-slot mailbox between a lane's fetcher thread and the lane (cfg.prefetch)
+    struct Prefetcher {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::unique_ptr<Fetched> slot;
+        bool quitting = false;
+        void put(std::unique_ptr<Fetched> w) {
+            std::lock_guard<std::mutex> l(mu);
+            slot = std::move(w);
+            cv.notify_all();
+        }
+        bool wait_empty() {  // fetcher side: false = quit
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return !slot || quitting; });
+            return !quitting;
+        }
+        std::unique_ptr<Fetched> take(std::atomic<int>& stop_flag) {  // lane side; nullptr = stop was requested while waiting
+            std::unique_lock<std::mutex> l(mu);
+            while (!slot) {
+                if (stop_flag.load(std::memory_order_relaxed)) return nullptr;
+                // system_clock on purpose: a steady-clock wait is pthread_cond_clockwait, which the ThreadSanitizer of this
+                // toolchain does not intercept (it then reports the re-lock inside the wait as a double lock)
+                cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
+            }
+            auto w = std::move(slot);
+            cv.notify_all();
+            return w;
+        }
+        std::unique_ptr<Fetched> quit() {  // returns what was fetched and never taken (a claimed task must not be lost)
+            std::lock_guard<std::mutex> l(mu);
+            quitting = true;
+            cv.notify_all();
+            return std::move(slot);
+        }
+    };
+    // request_work over the lane's streams (its own first) + the claim metrics (lib.rs:613-623)
+    int claim_once(bx_ready_task* task, char* eb, size_t cap) {
+        int rc = 0;
+        for (const std::string& st : streams) {
+            rc = taskdb.request_work(taskdb.user, st.c_str(), task, eb, cap);
+            metrics.record_task_claim(st.c_str(), rc < 0 ? "error" : rc == 0 ? "empty" : "claimed");
+            if (rc != 0) break;
+        }
+        return rc;
+    }
+    // {"Prove":{"index":n}} -> n
+    static bool prove_index_of(const bx_ready_task& task, uint64_t* index) {
+        JVal def;
+        if (!parse_json(task.task_def, &def) || def.kind != JVal::Obj || def.obj.size() != 1 || def.obj[0].first != "Prove") return false;
+        const JVal& body = def.obj[0].second;
+        const JVal* f = body.kind == JVal::Obj ? body.find("index") : nullptr;
+        if (!f || f->kind != JVal::Num || !f->is_uint) return false;
+        *index = f->u;
+        return true;
+    }
+
     std::string store_get(const std::string& key, StoreValue* out) {
         auto t0 = Clock::now();
         char eb[256] = {0};
@@ -763,13 +830,15 @@ struct bx_agent {
     // update_task_done) can overlap the device half of the lane's next segment.  Each returns "" or the error chain
     // ("outer: inner", anyhow's `{:#}` form).
     //   first half: fetch -> deserialize -> prove_segment
-    std::string prove_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t index, Pending* out) {
+    std::string prove_stage(uint32_t lane_idx, const bx_ready_task& task, uint64_t index, Pending* out, Fetched* pre = nullptr) {
         out->start = Clock::now();
         out->task = task;
         out->job_prefix = std::string("job:") + task.job_id;
         out->segment_key = out->job_prefix + ":segments:" + std::to_string(index);  // SEGMENTS_PATH, tasks/mod.rs:25
-        StoreValue blob;
-        std::string e = store_get(out->segment_key, &blob);
+        StoreValue fetched_here;
+        const bool use_pre = pre && pre->fetched && pre->index == index;  // the lane's fetcher already did the GET (cfg.prefetch)
+        StoreValue& blob = use_pre ? pre->blob : fetched_here;
+        std::string e = use_pre ? pre->blob_err : store_get(out->segment_key, &fetched_here);
         if (!e.empty()) return "segment data not found for segment key: " + out->segment_key + ": " + e;
         out->opaque = prover.prove_blob != nullptr;
         if (out->opaque) {  // a real prover: bytes in, bytes out (prove.rs:36-109 happens inside the callback)
@@ -1005,7 +1074,7 @@ struct bx_agent {
     }
 
     // Agent::process_work (lib.rs:445-530), first half: TaskType dispatch + the device half of the prove task.
-    std::string dispatch(uint32_t lane, const bx_ready_task& task, Pending* out) {
+    std::string dispatch(uint32_t lane, const bx_ready_task& task, Pending* out, Fetched* pre = nullptr) {
         drain_children(out);  // a slot that was abandoned on an exception may still have helpers reading it
         JVal def;
         std::string bad = std::string("Invalid task_def: ") + task.job_id + ":" + task.task_id;
@@ -1023,7 +1092,7 @@ struct bx_agent {
             if (!uint_field("index", &idx)) return bad;
             out->kind = Pending::Prove;
             out->cleanup_keys.clear();
-            std::string e = prove_stage(lane, task, idx, out);
+            std::string e = prove_stage(lane, task, idx, out, pre);
             if (!e.empty()) return "[BENTO-WF-115] Prove failed: " + e;
             return "";
         }
@@ -1161,23 +1230,97 @@ struct bx_agent {
                 fin.release();
             }
         });
+        // cfg.prefetch: a fetcher thread claims the lane's NEXT task and fetches its segment while the lane proves the current one.
+        // With a store behind a network (an ~80 MB GET over the REST worker protocol) the lane's GPU share would otherwise idle for
+        // the length of every GET; with the in-memory store there is nothing to hide, which is why it is opt-in: the price is one
+        // task claimed ahead per lane (a tail imbalance of at most one proof at the end of a batch).
+        Prefetcher pf;
+        std::thread fetcher;
+        if (cfg.prefetch) {
+            fetcher = std::thread([&] {
+                while (pf.wait_empty()) {
+                    if (stop.load(std::memory_order_relaxed)) {  // no new claims once a stop was requested
+                        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                        continue;
+                    }
+                    std::unique_ptr<Fetched> w;
+                    try {
+                        w.reset(new Fetched());
+                        w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
+                        w->claimed = Clock::now();
+                        if (w->rc == 1 && prove_index_of(w->task, &w->index)) {  // SEGMENTS_PATH, tasks/mod.rs:25
+                            w->blob_err = store_get(std::string("job:") + w->task.job_id + ":segments:" + std::to_string(w->index), &w->blob);
+                            w->fetched = true;
+                        }
+                    } catch (const std::exception& e) {
+                        if (!w) return;  // not even the mailbox entry could be allocated: the lane will see a stop
+                        if (w->rc != 1) {
+                            w->rc = -1;
+                            snprintf(w->eb, sizeof w->eb, "exception in the fetcher: %s", e.what());
+                        } else {
+                            w->fetched = true;
+                            w->blob_err = std::string("exception while fetching the segment: ") + e.what();
+                        }
+                    }
+                    pf.put(std::move(w));
+                }
+            });
+        }
         Pending slots[2];
         int cur = 0;
         int64_t idle = 0;
-        while (!stop.load(std::memory_order_relaxed)) {
-            bx_ready_task task;
-            char eb[256] = {0};
-            int rc = 0;
-            for (const std::string& st : streams) {  // the lane's own stream first, then the ones it also serves
-                rc = taskdb.request_work(taskdb.user, st.c_str(), &task, eb, sizeof eb);
-                metrics.record_task_claim(st.c_str(), rc < 0 ? "error" : rc == 0 ? "empty" : "claimed");  // lib.rs:613-623
-                if (rc != 0) break;
+        // the device half of one claimed task + the failure bookkeeping of poll_work; false = fatal (the loop ends)
+        auto run_claimed = [&](Fetched& w) -> bool {
+            idle = 0;
+            Pending* p = &slots[cur];
+            p->claimed = w.claimed;  // processing_start, lib.rs:629
+            std::string err;
+            try {
+                err = dispatch(lane, w.task, p, &w);
+            } catch (const std::exception& e) {
+                err = std::string("[BENTO-WF-115] Prove failed: exception in the device half: ") + e.what();
             }
-            if (rc < 0) {
-                set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + eb);
+            if (!err.empty()) {
+                std::string f;
+                try {
+                    metrics.record_task_processing(task_type_label(w.task), "error", secs_since(p->claimed));
+                    f = handle_failure(w.task, err);
+                } catch (const std::exception& e) {
+                    f = std::string("exception while recording a task failure: ") + e.what();
+                }
+                if (!f.empty()) {
+                    set_fatal(f);
+                    return false;
+                }
+                return true;
+            }
+            fin.post(p);  // blocks while the previous segment's host half is still running
+            cur ^= 1;
+            return true;
+        };
+        while (!stop.load(std::memory_order_relaxed)) {
+            std::unique_ptr<Fetched> w;
+            if (cfg.prefetch) {
+                w = pf.take(stop);
+                if (!w) break;  // stop requested
+                if (w->rc == 0) {
+                    // the fetcher's "nothing ready" is as old as the proof that ran meanwhile, and a finish in flight may requeue
+                    // its task: the poll that counts as idle is one made now, by the lane, with nothing pending
+                    (void)fin.wait_idle();
+                    w.reset(new Fetched());
+                    w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
+                    w->claimed = Clock::now();
+                }
+            } else {
+                w.reset(new Fetched());
+                w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
+                w->claimed = Clock::now();
+            }
+            if (w->rc < 0) {
+                set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + w->eb);
                 break;
             }
-            if (rc == 0) {
+            if (w->rc == 0) {
                 // a finish still in flight may requeue its task (retry): only a poll made with nothing pending counts as idle
                 if (fin.wait_idle()) continue;
                 if (max_idle_polls >= 0 && ++idle >= max_idle_polls) break;
@@ -1187,31 +1330,17 @@ struct bx_agent {
                     std::this_thread::sleep_for(std::chrono::duration<double>(std::min(cfg.poll_time, 0.05)));
                 continue;
             }
-            idle = 0;
-            Pending* p = &slots[cur];
-            p->claimed = Clock::now();  // processing_start, lib.rs:629
-            std::string err;
-            try {
-                err = dispatch(lane, task, p);
-            } catch (const std::exception& e) {
-                err = std::string("[BENTO-WF-115] Prove failed: exception in the device half: ") + e.what();
+            if (!run_claimed(*w)) break;
+        }
+        if (cfg.prefetch) {
+            // a task the fetcher claimed and the lane never took is still 'running' in the task db: it is run now, not lost
+            std::unique_ptr<Fetched> left = pf.quit();
+            fetcher.join();
+            if (!left) {
+                std::lock_guard<std::mutex> l(pf.mu);
+                left = std::move(pf.slot);  // put() raced with quit()
             }
-            if (!err.empty()) {
-                std::string f;
-                try {
-                    metrics.record_task_processing(task_type_label(task), "error", secs_since(p->claimed));
-                    f = handle_failure(task, err);
-                } catch (const std::exception& e) {
-                    f = std::string("exception while recording a task failure: ") + e.what();
-                }
-                if (!f.empty()) {
-                    set_fatal(f);
-                    break;
-                }
-                continue;
-            }
-            fin.post(p);  // blocks while the previous segment's host half is still running
-            cur ^= 1;
+            if (left && left->rc == 1) (void)run_claimed(*left);
         }
         fin.quit();
         finisher.join();
@@ -1506,6 +1635,7 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
             return "bx_agent_create: lift_po2 must be 0 or in [9, 24]";
         }
         if (!a->cfg.join_po2) a->cfg.join_po2 = 18;
+        a->cfg.prefetch = a->cfg.prefetch ? 1 : 0;
         if (a->cfg.join_po2 < 9 || a->cfg.join_po2 > 24) {
             delete a;
             return "bx_agent_create: join_po2 must be in [9, 24]";

@@ -244,6 +244,12 @@ typedef struct bx_agent_config {
                               * store the lifted receipt): one more synthetic proof of 2^N cycles seeded by bx_join_seed(segment seal),
                               * and THAT is what is stored under synthetic_receipts:{task} for the joins to consume.  Like the join
                               * stand-in it is not a recursion proof; it gives a Prove task its real anatomy (two proofs) */
+    int32_t prefetch;        /* 1 = every lane runs a fetcher thread that claims the lane's NEXT task and GETs its segment while the lane
+                              * proves the current one (pull-when-idle + 2-deep pipelining): with a store behind a
+                              * network — an ~80 MB GET over the REST worker protocol — the lane's share of the GPU no longer idles for
+                              * the length of a GET.  Costs one task claimed ahead per lane (at the end of a batch a claimed task may wait
+                              * for its lane while another lane idles).  0 (default) = claim, fetch, prove, in that order, like the
+                              * reference's agent */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;

@@ -51,8 +51,9 @@ static const char* prove(void*, uint32_t lane, uint32_t, const uint8_t* segment,
 
 // Second phase: a PLANNED job (bx_plan_job: K proves -> log-depth tail of stand-in joins -> resolve -> finalize) through the same
 // 6 lanes with the same randomly failing prover: every task ends done exactly once, and no task was claimed before each of its
-// prerequisites was done (timestamps of the task db), whatever the interleaving of lanes, finishers and retries.
-static int planned_job_phase(void) {
+// prerequisites was done (timestamps of the task db), whatever the interleaving of lanes, finishers and retries.  Run twice: serial
+// lanes, then with the claim-ahead fetcher (bx_agent_config.prefetch) — a third thread per lane that claims and GETs.
+static int planned_job_phase(int prefetch) {
     bx_mem_store* store = nullptr;
     bx_mem_taskdb* db = nullptr;
     if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;
@@ -83,6 +84,7 @@ static int planned_job_phase(void) {
     cfg.synthetic = 1;
     cfg.poll_time = 0.001;
     cfg.join_po2 = 9;
+    cfg.prefetch = prefetch;  // second run: every lane has a fetcher thread claiming one task ahead and doing its GET
     cfg.lift_po2 = 9;  // every Prove task also runs the stand-in lift: the segment seal is verified on a helper thread beside it
     snprintf(cfg.also_streams, sizeof cfg.also_streams, "aux");
     bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};
@@ -141,12 +143,12 @@ static int planned_job_phase(void) {
         fprintf(stderr, "planned job: %zu keys left in the hot store\n", keys);
         return 1;
     }
-    printf("planned job ok: %llu tasks (%d proves, %d joins, resolve, finalize)\n", (unsigned long long)created, K, joins);
+    printf("planned job ok%s: %llu tasks (%d proves, %d joins, resolve, finalize)\n", prefetch ? " (prefetch)" : "", (unsigned long long)created, K, joins);
     return 0;
 }
 
 int main() {
-    if (planned_job_phase()) return 1;
+    if (planned_job_phase(0) || planned_job_phase(1)) return 1;
     bx_mem_store* store = nullptr;
     bx_mem_taskdb* db = nullptr;
     if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;

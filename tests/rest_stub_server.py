@@ -25,6 +25,7 @@ class State:
         self.drop_silently = False  # ... without announcing it ("Connection: close" left out)
         self.served = 0
         self.stall_next = 0.0    # the next request is read and logged, then the handler sleeps this long before answering (a hung upstream)
+        self.get_delay = 0.0     # every GET of a hot key takes this long before the body is sent (an ~80 MB segment download)
         self.interim_next = 0    # answer the next request with this many "100 Continue" interim responses before the real one
 
     def create_task(self, stream, job_id, task_id, task_def, max_retries=0):
@@ -42,6 +43,8 @@ class State:
 def make_handler(st):
     class H(BaseHTTPRequestHandler):
         protocol_version = "HTTP/1.1"
+        wbufsize = -1  # headers and body leave in ONE segment (handle_one_request flushes): unbuffered, the body waits ~40 ms for the
+        #                client's delayed ACK of the headers (Nagle), which no real server does
 
         def log_message(self, *a):
             pass
@@ -89,6 +92,8 @@ def make_handler(st):
             parts = path.strip("/").split("/")
             if parts[:2] == ["worker", "hot"]:
                 key = "/".join(parts[2:])
+                if method == "GET" and st.get_delay:
+                    time.sleep(st.get_delay)  # outside the lock: other requests are served meanwhile
                 with st.mu:
                     if method == "GET":
                         v = st.hot.get(key)
