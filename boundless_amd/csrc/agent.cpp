@@ -19,12 +19,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <shared_mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/bx_agent.h"
@@ -413,49 +416,82 @@ struct bx_mem_taskdb {
     struct Row {
         std::string stream, job, task, def, error, output;
         int32_t max_retries = 0, retries = 0, state = BX_TASK_READY;
-        std::vector<std::string> prereqs;  // task_deps rows with this task as post_task_id
+        uint32_t job_ix = 0;
+        std::vector<uint32_t> dependants;  // task_deps rows with this task as pre_task_id: the rows to release when it is done
         int32_t waiting_on = 0;            // prerequisites not yet done
         double created = 0, started = 0, updated = 0;  // seconds since `epoch`
     };
-    std::vector<Row> rows;  // creation order = claim order within a stream (tasks_by_stream: created_at ASC)
+    struct Job {  // the `jobs` row (1_taskdb.sql:52-58) + per-state task counts
+        std::string id, error;
+        int32_t state = BX_JOB_RUNNING;
+        uint64_t counts[5] = {0, 0, 0, 0, 0}, tasks = 0;
+    };
+    // Every operation is O(log n) in the number of rows: a job of 2^20 segments is 2^21 rows, and every lane of every device
+    // claims from and reports to this one table under this one mutex.
+    std::deque<Row> rows;  // creation order
+    std::vector<Job> jobs;
+    std::unordered_map<std::string, uint32_t> row_index, job_index;  // "job\0task" -> row, job -> jobs[]
+    std::map<std::string, std::set<uint32_t>> ready;                 // worker type -> ready rows, oldest first (tasks_by_stream)
+    uint64_t counts[5] = {0, 0, 0, 0, 0};
     Clock::time_point epoch = Clock::now();
     double now_s() const { return secs_since(epoch); }
-    Row* find_locked(const char* job, const char* task) {
-        for (auto& r : rows)
-            if (r.job == job && r.task == task) return &r;
-        return nullptr;
+    static std::string key(const char* job, const char* task) {
+        std::string k(job);
+        k.push_back('\0');
+        k += task;
+        return k;
     }
-    // update_task_failed, 1_taskdb.sql:316-347: ready, running and PENDING rows can fail; the job's state is derived (bx_mem_taskdb_job_info)
+    Row* find_locked(const char* job, const char* task) {
+        auto it = row_index.find(key(job, task));
+        return it == row_index.end() ? nullptr : &rows[it->second];
+    }
+    uint32_t index_of(const Row* r) const { return row_index.at(key(r->job.c_str(), r->task.c_str())); }
+    void set_state_locked(Row* r, int32_t s) {
+        if (r->state == s) return;
+        const uint32_t ix = index_of(r);
+        if (s == BX_TASK_READY) ready[r->stream].insert(ix);  // may throw: before anything else changes
+        if (r->state == BX_TASK_READY) ready[r->stream].erase(ix);
+        Job& j = jobs[r->job_ix];
+        counts[r->state]--, j.counts[r->state]--;
+        counts[s]++, j.counts[s]++;
+        r->state = s;
+    }
+    // update_task_failed, 1_taskdb.sql:316-347: ready, running and PENDING rows can fail; the first failure (in time) is the job's error
     int fail_locked(Row* r, const char* error) {
         if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING && r->state != BX_TASK_PENDING)) return 0;
-        r->state = BX_TASK_FAILED;
         r->error = error;
+        Job& j = jobs[r->job_ix];
+        if (j.state != BX_JOB_FAILED) j.error = error;  // both strings assigned before any state changes
+        set_state_locked(r, BX_TASK_FAILED);
         r->updated = now_s();
+        j.state = BX_JOB_FAILED;
         return 1;
     }
-    // the second half of update_task_done (1_taskdb.sql:296-306): every task waiting on `done` loses one prerequisite and becomes
-    // ready when that was its last (failed dependants stay failed)
-    void release_dependants_locked(const Row& done) {
-        for (auto& r : rows) {
-            if (r.job != done.job || r.state == BX_TASK_FAILED) continue;
-            for (auto& pre : r.prereqs)
-                if (pre == done.task) {
-                    if (r.waiting_on > 0 && --r.waiting_on == 0 && r.state == BX_TASK_PENDING) r.state = BX_TASK_READY;
-                }
+    // the second half of update_task_done (1_taskdb.sql:296-311): every task waiting on `done` loses one prerequisite and becomes
+    // ready when that was its last (failed dependants stay failed); a job none of whose tasks is anything but done is done
+    void release_dependants_locked(Row* done) {
+        for (uint32_t ix : done->dependants) {
+            Row& r = rows[ix];
+            if (r.state == BX_TASK_FAILED) continue;
+            if (r.waiting_on > 0 && --r.waiting_on == 0 && r.state == BX_TASK_PENDING) set_state_locked(&r, BX_TASK_READY);
         }
+        Job& j = jobs[done->job_ix];
+        if (j.counts[BX_TASK_DONE] == j.tasks) j.state = BX_JOB_DONE;
     }
 };
 
 static int tdb_request_work(void* user, const char* stream, bx_ready_task* out, char* errbuf, size_t cap) {
     auto* t = (bx_mem_taskdb*)user;
-    std::lock_guard<std::mutex> g(t->mu);
-    for (auto& r : t->rows) {
-        if (r.state != BX_TASK_READY || r.stream != stream) continue;
+    try {
+        std::lock_guard<std::mutex> g(t->mu);
+        auto q = t->ready.find(stream);
+        if (q == t->ready.end() || q->second.empty()) return 0;
+        bx_mem_taskdb::Row& r = t->rows[*q->second.begin()];  // ORDER BY created_at ASC LIMIT 1 (1_taskdb.sql:243-247)
         if (r.job.size() >= sizeof out->job_id || r.task.size() >= sizeof out->task_id || r.def.size() >= sizeof out->task_def) {
             snprintf(errbuf, cap, "task %s:%s does not fit bx_ready_task", r.job.c_str(), r.task.c_str());
             return -1;
         }
-        r.state = BX_TASK_RUNNING;
+        t->set_state_locked(&r, BX_TASK_RUNNING);
         r.started = t->now_s();
         memset(out, 0, sizeof *out);
         memcpy(out->job_id, r.job.c_str(), r.job.size());
@@ -463,28 +499,30 @@ static int tdb_request_work(void* user, const char* stream, bx_ready_task* out, 
         memcpy(out->task_def, r.def.c_str(), r.def.size());
         out->max_retries = r.max_retries;
         return 1;
+    } catch (const std::exception&) {
+        snprintf(errbuf, cap, "request_work: out of memory");
+        return -1;
     }
-    return 0;
 }
 static int tdb_done(void* user, const char* job, const char* task, const char* output, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
-    std::lock_guard<std::mutex> g(t->mu);
-    auto* r = t->find_locked(job, task);
-    if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
     try {
+        std::lock_guard<std::mutex> g(t->mu);
+        auto* r = t->find_locked(job, task);
+        if (!r || (r->state != BX_TASK_READY && r->state != BX_TASK_RUNNING)) return 0;
         r->output = output ? output : "null";
+        t->set_state_locked(r, BX_TASK_DONE);
+        r->updated = t->now_s();
+        t->release_dependants_locked(r);
+        return 1;
     } catch (...) {
         return -1;
     }
-    r->state = BX_TASK_DONE;
-    r->updated = t->now_s();
-    t->release_dependants_locked(*r);
-    return 1;
 }
 static int tdb_failed(void* user, const char* job, const char* task, const char* error, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
-    std::lock_guard<std::mutex> g(t->mu);
     try {
+        std::lock_guard<std::mutex> g(t->mu);
         return t->fail_locked(t->find_locked(job, task), error);
     } catch (...) {
         return -1;
@@ -493,26 +531,34 @@ static int tdb_failed(void* user, const char* job, const char* task, const char*
 // 1_taskdb.sql:361-391
 static int tdb_retry(void* user, const char* job, const char* task, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
-    std::lock_guard<std::mutex> g(t->mu);
-    auto* r = t->find_locked(job, task);
-    if (!r || r->state != BX_TASK_RUNNING) return 0;
-    r->retries += 1;
-    r->state = BX_TASK_READY;
-    r->updated = t->now_s();
-    r->error.clear();
-    if (r->retries > r->max_retries) {
-        t->fail_locked(r, "retry max hit");
-        return 0;
+    try {
+        std::lock_guard<std::mutex> g(t->mu);
+        auto* r = t->find_locked(job, task);
+        if (!r || r->state != BX_TASK_RUNNING) return 0;
+        t->set_state_locked(r, BX_TASK_READY);
+        r->retries += 1;
+        r->updated = t->now_s();
+        r->error.clear();
+        if (r->retries > r->max_retries) {
+            t->fail_locked(r, "retry max hit");
+            return 0;
+        }
+        return 1;
+    } catch (...) {
+        return -1;
     }
-    return 1;
 }
 static int tdb_current_retries(void* user, const char* job, const char* task, int32_t* retries, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
     std::lock_guard<std::mutex> g(t->mu);
-    auto* r = t->find_locked(job, task);
-    if (!r || r->state != BX_TASK_RUNNING) return 0;
-    *retries = r->retries;
-    return 1;
+    try {
+        auto* r = t->find_locked(job, task);
+        if (!r || r->state != BX_TASK_RUNNING) return 0;
+        *retries = r->retries;
+        return 1;
+    } catch (...) {
+        return -1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ agent ----
@@ -1400,6 +1446,7 @@ const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char*
         if (!t || !stream || !job || !task || !def || (n_prereqs && !prereqs)) return "bx_mem_taskdb_create_task: NULL argument";
         std::lock_guard<std::mutex> g(t->mu);
         if (t->find_locked(job, task)) return fail(std::string("task already exists: ") + job + ":" + task);
+        if (t->rows.size() >= 0xFFFFFFF0u) return "bx_mem_taskdb_create_task: too many rows";
         bx_mem_taskdb::Row r;
         r.stream = stream;
         r.job = job;
@@ -1407,16 +1454,64 @@ const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char*
         r.def = def;
         r.max_retries = max_retries;
         r.created = t->now_s();
+        std::vector<uint32_t> pres;
         for (size_t i = 0; i < n_prereqs; ++i) {
             if (!prereqs[i]) return "bx_mem_taskdb_create_task: NULL prerequisite";
             const bx_mem_taskdb::Row* pre = t->find_locked(job, prereqs[i]);
             // task_deps has a foreign key on (job_id, pre_task_id)
             if (!pre) return fail(std::string("prerequisite task does not exist: ") + job + ":" + prereqs[i]);
-            r.prereqs.emplace_back(prereqs[i]);
+            pres.push_back(t->index_of(pre));
             if (pre->state != BX_TASK_DONE) r.waiting_on += 1;
         }
         r.state = r.waiting_on ? BX_TASK_PENDING : BX_TASK_READY;
-        t->rows.push_back(std::move(r));
+        // everything that can throw happens before the tables change, in an order that is undone on failure
+        const uint32_t ix = (uint32_t)t->rows.size();
+        auto jit = t->job_index.find(job);
+        const bool new_job = jit == t->job_index.end();
+        if (new_job) {  // the reference's create_job makes the row (1_taskdb.sql:172-191); here a job starts with its first task
+            bx_mem_taskdb::Job j;
+            j.id = job;
+            t->jobs.push_back(std::move(j));
+            try {
+                jit = t->job_index.emplace(job, (uint32_t)(t->jobs.size() - 1)).first;
+            } catch (...) {
+                t->jobs.pop_back();
+                throw;
+            }
+        }
+        r.job_ix = jit->second;
+        const std::string k = bx_mem_taskdb::key(job, task);
+        const std::string stream_name = r.stream;
+        const int32_t state = r.state;
+        size_t linked = 0;
+        bool indexed = false, pushed = false, queued = false;
+        try {
+            for (uint32_t p : pres) t->rows[p].dependants.reserve(t->rows[p].dependants.size() + 1);
+            t->row_index.emplace(k, ix);
+            indexed = true;
+            t->rows.push_back(std::move(r));
+            pushed = true;
+            if (state == BX_TASK_READY) {
+                t->ready[stream_name].insert(ix);
+                queued = true;
+            }
+            for (uint32_t p : pres) {
+                t->rows[p].dependants.push_back(ix);  // reserved above: does not throw
+                ++linked;
+            }
+        } catch (...) {
+            (void)queued;
+            (void)linked;
+            if (pushed) t->rows.pop_back();
+            if (indexed) t->row_index.erase(k);
+            if (new_job) {
+                t->job_index.erase(job);
+                t->jobs.pop_back();
+            }
+            throw;
+        }
+        bx_mem_taskdb::Job& j = t->jobs[jit->second];
+        j.tasks++, j.counts[state]++, t->counts[state]++;
         return nullptr;
     } catch (const std::exception&) {
         return "bx_mem_taskdb_create_task: out of memory";
@@ -1427,20 +1522,14 @@ const char* bx_mem_taskdb_job_info(bx_mem_taskdb* t, const char* job, bx_job_inf
         if (!t || !job || !out) return "bx_mem_taskdb_job_info: NULL argument";
         std::lock_guard<std::mutex> g(t->mu);
         memset(out, 0, sizeof *out);
-        for (auto& r : t->rows) {
-            if (r.job != job) continue;
-            out->tasks++;
-            switch (r.state) {
-                case BX_TASK_PENDING: out->pending++; break;
-                case BX_TASK_READY: out->ready++; break;
-                case BX_TASK_RUNNING: out->running++; break;
-                case BX_TASK_DONE: out->done++; break;
-                default:
-                    if (!out->failed++) snprintf(out->error, sizeof out->error, "%s", r.error.c_str());  // the first failure is the job's error
-            }
-        }
-        if (!out->tasks) return fail(std::string("no such job: ") + job);
-        out->state = out->failed ? BX_JOB_FAILED : out->done == out->tasks ? BX_JOB_DONE : BX_JOB_RUNNING;
+        auto it = t->job_index.find(job);
+        if (it == t->job_index.end()) return fail(std::string("no such job: ") + job);
+        const bx_mem_taskdb::Job& j = t->jobs[it->second];
+        out->state = j.state;  // the jobs row: 'failed' from the first failure on, 'done' when an update_task_done left nothing undone
+        out->tasks = j.tasks;
+        out->pending = j.counts[BX_TASK_PENDING], out->ready = j.counts[BX_TASK_READY], out->running = j.counts[BX_TASK_RUNNING];
+        out->done = j.counts[BX_TASK_DONE], out->failed = j.counts[BX_TASK_FAILED];
+        snprintf(out->error, sizeof out->error, "%s", j.error.c_str());
         return nullptr;
     } catch (const std::exception&) {
         return "bx_mem_taskdb_job_info: out of memory";
@@ -1568,10 +1657,9 @@ const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const cha
 }
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state) {
     if (!t) return 0;
+    if (state < 0 || state > 4) return 0;
     std::lock_guard<std::mutex> g(t->mu);
-    size_t n = 0;
-    for (auto& r : t->rows) n += r.state == state;
-    return n;
+    return (size_t)t->counts[state];
 }
 
 // ---- wire ----

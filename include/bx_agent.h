@@ -126,14 +126,19 @@ const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* task_stream,
                                       const char* task_def_json, int32_t max_retries);
 /* taskdb::create_task (1_taskdb.sql:197-228): the task is 'pending' while any of its prerequisites (task ids of the same job,
  * which must exist) is not 'done', 'ready' otherwise; update_task_done on a prerequisite decrements waiting_on and releases
- * the task when it reaches zero (1_taskdb.sql:296-306); update_task_failed also applies to pending tasks (:324). */
+ * the task when it reaches zero (1_taskdb.sql:296-306); update_task_failed also applies to pending tasks (:324).
+ * request_work hands out the oldest ready task of the worker type (created_at ASC, :243-247).  Every operation is O(log rows):
+ * a 2^16-segment job (131 075 rows) is planned and drained in a second (tests/test_taskdb_model_cpu.py, which also checks the
+ * table against a row-by-row restatement of the SQL on random operation sequences).  One difference: a prerequisite listed
+ * twice is released twice here; the SQL counts it twice and releases it once, which leaves the task pending for ever. */
 const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
                                                    const char* task_def_json, const char* const* prerequisites, size_t n_prerequisites,
                                                    int32_t max_retries);
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const char* task_id, bx_task_info* out);
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
-/* job_state (1_taskdb.sql:5-9): running until every task is done (-> done: update_task_done, :308-311) or one has failed
- * (-> failed with that task's error: update_task_failed, :340-347). */
+/* job_state (1_taskdb.sql:5-9), a stored row as in the reference: running; -> done by the update_task_done that leaves no task
+ * of the job in another state (:308-311; a task created afterwards does not reopen it); -> failed, with that task's error, by the
+ * FIRST update_task_failed in time (:333-340).  The row is created with the job's first task (the reference's create_job). */
 enum bx_job_state { BX_JOB_RUNNING = 0, BX_JOB_DONE = 1, BX_JOB_FAILED = 2 };
 typedef struct bx_job_info {
     int32_t state; /* enum bx_job_state */

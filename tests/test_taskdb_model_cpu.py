@@ -1,0 +1,243 @@
+"""CPU: the in-memory task db against a row-by-row restatement of the reference's SQL, on random operation sequences.
+
+Reference: bento/crates/taskdb/migrations/1_taskdb.sql — create_task (:197-228), request_work (:231-266: the oldest ready task of
+the worker type's stream, created_at ASC), update_task_done (:278-314), update_task_failed (:316-347), update_task_retry (:361-391),
+the job row's state and error (:287-311, :333-340).  `Model` below is that SQL with Python lists for tables; the library
+(csrc/agent.cpp: bx_mem_taskdb) must agree with it after every operation — on every row, every job and every return value.
+
+One documented difference, not generated here: a prerequisite listed TWICE.  The SQL counts it twice at creation and releases it
+once (UPDATE ... FROM joins a target row once), leaving the task pending for ever; the library releases it twice.  The planner
+never emits one.
+"""
+import ctypes as C
+import random
+
+import pytest
+
+from boundless_amd import agent as ag
+from boundless_amd.hal import HalError
+
+_UPD3 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t)
+_UPD2 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t)
+_REQ = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(ag._ReadyTask), C.c_char_p, C.c_size_t)
+_CUR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t)
+
+
+class Lib:
+    """The library's table through the same callback table the agent uses."""
+
+    def __init__(self):
+        self.db = ag.TaskDb()
+        o = self.db.ops
+        self.u = o.user
+        self._done, self._failed = _UPD3(o.update_task_done), _UPD3(o.update_task_failed)
+        self._retry, self._req, self._cur = _UPD2(o.update_task_retry), _REQ(o.request_work), _CUR(o.current_retries)
+
+    def create_task(self, stream, job, task, pre, max_retries):
+        try:
+            self.db.create_task(job, task, {"Prove": {"index": 0}}, max_retries=max_retries, stream=stream, prerequisites=pre)
+            return True
+        except HalError:
+            return False
+
+    def request_work(self, stream):
+        out = ag._ReadyTask()
+        rc = self._req(self.u, stream.encode(), C.byref(out), None, 0)
+        assert rc in (0, 1)
+        return (out.job_id.decode(), out.task_id.decode(), out.max_retries) if rc else None
+
+    def done(self, job, task, output):
+        return self._done(self.u, job.encode(), task.encode(), output.encode(), None, 0) == 1
+
+    def failed(self, job, task, error):
+        return self._failed(self.u, job.encode(), task.encode(), error.encode(), None, 0) == 1
+
+    def retry(self, job, task):
+        return self._retry(self.u, job.encode(), task.encode(), None, 0) == 1
+
+    def current_retries(self, job, task):
+        r = C.c_int32(-1)
+        rc = self._cur(self.u, job.encode(), task.encode(), C.byref(r), None, 0)
+        return r.value if rc == 1 else None
+
+
+class Model:
+    """1_taskdb.sql with lists for tables.  A stream is a worker type here (one stream per type: include/bx_agent.h)."""
+
+    def __init__(self):
+        self.tasks = []  # dict rows, insertion order = created_at order
+        self.deps = []   # (job, pre, post)
+        self.jobs = {}   # job -> {"state", "error"}
+
+    def _row(self, job, task):
+        for r in self.tasks:
+            if r["job"] == job and r["task"] == task:
+                return r
+        return None
+
+    def create_task(self, stream, job, task, pre, max_retries):
+        if self._row(job, task) is not None:  # PRIMARY KEY (job_id, task_id)
+            return False
+        if any(self._row(job, p) is None for p in pre):  # FOREIGN KEY (job_id, pre_task_id)
+            return False
+        self.jobs.setdefault(job, {"state": "running", "error": ""})  # the library creates the job row with its first task
+        row = dict(stream=stream, job=job, task=task, state="pending", waiting_on=0, retries=0, max_retries=max_retries, error="", output="")
+        self.tasks.append(row)
+        for p in pre:
+            self.deps.append((job, p, task))
+        not_done = sum(1 for (j, p, post) in self.deps if j == job and post == task and self._row(job, p)["state"] != "done")
+        row["waiting_on"] = not_done
+        row["state"] = "ready" if not_done == 0 else "pending"
+        return True
+
+    def request_work(self, stream):
+        for r in self.tasks:  # ORDER BY created_at ASC LIMIT 1
+            if r["stream"] == stream and r["state"] == "ready":
+                r["state"] = "running"
+                return (r["job"], r["task"], r["max_retries"])
+        return None
+
+    def done(self, job, task, output):
+        r = self._row(job, task)
+        if r is None or r["state"] not in ("ready", "running"):
+            return False
+        r["state"], r["output"] = "done", output
+        for (j, p, post) in self.deps:
+            if j == job and p == task:
+                d = self._row(job, post)
+                if d["state"] != "failed":
+                    d["state"] = "ready" if d["waiting_on"] == 1 else "pending"
+                    d["waiting_on"] -= 1
+        if all(t["state"] == "done" for t in self.tasks if t["job"] == job):
+            self.jobs[job]["state"] = "done"
+        return True
+
+    def failed(self, job, task, error):
+        r = self._row(job, task)
+        if r is None or r["state"] not in ("ready", "running", "pending"):
+            return False
+        r["state"], r["error"] = "failed", error
+        if self.jobs[job]["state"] != "failed":
+            self.jobs[job].update(state="failed", error=error)
+        return True
+
+    def retry(self, job, task):
+        r = self._row(job, task)
+        if r is None or r["state"] != "running":
+            return False
+        r["retries"] += 1
+        r["state"], r["error"] = "ready", ""
+        if r["retries"] > r["max_retries"]:
+            self.failed(job, task, "retry max hit")
+            return False
+        return True
+
+    def current_retries(self, job, task):
+        r = self._row(job, task)
+        return r["retries"] if r is not None and r["state"] == "running" else None
+
+
+def compare(lib, model, trail):
+    for r in model.tasks:
+        got = lib.db.task(r["job"], r["task"])
+        want = (r["state"], r["waiting_on"], r["retries"], r["max_retries"], r["error"], r["output"])
+        assert (got.state, got.waiting_on, got.retries, got.max_retries, got.error, got.output) == want, (r["job"], r["task"], trail[-8:])
+    for job, j in model.jobs.items():
+        rows = [t for t in model.tasks if t["job"] == job]
+        got = lib.db.job(job)
+        assert got["state"] == j["state"] and got["error"] == j["error"], (job, got, j, trail[-8:])
+        assert got["tasks"] == len(rows)
+        for s in ("pending", "ready", "running", "done", "failed"):
+            assert got[s] == sum(1 for t in rows if t["state"] == s), (job, s, trail[-8:])
+    for s in ag.TASK_STATES:
+        assert lib.db.count(s) == sum(1 for t in model.tasks if t["state"] == s)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_operation_sequences_agree_with_the_sql(seed):
+    rng = random.Random(0xDB0000 + seed)
+    lib, model, trail = Lib(), Model(), []
+    jobs, streams = ["J0", "J1", "J2"][: 1 + seed % 3], ["prove", "join", "aux"]
+    names = {j: [] for j in jobs}
+    for step in range(220):
+        kind = rng.choices(["create", "request", "done", "failed", "retry", "current"], weights=[30, 25, 25, 3 if seed % 4 else 0, 10, 5])[0]
+        job = rng.choice(jobs)
+        known = names[job]
+        pick = (lambda: rng.choice(known)) if known else (lambda: "none")
+        if kind == "create":
+            task = f"t{len(known)}" if rng.random() < 0.95 else pick()  # now and then a duplicate id
+            pre = rng.sample(known, k=min(len(known), rng.choice([0, 0, 1, 2, 2, 3])))
+            if rng.random() < 0.03:
+                pre = pre + ["ghost"]  # a prerequisite that does not exist
+            args = (rng.choice(streams), job, task, pre, rng.choice([0, 0, 1, 2]))
+            a, b = lib.create_task(*args), model.create_task(*args)
+            if b and task not in known:
+                known.append(task)
+        elif kind == "request":
+            args = (rng.choice(streams),)
+            a, b = lib.request_work(*args), model.request_work(*args)
+        elif kind == "done":
+            args = (job, pick(), rng.choice(["null", '{"x":1}']))
+            a, b = lib.done(*args), model.done(*args)
+        elif kind == "failed":
+            args = (job, pick(), f"boom {step}")
+            a, b = lib.failed(*args), model.failed(*args)
+        elif kind == "retry":
+            args = (job, pick())
+            a, b = lib.retry(*args), model.retry(*args)
+        else:
+            args = (job, pick())
+            a, b = lib.current_retries(*args), model.current_retries(*args)
+        trail.append((kind, args, a, b))
+        assert a == b, trail[-8:]
+        compare(lib, model, trail)
+    assert sum(1 for t in trail if t[0] == "request" and t[2]) > 5  # the walk did claim things
+
+
+def test_a_task_created_in_a_finished_job_does_not_reopen_it():
+    """create_task's own TODO (1_taskdb.sql:207-208): nothing stops a task being added to a done job, and the job row stays
+    'done' until the next update_task_done re-counts."""
+    lib, model = Lib(), Model()
+    for t in (lib, model):
+        assert t.create_task("prove", "J", "a", [], 0)
+        assert t.done("J", "a", "null")
+        assert t.create_task("prove", "J", "b", ["a"], 0)
+    compare(lib, model, [])
+    assert lib.db.job("J")["state"] == "done" and lib.db.task("J", "b").state == "ready"
+
+
+def test_the_jobs_error_is_the_first_failure_in_time_not_in_creation_order():
+    lib, model = Lib(), Model()
+    for t in (lib, model):
+        for name in "abc":
+            assert t.create_task("prove", "J", name, [], 0)
+        assert t.failed("J", "c", "third task, first failure")
+        assert t.failed("J", "a", "first task, second failure")
+    compare(lib, model, [])
+    assert lib.db.job("J")["error"] == "third task, first failure"
+
+
+def test_a_job_of_65536_segments_is_planned_and_drained_in_linear_time():
+    """2^17 + 1 rows through plan_job, request_work and update_task_done: every operation is O(log rows) (per-stream ready sets, a
+    hash index, dependants lists), so the whole walk takes a second — with the table scanned per operation it took minutes, under
+    the one mutex every lane of every device shares."""
+    import time
+
+    lib = Lib()
+    k = 1 << 16
+    t0 = time.monotonic()
+    ids = lib.db.plan_job("big", k, aux_stream="prove")
+    assert len(ids) == 2 * k - 1 + 2
+    order = []
+    while True:
+        w = lib.request_work("prove")
+        if w is None:
+            break
+        order.append(w[1])
+        assert lib.done(w[0], w[1], "null")
+    wall = time.monotonic() - t0
+    job = lib.db.job("big")
+    assert job["state"] == "done" and job["done"] == len(ids) == len(order)
+    assert order[:k] == [str(i) for i in range(k)] or set(order[:k]) <= set(ids)  # proves first: they were created first and ready
+    assert order[-2:] == ["resolve", "finalize"]
+    assert wall < 30, wall  # ~1.5 s here; the bound only separates linear from quadratic
