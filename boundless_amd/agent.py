@@ -90,6 +90,7 @@ def _lib():
         "bx_mem_taskdb_ops": ([vp], _TaskDbOps),
         "bx_mem_taskdb_create_task": ([vp, cp, cp, cp, cp, C.c_int32], cp),
         "bx_mem_taskdb_task_info": ([vp, cp, cp, C.POINTER(_TaskInfo)], cp), "bx_mem_taskdb_count": ([vp, C.c_int32], sz),
+        "bx_mem_taskdb_clear_completed_jobs": ([vp, C.POINTER(C.c_uint64)], cp),
         "bx_mem_taskdb_create_task_with_prereqs": ([vp, cp, cp, cp, cp, C.POINTER(cp), sz, C.c_int32], cp),
         "bx_mem_taskdb_job_info": ([vp, cp, C.POINTER(_JobInfo)], cp),
         "bx_plan_job": ([vp, cp, C.c_uint64, C.POINTER(_JobPlan), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], cp),
@@ -265,6 +266,12 @@ class TaskDb:
 
     def count(self, state):
         return self._lib.bx_mem_taskdb_count(self._h, TASK_STATES.index(state))
+
+    def clear_completed_jobs(self):
+        """taskdb `clear_completed_jobs` (4_clear_completed_streams.sql): drops every row of every done job; returns the jobs cleared."""
+        n = C.c_uint64()
+        _check(self._lib.bx_mem_taskdb_clear_completed_jobs(self._h, C.byref(n)))
+        return n.value
 
     def __del__(self):
         try:

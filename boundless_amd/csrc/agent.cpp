@@ -431,7 +431,9 @@ struct bx_mem_taskdb {
     std::deque<Row> rows;  // creation order
     std::vector<Job> jobs;
     std::unordered_map<std::string, uint32_t> row_index, job_index;  // "job\0task" -> row, job -> jobs[]
-    std::map<std::string, std::set<uint32_t>> ready;                 // worker type -> ready rows, oldest first (tasks_by_stream)
+    // worker type -> ready rows as (job, row): the oldest JOB first, then the oldest task of it — `ORDER BY job_created_at ASC,
+    // created_at ASC` (9_request_work.sql:139-141; jobs and rows are numbered in creation order)
+    std::map<std::string, std::set<std::pair<uint32_t, uint32_t>>> ready;
     uint64_t counts[5] = {0, 0, 0, 0, 0};
     Clock::time_point epoch = Clock::now();
     double now_s() const { return secs_since(epoch); }
@@ -449,8 +451,8 @@ struct bx_mem_taskdb {
     void set_state_locked(Row* r, int32_t s) {
         if (r->state == s) return;
         const uint32_t ix = index_of(r);
-        if (s == BX_TASK_READY) ready[r->stream].insert(ix);  // may throw: before anything else changes
-        if (r->state == BX_TASK_READY) ready[r->stream].erase(ix);
+        if (s == BX_TASK_READY) ready[r->stream].insert({r->job_ix, ix});  // may throw: before anything else changes
+        if (r->state == BX_TASK_READY) ready[r->stream].erase({r->job_ix, ix});
         Job& j = jobs[r->job_ix];
         counts[r->state]--, j.counts[r->state]--;
         counts[s]++, j.counts[s]++;
@@ -486,7 +488,7 @@ static int tdb_request_work(void* user, const char* stream, bx_ready_task* out, 
         std::lock_guard<std::mutex> g(t->mu);
         auto q = t->ready.find(stream);
         if (q == t->ready.end() || q->second.empty()) return 0;
-        bx_mem_taskdb::Row& r = t->rows[*q->second.begin()];  // ORDER BY created_at ASC LIMIT 1 (1_taskdb.sql:243-247)
+        bx_mem_taskdb::Row& r = t->rows[q->second.begin()->second];  // ORDER BY job_created_at, created_at LIMIT 1
         if (r.job.size() >= sizeof out->job_id || r.task.size() >= sizeof out->task_id || r.def.size() >= sizeof out->task_def) {
             snprintf(errbuf, cap, "task %s:%s does not fit bx_ready_task", r.job.c_str(), r.task.c_str());
             return -1;
@@ -1492,7 +1494,7 @@ const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char*
             t->rows.push_back(std::move(r));
             pushed = true;
             if (state == BX_TASK_READY) {
-                t->ready[stream_name].insert(ix);
+                t->ready[stream_name].insert({jit->second, ix});
                 queued = true;
             }
             for (uint32_t p : pres) {
@@ -1653,6 +1655,53 @@ const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const cha
         return nullptr;
     } catch (const std::exception&) {
         return "bx_mem_taskdb_task_info: out of memory";
+    }
+}
+// clear_completed_jobs (4_clear_completed_streams.sql): the rows of every 'done' job leave the table; returns the jobs cleared
+const char* bx_mem_taskdb_clear_completed_jobs(bx_mem_taskdb* t, uint64_t* cleared) {
+    if (!t) return "bx_mem_taskdb_clear_completed_jobs: NULL argument";
+    try {
+        std::lock_guard<std::mutex> g(t->mu);
+        uint64_t n_done = 0;
+        for (auto& j : t->jobs) n_done += j.state == BX_JOB_DONE;
+        if (cleared) *cleared = n_done;
+        if (!n_done) return nullptr;
+        // build the surviving tables beside the old ones, then swap: a failure half way leaves the table as it was
+        const uint32_t GONE = 0xFFFFFFFFu;
+        std::vector<uint32_t> job_map(t->jobs.size(), GONE), row_map(t->rows.size(), GONE);
+        std::vector<bx_mem_taskdb::Job> jobs;
+        std::unordered_map<std::string, uint32_t> job_index, row_index;
+        for (size_t i = 0; i < t->jobs.size(); ++i)
+            if (t->jobs[i].state != BX_JOB_DONE) {
+                job_map[i] = (uint32_t)jobs.size();
+                job_index.emplace(t->jobs[i].id, job_map[i]);
+                jobs.push_back(t->jobs[i]);
+            }
+        uint32_t kept = 0;
+        for (size_t i = 0; i < t->rows.size(); ++i)
+            if (job_map[t->rows[i].job_ix] != GONE) row_map[i] = kept++;
+        std::deque<bx_mem_taskdb::Row> rows;
+        std::map<std::string, std::set<std::pair<uint32_t, uint32_t>>> ready;
+        uint64_t counts[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < t->rows.size(); ++i) {
+            if (row_map[i] == GONE) continue;
+            bx_mem_taskdb::Row r = t->rows[i];  // a copy: the old table stays whole until the swap
+            r.job_ix = job_map[r.job_ix];
+            for (uint32_t& d : r.dependants) d = row_map[d];  // dependants are rows of the same job: they survive with it
+            row_index.emplace(bx_mem_taskdb::key(r.job.c_str(), r.task.c_str()), row_map[i]);
+            if (r.state == BX_TASK_READY) ready[r.stream].insert({r.job_ix, row_map[i]});
+            counts[r.state]++;
+            rows.push_back(std::move(r));
+        }
+        t->rows.swap(rows);
+        t->jobs.swap(jobs);
+        t->job_index.swap(job_index);
+        t->row_index.swap(row_index);
+        t->ready.swap(ready);
+        memcpy(t->counts, counts, sizeof counts);
+        return nullptr;
+    } catch (const std::exception&) {
+        return "bx_mem_taskdb_clear_completed_jobs: out of memory";
     }
 }
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state) {

@@ -127,7 +127,8 @@ const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* task_stream,
 /* taskdb::create_task (1_taskdb.sql:197-228): the task is 'pending' while any of its prerequisites (task ids of the same job,
  * which must exist) is not 'done', 'ready' otherwise; update_task_done on a prerequisite decrements waiting_on and releases
  * the task when it reaches zero (1_taskdb.sql:296-306); update_task_failed also applies to pending tasks (:324).
- * request_work hands out the oldest ready task of the worker type (created_at ASC, :243-247).  Every operation is O(log rows):
+ * request_work hands out the oldest ready task of the OLDEST job of the worker type (job_created_at ASC, created_at ASC:
+ * 9_request_work.sql:139-141 — job-level FIFO: a job's late-created joins go before a younger job's proves).  Every operation is O(log rows):
  * a 2^16-segment job (131 075 rows) is planned and drained in a second (tests/test_taskdb_model_cpu.py, which also checks the
  * table against a row-by-row restatement of the SQL on random operation sequences).  One difference: a prerequisite listed
  * twice is released twice here; the SQL counts it twice and releases it once, which leaves the task pending for ever. */
@@ -136,6 +137,10 @@ const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char*
                                                    int32_t max_retries);
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const char* task_id, bx_task_info* out);
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
+/* clear_completed_jobs (bento/crates/taskdb/migrations/4_clear_completed_streams.sql): every row of every 'done' job leaves the
+ * table (the maintenance call that keeps a long-lived table bounded); *cleared (may be NULL) = the number of jobs removed.
+ * Failed and running jobs stay. */
+const char* bx_mem_taskdb_clear_completed_jobs(bx_mem_taskdb* t, uint64_t* cleared);
 /* job_state (1_taskdb.sql:5-9), a stored row as in the reference: running; -> done by the update_task_done that leaves no task
  * of the job in another state (:308-311; a task created afterwards does not reopen it); -> failed, with that task's error, by the
  * FIRST update_task_failed in time (:333-340).  The row is created with the job's first task (the reference's create_job). */

@@ -1,7 +1,7 @@
 """CPU: the in-memory task db against a row-by-row restatement of the reference's SQL, on random operation sequences.
 
-Reference: bento/crates/taskdb/migrations/1_taskdb.sql — create_task (:197-228), request_work (:231-266: the oldest ready task of
-the worker type's stream, created_at ASC), update_task_done (:278-314), update_task_failed (:316-347), update_task_retry (:361-391),
+Reference: bento/crates/taskdb/migrations/1_taskdb.sql — create_task (:197-228), request_work (as replaced by 9_request_work.sql
+:118-167: the oldest ready task of the OLDEST job, `ORDER BY job_created_at ASC, created_at ASC`), update_task_done (:278-314), update_task_failed (:316-347), update_task_retry (:361-391),
 the job row's state and error (:287-311, :333-340).  `Model` below is that SQL with Python lists for tables; the library
 (csrc/agent.cpp: bx_mem_taskdb) must agree with it after every operation — on every row, every job and every return value.
 
@@ -55,6 +55,9 @@ class Lib:
     def retry(self, job, task):
         return self._retry(self.u, job.encode(), task.encode(), None, 0) == 1
 
+    def clear_completed_jobs(self):
+        return self.db.clear_completed_jobs()
+
     def current_retries(self, job, task):
         r = C.c_int32(-1)
         rc = self._cur(self.u, job.encode(), task.encode(), C.byref(r), None, 0)
@@ -67,7 +70,7 @@ class Model:
     def __init__(self):
         self.tasks = []  # dict rows, insertion order = created_at order
         self.deps = []   # (job, pre, post)
-        self.jobs = {}   # job -> {"state", "error"}
+        self.jobs = {}   # job -> {"state", "error", "created"}; dicts keep insertion order = job_created_at order
 
     def _row(self, job, task):
         for r in self.tasks:
@@ -80,7 +83,9 @@ class Model:
             return False
         if any(self._row(job, p) is None for p in pre):  # FOREIGN KEY (job_id, pre_task_id)
             return False
-        self.jobs.setdefault(job, {"state": "running", "error": ""})  # the library creates the job row with its first task
+        if job not in self.jobs:
+            self.n_jobs_ever = getattr(self, "n_jobs_ever", 0) + 1
+            self.jobs[job] = {"state": "running", "error": "", "created": self.n_jobs_ever}  # the job row comes with its first task
         row = dict(stream=stream, job=job, task=task, state="pending", waiting_on=0, retries=0, max_retries=max_retries, error="", output="")
         self.tasks.append(row)
         for p in pre:
@@ -91,11 +96,20 @@ class Model:
         return True
 
     def request_work(self, stream):
-        for r in self.tasks:  # ORDER BY created_at ASC LIMIT 1
-            if r["stream"] == stream and r["state"] == "ready":
-                r["state"] = "running"
-                return (r["job"], r["task"], r["max_retries"])
-        return None
+        ready = [(self.jobs[r["job"]]["created"], i) for i, r in enumerate(self.tasks) if r["stream"] == stream and r["state"] == "ready"]
+        if not ready:
+            return None
+        r = self.tasks[min(ready)[1]]  # ORDER BY job_created_at ASC, created_at ASC LIMIT 1
+        r["state"] = "running"
+        return (r["job"], r["task"], r["max_retries"])
+
+    def clear_completed_jobs(self):
+        gone = [j for j, row in self.jobs.items() if row["state"] == "done"]
+        self.tasks = [t for t in self.tasks if t["job"] not in gone]
+        self.deps = [d for d in self.deps if d[0] not in gone]
+        for j in gone:
+            del self.jobs[j]
+        return len(gone)
 
     def done(self, job, task, output):
         r = self._row(job, task)
@@ -160,7 +174,8 @@ def test_random_operation_sequences_agree_with_the_sql(seed):
     jobs, streams = ["J0", "J1", "J2"][: 1 + seed % 3], ["prove", "join", "aux"]
     names = {j: [] for j in jobs}
     for step in range(220):
-        kind = rng.choices(["create", "request", "done", "failed", "retry", "current"], weights=[30, 25, 25, 3 if seed % 4 else 0, 10, 5])[0]
+        kind = rng.choices(["create", "request", "done", "failed", "retry", "current", "clear"],
+                           weights=[30, 25, 25, 3 if seed % 4 else 0, 10, 5, 2 if seed % 2 else 0])[0]
         job = rng.choice(jobs)
         known = names[job]
         pick = (lambda: rng.choice(known)) if known else (lambda: "none")
@@ -185,6 +200,14 @@ def test_random_operation_sequences_agree_with_the_sql(seed):
         elif kind == "retry":
             args = (job, pick())
             a, b = lib.retry(*args), model.retry(*args)
+        elif kind == "clear":
+            args = ()
+            a, b = lib.clear_completed_jobs(), model.clear_completed_jobs()
+            for j in jobs:
+                if j not in model.jobs:
+                    names[j] = []  # the job is gone: its ids are free again, and a new task re-creates the job row (youngest)
+                    with pytest.raises(HalError, match="no such job"):
+                        lib.db.job(j)
         else:
             args = (job, pick())
             a, b = lib.current_retries(*args), model.current_retries(*args)
@@ -241,3 +264,50 @@ def test_a_job_of_65536_segments_is_planned_and_drained_in_linear_time():
     assert order[:k] == [str(i) for i in range(k)] or set(order[:k]) <= set(ids)  # proves first: they were created first and ready
     assert order[-2:] == ["resolve", "finalize"]
     assert wall < 30, wall  # ~1.5 s here; the bound only separates linear from quadratic
+
+
+def test_request_work_is_job_level_fifo():
+    """9_request_work.sql:139-141: a job's tasks go before a younger job's, whenever they were created — here A's join is created
+    (and becomes ready) after all of B's proves, and is still claimed before them."""
+    lib, model = Lib(), Model()
+    for t in (lib, model):
+        assert t.create_task("prove", "A", "0", [], 0) and t.create_task("prove", "A", "1", [], 0)
+        assert t.create_task("prove", "B", "0", [], 0) and t.create_task("prove", "B", "1", [], 0)
+        assert t.create_task("prove", "A", "2", ["0", "1"], 0)
+        got = []
+        while (w := t.request_work("prove")) is not None:
+            got.append(w[:2])
+            assert t.done(w[0], w[1], "null")
+        assert got == [("A", "0"), ("A", "1"), ("A", "2"), ("B", "0"), ("B", "1")]
+    compare(lib, model, [])
+
+
+def test_clear_completed_jobs_drops_done_jobs_only_and_the_rest_keeps_working():
+    lib = Lib()
+    for job in ("done-1", "run", "done-2", "bad"):
+        lib.db.plan_job(job, 3, aux_stream="prove")
+    for job in ("done-1", "done-2"):
+        for t in ["0", "1", "2", "3", "4", "resolve", "finalize"]:
+            assert lib.done(job, t, "null")
+    assert lib.failed("bad", "1", "boom")
+    assert lib.done("run", "0", "null") and lib.done("run", "1", "null")  # its first join (task 3) is ready now
+    before = {t: lib.db.task("run", t) for t in ["0", "1", "2", "3", "4", "resolve", "finalize"]}
+    assert lib.clear_completed_jobs() == 2 and lib.clear_completed_jobs() == 0
+    for job in ("done-1", "done-2"):
+        with pytest.raises(HalError, match="no such job"):
+            lib.db.job(job)
+        with pytest.raises(HalError, match="no such task"):
+            lib.db.task(job, "0")
+    after = {t: lib.db.task("run", t) for t in before}
+    assert {t: (r.state, r.waiting_on) for t, r in after.items()} == {t: (r.state, r.waiting_on) for t, r in before.items()}
+    assert lib.db.job("bad")["state"] == "failed" and lib.db.job("run")["state"] == "running"
+    assert lib.db.count("done") == 2 and lib.db.count("failed") == 1
+    # the surviving job runs to its end: dependants lists, ready sets and the index were rebuilt consistently
+    order = []
+    while (w := lib.request_work("prove")) is not None:
+        order.append(w[:2])
+        assert lib.done(w[0], w[1], "null")
+    assert [t for j, t in order if j == "run"] == ["2", "3", "4", "resolve", "finalize"]
+    assert lib.db.job("run")["state"] == "done"
+    lib.db.plan_job("done-1", 1, aux_stream="prove")  # a cleared job id may be used again
+    assert lib.db.job("done-1")["tasks"] == 3
