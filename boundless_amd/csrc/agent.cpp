@@ -1346,9 +1346,24 @@ struct bx_agent {
             cur ^= 1;
             return true;
         };
+        bool prefetching = cfg.prefetch != 0;
+        // ends the fetcher and returns the task it claimed that the lane never took (still 'running' in the task db), if any
+        auto stop_fetcher = [&]() -> std::unique_ptr<Fetched> {
+            if (!prefetching) return nullptr;
+            prefetching = false;
+            std::unique_ptr<Fetched> left = pf.quit();
+            fetcher.join();
+            if (!left) {
+                std::lock_guard<std::mutex> l(pf.mu);
+                left = std::move(pf.slot);  // put() raced with quit()
+            }
+            if (left && left->rc != 1) left.reset();
+            return left;
+        };
+        bool fatal_seen = false;
         while (!stop.load(std::memory_order_relaxed)) {
             std::unique_ptr<Fetched> w;
-            if (cfg.prefetch) {
+            if (prefetching) {
                 w = pf.take(stop);
                 if (!w) break;  // stop requested
                 if (w->rc == 0) {
@@ -1366,30 +1381,38 @@ struct bx_agent {
             }
             if (w->rc < 0) {
                 set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + w->eb);
+                fatal_seen = true;
                 break;
             }
             if (w->rc == 0) {
                 // a finish still in flight may requeue its task (retry): only a poll made with nothing pending counts as idle
                 if (fin.wait_idle()) continue;
-                if (max_idle_polls >= 0 && ++idle >= max_idle_polls) break;
+                if (max_idle_polls >= 0 && ++idle >= max_idle_polls) {
+                    // out of idle polls.  A task the fetcher holds is not idleness: its completion may release dependants that no
+                    // other lane is left to claim, so the lane runs it and goes on polling (serially from here) until idle again
+                    if (std::unique_ptr<Fetched> left = stop_fetcher()) {
+                        if (!run_claimed(*left)) {
+                            fatal_seen = true;
+                            break;
+                        }
+                        continue;
+                    }
+                    break;
+                }
                 // sleep poll_time in slices so a stop request is honoured promptly
                 auto until = Clock::now() + std::chrono::duration<double>(cfg.poll_time);
                 while (!stop.load(std::memory_order_relaxed) && Clock::now() < until)
                     std::this_thread::sleep_for(std::chrono::duration<double>(std::min(cfg.poll_time, 0.05)));
                 continue;
             }
-            if (!run_claimed(*w)) break;
-        }
-        if (cfg.prefetch) {
-            // a task the fetcher claimed and the lane never took is still 'running' in the task db: it is run now, not lost
-            std::unique_ptr<Fetched> left = pf.quit();
-            fetcher.join();
-            if (!left) {
-                std::lock_guard<std::mutex> l(pf.mu);
-                left = std::move(pf.slot);  // put() raced with quit()
+            if (!run_claimed(*w)) {
+                fatal_seen = true;
+                break;
             }
-            if (left && left->rc == 1) (void)run_claimed(*left);
         }
+        // stop request or fatal error: a task the fetcher claimed is still run (not lost), unless the task db itself is failing
+        if (std::unique_ptr<Fetched> left = stop_fetcher())
+            if (!fatal_seen) (void)run_claimed(*left);
         fin.quit();
         finisher.join();
     }

@@ -158,11 +158,15 @@ def expected_root(n, seg_po2, join_po2, base_seed):
     return root, seals[root]
 
 
+@pytest.mark.parametrize("prefetch", [False, True])
 @pytest.mark.parametrize("n,lanes", [(1, 1), (2, 2), (7, 3), (16, 4), (37, 5)])
-def test_a_planned_job_runs_to_its_rollup_receipt_through_the_lanes(n, lanes):
+def test_a_planned_job_runs_to_its_rollup_receipt_through_the_lanes(n, lanes, prefetch):
+    """prefetch: every lane claims one task ahead (include/bx_agent.h).  A lane that runs out of idle polls while its fetcher holds
+    a task runs that task and keeps polling — the task's completion may release the job's last tasks when every other lane has
+    already left."""
     base = 0xB0D1E550000
     prover = FakeProver(fail_once={(11, 2 * n - 2)} if n > 1 else ())  # the ROOT join fails once and is retried
-    a = ag.Agent(prover=prover, verify=False, poll_time=0.002, inflight=lanes, join_po2=11, also_streams="aux")
+    a = ag.Agent(prover=prover, verify=False, poll_time=0.002, inflight=lanes, join_po2=11, also_streams="aux", prefetch=prefetch)
     try:
         for i in range(n):
             a.store.set_key_with_expiry(f"job:J:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=13)), 600)
