@@ -30,7 +30,8 @@ class _HotStoreOps(C.Structure):
 
 class _TaskDbOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("request_work", C.c_void_p), ("update_task_done", C.c_void_p),
-                ("update_task_failed", C.c_void_p), ("update_task_retry", C.c_void_p), ("current_retries", C.c_void_p)]
+                ("update_task_failed", C.c_void_p), ("update_task_retry", C.c_void_p), ("current_retries", C.c_void_p),
+                ("requeue_tasks", C.c_void_p)]
 
 
 _SEAL_WORDS_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32)
@@ -55,7 +56,7 @@ class _ReadyTask(C.Structure):
 
 class _TaskInfo(C.Structure):
     _fields_ = [("state", C.c_int32), ("retries", C.c_int32), ("max_retries", C.c_int32), ("error", C.c_char * 1100),
-                ("output", C.c_char * 256), ("waiting_on", C.c_int32), ("created_s", C.c_double), ("started_s", C.c_double),
+                ("output", C.c_char * 256), ("waiting_on", C.c_int32), ("timeout_secs", C.c_int32), ("created_s", C.c_double), ("started_s", C.c_double),
                 ("updated_s", C.c_double)]
 
 
@@ -66,7 +67,8 @@ class _JobInfo(C.Structure):
 
 class _JobPlan(C.Structure):
     _fields_ = [("prove_stream", C.c_char * 64), ("join_stream", C.c_char * 64), ("aux_stream", C.c_char * 64), ("prove_retries", C.c_int32),
-                ("join_retries", C.c_int32), ("resolve_retries", C.c_int32), ("finalize_retries", C.c_int32), ("subtree_only", C.c_int32)]
+                ("join_retries", C.c_int32), ("resolve_retries", C.c_int32), ("finalize_retries", C.c_int32), ("subtree_only", C.c_int32),
+                ("prove_timeout", C.c_int32), ("join_timeout", C.c_int32), ("resolve_timeout", C.c_int32), ("finalize_timeout", C.c_int32)]
 
 
 class _AgentConfig(C.Structure):
@@ -74,7 +76,8 @@ class _AgentConfig(C.Structure):
                 ("w_accum", C.c_uint32), ("redis_ttl", C.c_uint64), ("poll_time", C.c_double), ("no_verify", C.c_int32),
                 ("task_stream", C.c_char * 64), ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16), ("synthetic", C.c_int32),
                 ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32), ("po2_min", C.c_uint32), ("po2_max", C.c_uint32),
-                ("max_shapes", C.c_uint32), ("join_po2", C.c_uint32), ("also_streams", C.c_char * 128), ("lift_po2", C.c_uint32), ("prefetch", C.c_int32)]
+                ("max_shapes", C.c_uint32), ("join_po2", C.c_uint32), ("also_streams", C.c_char * 128), ("lift_po2", C.c_uint32), ("prefetch", C.c_int32), ("monitor_requeue", C.c_int32),
+                ("requeue_poll_interval", C.c_double)]
 
 
 def _lib():
@@ -91,6 +94,9 @@ def _lib():
         "bx_mem_taskdb_create_task": ([vp, cp, cp, cp, cp, C.c_int32], cp),
         "bx_mem_taskdb_task_info": ([vp, cp, cp, C.POINTER(_TaskInfo)], cp), "bx_mem_taskdb_count": ([vp, C.c_int32], sz),
         "bx_mem_taskdb_clear_completed_jobs": ([vp, C.POINTER(C.c_uint64)], cp),
+        "bx_mem_taskdb_create_task_ex": ([vp, cp, cp, cp, cp, C.POINTER(C.c_char_p), sz, C.c_int32, C.c_int32], cp),
+        "bx_mem_taskdb_requeue_tasks": ([vp, C.c_int64, C.POINTER(C.c_uint64)], cp),
+        "bx_mem_taskdb_advance_clock": ([vp, C.c_double], cp),
         "bx_mem_taskdb_create_task_with_prereqs": ([vp, cp, cp, cp, cp, C.POINTER(cp), sz, C.c_int32], cp),
         "bx_mem_taskdb_job_info": ([vp, cp, C.POINTER(_JobInfo)], cp),
         "bx_plan_job": ([vp, cp, C.c_uint64, C.POINTER(_JobPlan), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], cp),
@@ -210,6 +216,7 @@ class TaskRow:
         self.retries, self.max_retries = info.retries, info.max_retries
         self.error, self.output = info.error.decode(), info.output.decode()
         self.waiting_on = info.waiting_on
+        self.timeout_secs = info.timeout_secs
         self.created_s, self.started_s, self.updated_s = info.created_s, info.started_s, info.updated_s
 
 
@@ -224,20 +231,33 @@ class TaskDb:
         self.ops = self._lib.bx_mem_taskdb_ops(self._h)
         self._ids = []
 
-    def create_task(self, job_id, task_id, task_def, max_retries=3, stream="prove", prerequisites=()):
-        """taskdb::create_task (1_taskdb.sql:197-228): 'pending' while a prerequisite (task ids of the same job) is not done."""
+    def create_task(self, job_id, task_id, task_def, max_retries=3, stream="prove", prerequisites=(), timeout_secs=None):
+        """taskdb::create_task (1_taskdb.sql:197-228): 'pending' while a prerequisite (task ids of the same job) is not done.
+        timeout_secs: how long the task may stay running before `requeue_tasks` retries it (None = never)."""
         d = task_def if isinstance(task_def, str) else json.dumps(task_def)
         pre = [str(p).encode() for p in prerequisites]
         arr = (C.c_char_p * max(len(pre), 1))(*pre)
-        _check(self._lib.bx_mem_taskdb_create_task_with_prereqs(self._h, stream.encode(), str(job_id).encode(), str(task_id).encode(),
-                                                                d.encode(), arr, len(pre), max_retries))
+        _check(self._lib.bx_mem_taskdb_create_task_ex(self._h, stream.encode(), str(job_id).encode(), str(task_id).encode(), d.encode(), arr,
+                                                      len(pre), max_retries, 0x7FFFFFFF if timeout_secs is None else int(timeout_secs)))
         self._ids.append((str(job_id), str(task_id)))
 
-    def plan_job(self, job_id, n_segments, prove_stream="", join_stream="", aux_stream="", retries=3, subtree_only=False):
+    def requeue_tasks(self, limit=100):
+        """taskdb::requeue_tasks (bento/crates/taskdb/src/lib.rs:328-358): running tasks past their timeout go through update_task_retry;
+        returns how many had timed out."""
+        n = C.c_uint64()
+        _check(self._lib.bx_mem_taskdb_requeue_tasks(self._h, limit, C.byref(n)))
+        return n.value
+
+    def advance_clock(self, seconds):
+        """Test hook: the table's clock jumps forward."""
+        _check(self._lib.bx_mem_taskdb_advance_clock(self._h, float(seconds)))
+
+    def plan_job(self, job_id, n_segments, prove_stream="", join_stream="", aux_stream="", retries=3, subtree_only=False, timeouts=(0, 0, 0, 0)):
         """bx_plan_job: the executor's planner loop (executor.rs:566-698) — one task row per planner task, prerequisites as the
         planner's dependencies.  Returns the task ids created, in creation order; `self.root_task` = the task whose receipt is the
         job's root.  subtree_only: stop at the root join (no resolve / finalize): one GPU's share of a larger job."""
-        plan = _JobPlan(prove_stream.encode(), join_stream.encode(), aux_stream.encode(), retries, retries, retries, retries, int(subtree_only))
+        plan = _JobPlan(prove_stream.encode(), join_stream.encode(), aux_stream.encode(), retries, retries, retries, retries, int(subtree_only),
+                        *timeouts)  # prove, join, resolve, finalize timeout_secs; 0 = the reference's defaults 30 / 10 / 120 / 10
         n, root = C.c_uint64(), C.c_uint64()
         _check(self._lib.bx_plan_job(self._h, str(job_id).encode(), n_segments, C.byref(plan), C.byref(n), C.byref(root)))
         self.root_task = root.value
@@ -323,7 +343,8 @@ class Agent:
 
     def __init__(self, prover=None, device=0, inflight=None, widths=(16, 256, 64), redis_ttl=8 * 60 * 60, poll_time=1.0,
                  verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20, devices=None, synthetic=True,
-                 terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None, join_po2=0, also_streams="", lift_po2=0, prefetch=False):
+                 terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None, join_po2=0, also_streams="", lift_po2=0, prefetch=False,
+                 monitor_requeue=False, requeue_poll_interval=0.0):
         self._lib = _lib()
         self.store = store or HotStore()
         self.taskdb = taskdb or TaskDb()
@@ -333,7 +354,8 @@ class Agent:
                            w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, no_verify=int(not verify),
                            task_stream=task_stream.encode(), synthetic=int(bool(synthetic)), cons_terms=terms, cons_degree=degree,
                            po2_min=po2_range[0], po2_max=po2_range[1], max_shapes=max_shapes, join_po2=join_po2,
-                           also_streams=also_streams.encode(), lift_po2=lift_po2, prefetch=int(bool(prefetch)))
+                           also_streams=also_streams.encode(), lift_po2=lift_po2, prefetch=int(bool(prefetch)),
+                           monitor_requeue=int(bool(monitor_requeue)), requeue_poll_interval=requeue_poll_interval)
         if devices:
             cfg.n_devices = len(devices)
             for i, d in enumerate(devices):

@@ -416,6 +416,7 @@ struct bx_mem_taskdb {
     struct Row {
         std::string stream, job, task, def, error, output;
         int32_t max_retries = 0, retries = 0, state = BX_TASK_READY;
+        int32_t timeout_secs = INT32_MAX;  // tasks.timeout_secs: how long the task may stay 'running' before requeue_tasks retries it
         uint32_t job_ix = 0;
         std::vector<uint32_t> dependants;  // task_deps rows with this task as pre_task_id: the rows to release when it is done
         int32_t waiting_on = 0;            // prerequisites not yet done
@@ -436,7 +437,9 @@ struct bx_mem_taskdb {
     std::map<std::string, std::set<std::pair<uint32_t, uint32_t>>> ready;
     uint64_t counts[5] = {0, 0, 0, 0, 0};
     Clock::time_point epoch = Clock::now();
-    double now_s() const { return secs_since(epoch); }
+    double clock_skew = 0;  // bx_mem_taskdb_advance_clock: tests move time instead of sleeping
+    double now_s() const { return secs_since(epoch) + clock_skew; }
+    std::set<uint32_t> running;  // rows in state 'running': what requeue_tasks scans
     static std::string key(const char* job, const char* task) {
         std::string k(job);
         k.push_back('\0');
@@ -452,7 +455,9 @@ struct bx_mem_taskdb {
         if (r->state == s) return;
         const uint32_t ix = index_of(r);
         if (s == BX_TASK_READY) ready[r->stream].insert({r->job_ix, ix});  // may throw: before anything else changes
+        if (s == BX_TASK_RUNNING) running.insert(ix);                      // (at most one of the two inserts happens per call)
         if (r->state == BX_TASK_READY) ready[r->stream].erase({r->job_ix, ix});
+        if (r->state == BX_TASK_RUNNING) running.erase(ix);
         Job& j = jobs[r->job_ix];
         counts[r->state]--, j.counts[r->state]--;
         counts[s]++, j.counts[s]++;
@@ -531,22 +536,45 @@ static int tdb_failed(void* user, const char* job, const char* task, const char*
     }
 }
 // 1_taskdb.sql:361-391
+static int retry_locked(bx_mem_taskdb* t, bx_mem_taskdb::Row* r) {
+    if (!r || r->state != BX_TASK_RUNNING) return 0;
+    t->set_state_locked(r, BX_TASK_READY);
+    r->retries += 1;
+    r->updated = t->now_s();
+    r->error.clear();
+    if (r->retries > r->max_retries) {
+        t->fail_locked(r, "retry max hit");
+        return 0;
+    }
+    return 1;
+}
 static int tdb_retry(void* user, const char* job, const char* task, char*, size_t) {
     auto* t = (bx_mem_taskdb*)user;
     try {
         std::lock_guard<std::mutex> g(t->mu);
-        auto* r = t->find_locked(job, task);
-        if (!r || r->state != BX_TASK_RUNNING) return 0;
-        t->set_state_locked(r, BX_TASK_READY);
-        r->retries += 1;
-        r->updated = t->now_s();
-        r->error.clear();
-        if (r->retries > r->max_retries) {
-            t->fail_locked(r, "retry max hit");
-            return 0;
-        }
-        return 1;
+        return retry_locked(t, t->find_locked(job, task));
     } catch (...) {
+        return -1;
+    }
+}
+// taskdb::requeue_tasks (bento/crates/taskdb/src/lib.rs:328-358): up to `limit` tasks that have been 'running' for longer than their
+// timeout_secs since GREATEST(started_at, updated_at) go through update_task_retry — back to 'ready' with one more retry, or
+// 'failed' ("retry max hit") when that exceeds max_retries.  Returns the number of timed-out tasks found, < 0 on error.
+static int64_t tdb_requeue(void* user, int64_t limit, char* errbuf, size_t cap) {
+    auto* t = (bx_mem_taskdb*)user;
+    try {
+        std::lock_guard<std::mutex> g(t->mu);
+        const double now = t->now_s();
+        std::vector<uint32_t> timed_out;
+        for (uint32_t ix : t->running) {
+            if (limit >= 0 && (int64_t)timed_out.size() >= limit) break;
+            const bx_mem_taskdb::Row& r = t->rows[ix];
+            if ((double)r.timeout_secs < now - std::max(r.started, r.updated)) timed_out.push_back(ix);
+        }
+        for (uint32_t ix : timed_out) (void)retry_locked(t, &t->rows[ix]);
+        return (int64_t)timed_out.size();
+    } catch (const std::exception&) {
+        snprintf(errbuf, cap, "requeue_tasks: out of memory");
         return -1;
     }
 }
@@ -1458,15 +1486,34 @@ const char* bx_mem_taskdb_create(bx_mem_taskdb** out) {
 }
 void bx_mem_taskdb_destroy(bx_mem_taskdb* t) { delete t; }
 bx_taskdb_ops bx_mem_taskdb_ops(bx_mem_taskdb* t) {
-    return bx_taskdb_ops{t, tdb_request_work, tdb_done, tdb_failed, tdb_retry, tdb_current_retries};
+    return bx_taskdb_ops{t, tdb_request_work, tdb_done, tdb_failed, tdb_retry, tdb_current_retries, tdb_requeue};
 }
 const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
                                       int32_t max_retries) {
-    return bx_mem_taskdb_create_task_with_prereqs(t, stream, job, task, def, nullptr, 0, max_retries);
+    return bx_mem_taskdb_create_task_ex(t, stream, job, task, def, nullptr, 0, max_retries, INT32_MAX);
 }
-// taskdb::create_task, 1_taskdb.sql:197-228
 const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
                                                    const char* const* prereqs, size_t n_prereqs, int32_t max_retries) {
+    return bx_mem_taskdb_create_task_ex(t, stream, job, task, def, prereqs, n_prereqs, max_retries, INT32_MAX);
+}
+const char* bx_mem_taskdb_advance_clock(bx_mem_taskdb* t, double seconds) {
+    if (!t) return "bx_mem_taskdb_advance_clock: NULL argument";
+    if (!(seconds >= 0)) return "bx_mem_taskdb_advance_clock: time only moves forward";
+    std::lock_guard<std::mutex> g(t->mu);
+    t->clock_skew += seconds;
+    return nullptr;
+}
+const char* bx_mem_taskdb_requeue_tasks(bx_mem_taskdb* t, int64_t limit, uint64_t* timed_out) {
+    if (!t) return "bx_mem_taskdb_requeue_tasks: NULL argument";
+    char eb[128] = {0};
+    int64_t n = tdb_requeue(t, limit, eb, sizeof eb);
+    if (n < 0) return fail(eb);
+    if (timed_out) *timed_out = (uint64_t)n;
+    return nullptr;
+}
+// taskdb::create_task, 1_taskdb.sql:197-228
+const char* bx_mem_taskdb_create_task_ex(bx_mem_taskdb* t, const char* stream, const char* job, const char* task, const char* def,
+                                         const char* const* prereqs, size_t n_prereqs, int32_t max_retries, int32_t timeout_secs) {
     try {
         if (!t || !stream || !job || !task || !def || (n_prereqs && !prereqs)) return "bx_mem_taskdb_create_task: NULL argument";
         std::lock_guard<std::mutex> g(t->mu);
@@ -1478,6 +1525,7 @@ const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char*
         r.task = task;
         r.def = def;
         r.max_retries = max_retries;
+        r.timeout_secs = timeout_secs;
         r.created = t->now_s();
         std::vector<uint32_t> pres;
         for (size_t i = 0; i < n_prereqs; ++i) {
@@ -1573,6 +1621,11 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
         memset(&plan, 0, sizeof plan);
         if (plan_in) plan = *plan_in;
         else plan.prove_retries = plan.join_retries = plan.resolve_retries = plan.finalize_retries = 3;
+        // the agent's defaults (bento/crates/workflow/src/lib.rs:108-136), handed to create_task as timeout_secs (executor.rs:82,144,206,226)
+        if (plan.prove_timeout <= 0) plan.prove_timeout = 30;
+        if (plan.join_timeout <= 0) plan.join_timeout = 10;
+        if (plan.resolve_timeout <= 0) plan.resolve_timeout = 120;
+        if (plan.finalize_timeout <= 0) plan.finalize_timeout = 10;
         plan.prove_stream[sizeof plan.prove_stream - 1] = plan.join_stream[sizeof plan.join_stream - 1] = plan.aux_stream[sizeof plan.aux_stream - 1] = 0;
         const std::string prove_stream = plan.prove_stream[0] ? plan.prove_stream : "prove";
         const std::string join_stream = plan.join_stream[0] ? plan.join_stream : prove_stream;
@@ -1585,16 +1638,17 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
             const char* e = nullptr;
             switch (tt.command) {
                 case BX_PLAN_SEGMENT:  // the segment INDEX, not the planner's task number, goes into the request (executor.rs:94-104)
-                    e = bx_mem_taskdb_create_task(t, prove_stream.c_str(), job, name.c_str(),
-                                                  ("{\"Prove\":{\"index\":" + std::to_string(segment_index) + "}}").c_str(), plan.prove_retries);
+                    e = bx_mem_taskdb_create_task_ex(t, prove_stream.c_str(), job, name.c_str(),
+                                                     ("{\"Prove\":{\"index\":" + std::to_string(segment_index) + "}}").c_str(), nullptr, 0,
+                                                     plan.prove_retries, plan.prove_timeout);
                     created += !e;
                     break;
                 case BX_PLAN_JOIN: {
                     const std::string l = std::to_string(tt.depends_on[0]), r = std::to_string(tt.depends_on[1]);
                     const char* pre[2] = {l.c_str(), r.c_str()};
-                    e = bx_mem_taskdb_create_task_with_prereqs(t, join_stream.c_str(), job, name.c_str(),
-                                                               ("{\"Join\":{\"idx\":" + name + ",\"left\":" + l + ",\"right\":" + r + "}}").c_str(), pre, 2,
-                                                               plan.join_retries);
+                    e = bx_mem_taskdb_create_task_ex(t, join_stream.c_str(), job, name.c_str(),
+                                                     ("{\"Join\":{\"idx\":" + name + ",\"left\":" + l + ",\"right\":" + r + "}}").c_str(), pre, 2,
+                                                     plan.join_retries, plan.join_timeout);
                     created += !e;
                     break;
                 }
@@ -1603,14 +1657,15 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
                     if (plan.subtree_only) break;  // the root receipt is handed to whoever joins the subtrees
                     const std::string m = std::to_string(tt.depends_on[0]);
                     const char* pre[1] = {m.c_str()};
-                    e = bx_mem_taskdb_create_task_with_prereqs(t, join_stream.c_str(), job, "resolve",
-                                                               ("{\"Resolve\":{\"max_idx\":" + m + ",\"union_max_idx\":null}}").c_str(), pre, 1,
-                                                               plan.resolve_retries);
+                    e = bx_mem_taskdb_create_task_ex(t, join_stream.c_str(), job, "resolve",
+                                                     ("{\"Resolve\":{\"max_idx\":" + m + ",\"union_max_idx\":null}}").c_str(), pre, 1,
+                                                     plan.resolve_retries, plan.resolve_timeout);  // x assumption_count, which is 1 here
                     created += !e;
                     if (!e) {
                         const char* pre2[1] = {"resolve"};
-                        e = bx_mem_taskdb_create_task_with_prereqs(t, aux_stream.c_str(), job, "finalize",
-                                                                   ("{\"Finalize\":{\"max_idx\":" + m + "}}").c_str(), pre2, 1, plan.finalize_retries);
+                        e = bx_mem_taskdb_create_task_ex(t, aux_stream.c_str(), job, "finalize",
+                                                         ("{\"Finalize\":{\"max_idx\":" + m + "}}").c_str(), pre2, 1, plan.finalize_retries,
+                                                         plan.finalize_timeout);
                         created += !e;
                     }
                     break;
@@ -1670,6 +1725,7 @@ const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job, const cha
         out->retries = r->retries;
         out->max_retries = r->max_retries;
         out->waiting_on = r->waiting_on;
+        out->timeout_secs = r->timeout_secs;
         out->created_s = r->created;
         out->started_s = r->started;
         out->updated_s = r->updated;
@@ -1705,6 +1761,7 @@ const char* bx_mem_taskdb_clear_completed_jobs(bx_mem_taskdb* t, uint64_t* clear
             if (job_map[t->rows[i].job_ix] != GONE) row_map[i] = kept++;
         std::deque<bx_mem_taskdb::Row> rows;
         std::map<std::string, std::set<std::pair<uint32_t, uint32_t>>> ready;
+        std::set<uint32_t> running;
         uint64_t counts[5] = {0, 0, 0, 0, 0};
         for (size_t i = 0; i < t->rows.size(); ++i) {
             if (row_map[i] == GONE) continue;
@@ -1713,6 +1770,7 @@ const char* bx_mem_taskdb_clear_completed_jobs(bx_mem_taskdb* t, uint64_t* clear
             for (uint32_t& d : r.dependants) d = row_map[d];  // dependants are rows of the same job: they survive with it
             row_index.emplace(bx_mem_taskdb::key(r.job.c_str(), r.task.c_str()), row_map[i]);
             if (r.state == BX_TASK_READY) ready[r.stream].insert({r.job_ix, row_map[i]});
+            if (r.state == BX_TASK_RUNNING) running.insert(row_map[i]);
             counts[r.state]++;
             rows.push_back(std::move(r));
         }
@@ -1721,6 +1779,7 @@ const char* bx_mem_taskdb_clear_completed_jobs(bx_mem_taskdb* t, uint64_t* clear
         t->job_index.swap(job_index);
         t->row_index.swap(row_index);
         t->ready.swap(ready);
+        t->running.swap(running);
         memcpy(t->counts, counts, sizeof counts);
         return nullptr;
     } catch (const std::exception&) {
@@ -1896,6 +1955,34 @@ const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* ta
     std::atomic<uint64_t> done{0};
     std::vector<std::string> fatal;
     std::vector<std::thread> threads;
+    // the requeue monitor (lib.rs:283-303 -> poll_for_requeue :536-551): tasks that stayed 'running' past their timeout — their lane
+    // hung, or the process that claimed them died — go back to 'ready' for any other lane; runs beside the lanes until they are done
+    std::atomic<int> monitor_quit{0};
+    std::thread monitor;
+    if (a->cfg.monitor_requeue && a->taskdb.requeue_tasks) {
+        try {
+            monitor = std::thread([a, &monitor_quit] {
+                const double interval = a->cfg.requeue_poll_interval > 0 ? a->cfg.requeue_poll_interval : 5.0;
+                while (!monitor_quit.load(std::memory_order_relaxed) && !a->stop.load(std::memory_order_relaxed)) {
+                    char eb[256] = {0};
+                    (void)a->taskdb.requeue_tasks(a->taskdb.user, 100, eb, sizeof eb);  // an error is retried at the next tick, as in the reference
+                    auto until = Clock::now() + std::chrono::duration<double>(interval);
+                    while (!monitor_quit.load(std::memory_order_relaxed) && !a->stop.load(std::memory_order_relaxed) && Clock::now() < until)
+                        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(interval, 0.02)));
+                }
+            });
+        } catch (...) {
+            return "bx_agent_poll_work: could not start the requeue monitor";
+        }
+    }
+    struct MonitorJoin {
+        std::atomic<int>& quit;
+        std::thread& th;
+        ~MonitorJoin() {
+            quit.store(1);
+            if (th.joinable()) th.join();
+        }
+    } monitor_join{monitor_quit, monitor};
     try {
         fatal.resize(a->lanes.size());
         for (uint32_t l = 1; l < a->lanes.size(); ++l)

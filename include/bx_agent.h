@@ -94,6 +94,11 @@ typedef struct bx_taskdb_ops {
     int (*update_task_retry)(void* user, const char* job_id, const char* task_id, char* errbuf, size_t cap);
     int (*current_retries)(void* user, const char* job_id, const char* task_id, int32_t* retries, char* errbuf,
                            size_t cap);
+    /* taskdb::requeue_tasks (bento/crates/taskdb/src/lib.rs:328-358), what the agent's requeue monitor calls
+     * (cfg.monitor_requeue): up to `limit` tasks 'running' for longer than their timeout_secs go through update_task_retry.
+     * Returns the number of timed-out tasks found, < 0 on error.  May be NULL (a task db that requeues by itself, like the
+     * API server behind the REST worker protocol): the monitor is then not started. */
+    int64_t (*requeue_tasks)(void* user, int64_t limit, char* errbuf, size_t cap);
 } bx_taskdb_ops;
 
 /* In-memory implementations (thread-safe). The returned ops borrow the object; destroy it after the agent. */
@@ -115,6 +120,7 @@ typedef struct bx_task_info {
     char error[1100];
     char output[256];
     int32_t waiting_on;  /* prerequisites not yet done (tasks.waiting_on) */
+    int32_t timeout_secs; /* tasks.timeout_secs (INT32_MAX = created without one) */
     double created_s, started_s, updated_s; /* seconds since the task db was created: created_at, started_at (most recent claim),
                                              * updated_at (done | failed | retry); 0 = not yet */
 } bx_task_info;
@@ -135,6 +141,16 @@ const char* bx_mem_taskdb_create_task(bx_mem_taskdb* t, const char* task_stream,
 const char* bx_mem_taskdb_create_task_with_prereqs(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
                                                    const char* task_def_json, const char* const* prerequisites, size_t n_prerequisites,
                                                    int32_t max_retries);
+/* The full form (taskdb::create_task, bento/crates/taskdb/src/lib.rs:201-210): timeout_secs = how long the task may stay 'running'
+ * (since its claim or last update) before requeue_tasks sends it through update_task_retry.  The two shorter forms above create
+ * tasks that never time out (INT32_MAX). */
+const char* bx_mem_taskdb_create_task_ex(bx_mem_taskdb* t, const char* task_stream, const char* job_id, const char* task_id,
+                                         const char* task_def_json, const char* const* prerequisites, size_t n_prerequisites,
+                                         int32_t max_retries, int32_t timeout_secs);
+/* taskdb::requeue_tasks on this table (see bx_taskdb_ops::requeue_tasks); limit < 0 = no limit; *timed_out may be NULL. */
+const char* bx_mem_taskdb_requeue_tasks(bx_mem_taskdb* t, int64_t limit, uint64_t* timed_out);
+/* Test hook: the table's clock (created_at / started_at / updated_at / now) jumps `seconds` >= 0 forward. */
+const char* bx_mem_taskdb_advance_clock(bx_mem_taskdb* t, double seconds);
 const char* bx_mem_taskdb_task_info(bx_mem_taskdb* t, const char* job_id, const char* task_id, bx_task_info* out);
 size_t bx_mem_taskdb_count(bx_mem_taskdb* t, int32_t state);
 /* clear_completed_jobs (bento/crates/taskdb/migrations/4_clear_completed_streams.sql): every row of every 'done' job leaves the
@@ -170,6 +186,8 @@ typedef struct bx_job_plan {
     int32_t subtree_only; /* 1 = stop at the root join: no resolve / finalize tasks.  The job is one GPU's share of a larger job whose
                            * top levels another agent joins from the subtree roots (one process per GPU: the roots cross GPUs, the
                            * segments never do) */
+    int32_t prove_timeout, join_timeout, resolve_timeout, finalize_timeout; /* timeout_secs of the tasks created; <= 0 = the
+                           * agent's defaults 30 / 10 / 120 / 10 (bento/crates/workflow/src/lib.rs:108-136) */
 } bx_job_plan;
 /* root_task (may be NULL) receives the task number whose receipt is the job's root: the last join, or task 0 for a single segment. */
 const char* bx_plan_job(bx_mem_taskdb* t, const char* job_id, uint64_t n_segments, const bx_job_plan* plan /* NULL = defaults */,
@@ -260,6 +278,11 @@ typedef struct bx_agent_config {
                               * the length of a GET.  Costs one task claimed ahead per lane (at the end of a batch a claimed task may wait
                               * for its lane while another lane idles).  0 (default) = claim, fetch, prove, in that order, like the
                               * reference's agent */
+    int32_t monitor_requeue; /* 1 = poll_work also runs the requeue monitor (the reference's --monitor-requeue, lib.rs:101-103,283-303):
+                              * every requeue_poll_interval seconds, taskdb requeue_tasks(100) sends tasks that stayed 'running' past
+                              * their timeout_secs back through update_task_retry, so another lane (another GPU) picks up what a hung
+                              * lane or a dead process had claimed.  Needs bx_taskdb_ops::requeue_tasks; 0 (default) = off */
+    double requeue_poll_interval; /* seconds; 0 = 5 (lib.rs:148-150) */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;

@@ -84,7 +84,9 @@ static int planned_job_phase(int prefetch) {
     cfg.synthetic = 1;
     cfg.poll_time = 0.001;
     cfg.join_po2 = 9;
-    cfg.prefetch = prefetch;  // second run: every lane has a fetcher thread claiming one task ahead and doing its GET
+    cfg.prefetch = prefetch;  // second run: every lane has a fetcher thread claiming one task ahead and doing its GET ...
+    cfg.monitor_requeue = prefetch;  // ... and the requeue monitor sweeps the table every millisecond beside them (nothing times out)
+    cfg.requeue_poll_interval = 0.001;
     cfg.lift_po2 = 9;  // every Prove task also runs the stand-in lift: the segment seal is verified on a helper thread beside it
     snprintf(cfg.also_streams, sizeof cfg.also_streams, "aux");
     bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};

@@ -192,3 +192,72 @@ def test_prefetch_over_the_rest_worker_protocol_hides_the_download():
     assert logs[0] == logs[1]
     assert walls[0] >= n * (get_s + prove_s) * 0.95
     assert walls[1] < 0.8 * walls[0], walls
+
+
+# ------------------------------------------------------------------------------------------------- the requeue monitor
+class HangingProver:
+    """The first attempt at `hang_index` takes `hang_s` (a wedged device); everything else is quick."""
+
+    def __init__(self, hang_index, hang_s):
+        self.hang_index, self.hang_s = hang_index, hang_s
+        self.calls = []
+        self.mu = threading.Lock()
+
+    def prove_segment(self, seg):
+        with self.mu:
+            first = (seg.index == self.hang_index) and not any(i == seg.index for i, _ in self.calls)
+            self.calls.append((seg.index, time.monotonic()))
+        time.sleep(self.hang_s if first else 0.005)
+        return SegmentReceipt(seal=(np.arange(16, dtype=np.uint32) + np.uint32(seg.seed & 0xFFFF)), index=seg.index, po2=seg.po2)
+
+
+def test_the_requeue_monitor_hands_a_hung_lanes_task_to_another_lane():
+    """--monitor-requeue (bento/crates/workflow/src/lib.rs:101-103,283-303 -> poll_for_requeue :536-551 -> taskdb::requeue_tasks): a task
+    that stayed 'running' past its timeout_secs goes back to 'ready' with one more retry and the other lane proves it, long before
+    the wedged lane returns; the late finisher's update_task_done finds the task done already and changes nothing."""
+    n, hang_s = 8, 2.5
+    prover = HangingProver(hang_index=2, hang_s=hang_s)
+    a = ag.Agent(prover=prover, verify=False, poll_time=0.01, inflight=2, monitor_requeue=True, requeue_poll_interval=0.05)
+    try:
+        for i in range(n):
+            a.store.set_key_with_expiry(f"job:Q:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=13)), 600)
+            a.taskdb.create_task("Q", str(i), {"Prove": {"index": i}}, max_retries=2, timeout_secs=1)
+        done_at = {}
+
+        def watch():
+            t0 = time.monotonic()
+            while time.monotonic() - t0 < 10 and len(done_at) < 1:
+                if a.taskdb.job("Q")["state"] == "done":
+                    done_at["job"] = time.monotonic() - t0
+                time.sleep(0.01)
+
+        w = threading.Thread(target=watch)
+        w.start()
+        t0 = time.monotonic()
+        done = a.poll_work(max_idle_polls=150)  # the healthy lane keeps polling (1.5 s of idleness) while the other one is wedged
+        wall = time.monotonic() - t0
+        w.join()
+        rows = [a.taskdb.task("Q", str(i)) for i in range(n)]
+        assert all(r.state == "done" for r in rows) and a.taskdb.job("Q")["state"] == "done"
+        assert [r.retries for r in rows] == [0, 0, 1, 0, 0, 0, 0, 0]  # requeued once, by the monitor
+        assert sorted(i for i, _ in prover.calls) == sorted(list(range(n)) + [2])  # proved twice: by the wedged lane and by the other
+        assert done >= n
+        assert 1.0 < done_at["job"] < hang_s - 0.5  # the job was done ~1 s (the timeout) in, not when the wedged lane came back
+        assert wall >= hang_s * 0.95  # poll_work itself waits for its lanes
+        assert sorted(a.store.keys()) == sorted(f"job:Q:synthetic_receipts:{i}" for i in range(n))
+    finally:
+        a.close()
+
+
+def test_without_the_monitor_a_hung_lane_keeps_its_task():
+    prover = HangingProver(hang_index=1, hang_s=1.6)
+    a = ag.Agent(prover=prover, verify=False, poll_time=0.002, inflight=2)
+    try:
+        for i in range(4):
+            a.store.set_key_with_expiry(f"job:Q:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=13)), 600)
+            a.taskdb.create_task("Q", str(i), {"Prove": {"index": i}}, max_retries=2, timeout_secs=1)
+        assert a.poll_work(max_idle_polls=3) == 4
+        assert [a.taskdb.task("Q", str(i)).retries for i in range(4)] == [0, 0, 0, 0]
+        assert sorted(i for i, _ in prover.calls) == [0, 1, 2, 3]
+    finally:
+        a.close()

@@ -33,12 +33,19 @@ class Lib:
         self._done, self._failed = _UPD3(o.update_task_done), _UPD3(o.update_task_failed)
         self._retry, self._req, self._cur = _UPD2(o.update_task_retry), _REQ(o.request_work), _CUR(o.current_retries)
 
-    def create_task(self, stream, job, task, pre, max_retries):
+    def create_task(self, stream, job, task, pre, max_retries, timeout=None):
         try:
-            self.db.create_task(job, task, {"Prove": {"index": 0}}, max_retries=max_retries, stream=stream, prerequisites=pre)
+            self.db.create_task(job, task, {"Prove": {"index": 0}}, max_retries=max_retries, stream=stream, prerequisites=pre,
+                                timeout_secs=timeout)
             return True
         except HalError:
             return False
+
+    def advance(self, seconds):
+        self.db.advance_clock(seconds)
+
+    def requeue(self, limit=100):
+        return self.db.requeue_tasks(limit)
 
     def request_work(self, stream):
         out = ag._ReadyTask()
@@ -71,6 +78,7 @@ class Model:
         self.tasks = []  # dict rows, insertion order = created_at order
         self.deps = []   # (job, pre, post)
         self.jobs = {}   # job -> {"state", "error", "created"}; dicts keep insertion order = job_created_at order
+        self.now = 0.0   # moved by advance() only: the real time a test takes is far below the margins the generator leaves
 
     def _row(self, job, task):
         for r in self.tasks:
@@ -78,7 +86,18 @@ class Model:
                 return r
         return None
 
-    def create_task(self, stream, job, task, pre, max_retries):
+    def advance(self, seconds):
+        self.now += seconds
+
+    def requeue(self, limit=100):
+        """requeue_tasks, bento/crates/taskdb/src/lib.rs:328-358 (GREATEST ignores a NULL updated_at)."""
+        timed_out = [r for r in self.tasks if r["state"] == "running" and r["timeout"] is not None
+                     and r["timeout"] < self.now - max(r["started"], r["updated"] or 0.0)][:limit]
+        for r in timed_out:
+            self.retry(r["job"], r["task"])
+        return len(timed_out)
+
+    def create_task(self, stream, job, task, pre, max_retries, timeout=None):
         if self._row(job, task) is not None:  # PRIMARY KEY (job_id, task_id)
             return False
         if any(self._row(job, p) is None for p in pre):  # FOREIGN KEY (job_id, pre_task_id)
@@ -86,7 +105,8 @@ class Model:
         if job not in self.jobs:
             self.n_jobs_ever = getattr(self, "n_jobs_ever", 0) + 1
             self.jobs[job] = {"state": "running", "error": "", "created": self.n_jobs_ever}  # the job row comes with its first task
-        row = dict(stream=stream, job=job, task=task, state="pending", waiting_on=0, retries=0, max_retries=max_retries, error="", output="")
+        row = dict(stream=stream, job=job, task=task, state="pending", waiting_on=0, retries=0, max_retries=max_retries, error="", output="",
+                   timeout=timeout, started=0.0, updated=None)
         self.tasks.append(row)
         for p in pre:
             self.deps.append((job, p, task))
@@ -100,7 +120,7 @@ class Model:
         if not ready:
             return None
         r = self.tasks[min(ready)[1]]  # ORDER BY job_created_at ASC, created_at ASC LIMIT 1
-        r["state"] = "running"
+        r["state"], r["started"] = "running", self.now
         return (r["job"], r["task"], r["max_retries"])
 
     def clear_completed_jobs(self):
@@ -115,7 +135,7 @@ class Model:
         r = self._row(job, task)
         if r is None or r["state"] not in ("ready", "running"):
             return False
-        r["state"], r["output"] = "done", output
+        r["state"], r["output"], r["updated"] = "done", output, self.now
         for (j, p, post) in self.deps:
             if j == job and p == task:
                 d = self._row(job, post)
@@ -130,7 +150,7 @@ class Model:
         r = self._row(job, task)
         if r is None or r["state"] not in ("ready", "running", "pending"):
             return False
-        r["state"], r["error"] = "failed", error
+        r["state"], r["error"], r["updated"] = "failed", error, self.now
         if self.jobs[job]["state"] != "failed":
             self.jobs[job].update(state="failed", error=error)
         return True
@@ -140,7 +160,7 @@ class Model:
         if r is None or r["state"] != "running":
             return False
         r["retries"] += 1
-        r["state"], r["error"] = "ready", ""
+        r["state"], r["error"], r["updated"] = "ready", "", self.now
         if r["retries"] > r["max_retries"]:
             self.failed(job, task, "retry max hit")
             return False
@@ -154,8 +174,8 @@ class Model:
 def compare(lib, model, trail):
     for r in model.tasks:
         got = lib.db.task(r["job"], r["task"])
-        want = (r["state"], r["waiting_on"], r["retries"], r["max_retries"], r["error"], r["output"])
-        assert (got.state, got.waiting_on, got.retries, got.max_retries, got.error, got.output) == want, (r["job"], r["task"], trail[-8:])
+        want = (r["state"], r["waiting_on"], r["retries"], r["max_retries"], r["error"], r["output"], r["timeout"] or 0x7FFFFFFF)
+        assert (got.state, got.waiting_on, got.retries, got.max_retries, got.error, got.output, got.timeout_secs) == want, (r["job"], r["task"], trail[-8:])
     for job, j in model.jobs.items():
         rows = [t for t in model.tasks if t["job"] == job]
         got = lib.db.job(job)
@@ -174,8 +194,8 @@ def test_random_operation_sequences_agree_with_the_sql(seed):
     jobs, streams = ["J0", "J1", "J2"][: 1 + seed % 3], ["prove", "join", "aux"]
     names = {j: [] for j in jobs}
     for step in range(220):
-        kind = rng.choices(["create", "request", "done", "failed", "retry", "current", "clear"],
-                           weights=[30, 25, 25, 3 if seed % 4 else 0, 10, 5, 2 if seed % 2 else 0])[0]
+        kind = rng.choices(["create", "request", "done", "failed", "retry", "current", "clear", "advance", "requeue"],
+                           weights=[30, 25, 25, 3 if seed % 4 else 0, 10, 5, 2 if seed % 2 else 0, 6, 6])[0]
         job = rng.choice(jobs)
         known = names[job]
         pick = (lambda: rng.choice(known)) if known else (lambda: "none")
@@ -184,7 +204,8 @@ def test_random_operation_sequences_agree_with_the_sql(seed):
             pre = rng.sample(known, k=min(len(known), rng.choice([0, 0, 1, 2, 2, 3])))
             if rng.random() < 0.03:
                 pre = pre + ["ghost"]  # a prerequisite that does not exist
-            args = (rng.choice(streams), job, task, pre, rng.choice([0, 0, 1, 2]))
+            # timeouts 2 / 5 / 9 s against a clock that moves in multiples of 0.37 s: never within 0.1 s of a timeout
+            args = (rng.choice(streams), job, task, pre, rng.choice([0, 0, 1, 2]), rng.choice([None, 2, 5, 9]))
             a, b = lib.create_task(*args), model.create_task(*args)
             if b and task not in known:
                 known.append(task)
@@ -200,6 +221,12 @@ def test_random_operation_sequences_agree_with_the_sql(seed):
         elif kind == "retry":
             args = (job, pick())
             a, b = lib.retry(*args), model.retry(*args)
+        elif kind == "advance":
+            args = (0.37 * rng.randint(1, 8),)
+            a, b = lib.advance(*args), model.advance(*args)
+        elif kind == "requeue":
+            args = (100,)
+            a, b = lib.requeue(*args), model.requeue(*args)
         elif kind == "clear":
             args = ()
             a, b = lib.clear_completed_jobs(), model.clear_completed_jobs()
@@ -311,3 +338,39 @@ def test_clear_completed_jobs_drops_done_jobs_only_and_the_rest_keeps_working():
     assert lib.db.job("run")["state"] == "done"
     lib.db.plan_job("done-1", 1, aux_stream="prove")  # a cleared job id may be used again
     assert lib.db.job("done-1")["tasks"] == 3
+
+
+def test_requeue_tasks_retries_what_ran_past_its_timeout_and_fails_what_has_no_retries_left():
+    """requeue_tasks (bento/crates/taskdb/src/lib.rs:328-358; its own test is :1254): the clock a task is measured against restarts
+    at every claim and every update (GREATEST(started_at, updated_at))."""
+    lib = Lib()
+    db = lib.db
+    db.create_task("J", "a", {"Prove": {"index": 0}}, max_retries=1, timeout_secs=10)
+    db.create_task("J", "b", {"Prove": {"index": 1}}, max_retries=0, timeout_secs=10)
+    db.create_task("J", "c", {"Prove": {"index": 2}}, max_retries=5)  # no timeout: never requeued
+    db.create_task("J", "d", {"Prove": {"index": 3}}, max_retries=5, timeout_secs=10)  # stays ready: not running, not requeued
+    assert [lib.request_work("prove")[1] for _ in range(3)] == ["a", "b", "c"]
+    assert db.requeue_tasks() == 0
+    db.advance_clock(9.0)
+    assert db.requeue_tasks() == 0  # 9 s < 10 s
+    db.advance_clock(2.0)
+    assert db.requeue_tasks() == 2  # a and b ran 11 s
+    a, b, c, d = (db.task("J", t) for t in "abcd")
+    assert (a.state, a.retries) == ("ready", 1)
+    assert (b.state, b.retries, b.error) == ("failed", 1, "retry max hit") and db.job("J")["error"] == "retry max hit"
+    assert (c.state, c.retries) == ("running", 0) and (d.state, d.retries) == ("ready", 0)
+    assert db.requeue_tasks() == 0
+    assert lib.request_work("prove")[1] == "a"  # a is older than d: claimed again, its clock restarts
+    db.advance_clock(9.0)
+    assert db.requeue_tasks() == 0
+    db.advance_clock(2.0)
+    assert db.requeue_tasks() == 1 and db.task("J", "a").state == "failed" and db.task("J", "a").retries == 2
+    # the limit bounds one sweep
+    for i in range(5):
+        db.create_task("K", f"t{i}", {"Prove": {"index": i}}, max_retries=9, timeout_secs=1)
+    while lib.request_work("prove"):
+        pass
+    db.advance_clock(2.0)
+    assert db.requeue_tasks(limit=3) == 3 and db.requeue_tasks(limit=3) == 2 and db.requeue_tasks(limit=3) == 0
+    with pytest.raises(HalError, match="forward"):
+        db.advance_clock(-1.0)
