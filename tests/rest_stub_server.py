@@ -117,11 +117,16 @@ def make_handler(st):
                 deadline = time.time() + int(q.get("wait_timeout_secs", ["0"])[0])
                 while True:
                     with st.mu:
-                        for t in st.tasks:
-                            if t["state"] == "ready" and t["stream"] == stream:
-                                t["state"] = "running"
-                                return self._json(dict(job_id=t["job_id"], task_id=t["task_id"], task_def=t["task_def"], prereqs=[],
-                                                       max_retries=t["max_retries"]))
+                        # taskdb::request_work: the oldest ready task of the OLDEST job (9_request_work.sql:139-141)
+                        first = {}
+                        for i, t in enumerate(st.tasks):
+                            first.setdefault(t["job_id"], i)
+                        ready = [(first[t["job_id"]], i) for i, t in enumerate(st.tasks) if t["state"] == "ready" and t["stream"] == stream]
+                        if ready:
+                            t = st.tasks[min(ready)[1]]
+                            t["state"] = "running"
+                            return self._json(dict(job_id=t["job_id"], task_id=t["task_id"], task_def=t["task_def"], prereqs=[],
+                                                   max_retries=t["max_retries"]))
                     if time.time() >= deadline:
                         return self._send(200, b"null")
                     time.sleep(0.01)
