@@ -1389,54 +1389,63 @@ struct bx_agent {
             return left;
         };
         bool fatal_seen = false;
-        while (!stop.load(std::memory_order_relaxed)) {
-            std::unique_ptr<Fetched> w;
-            if (prefetching) {
-                w = pf.take(stop);
-                if (!w) break;  // stop requested
-                if (w->rc == 0) {
-                    // the fetcher's "nothing ready" is as old as the proof that ran meanwhile, and a finish in flight may requeue
-                    // its task: the poll that counts as idle is one made now, by the lane, with nothing pending
-                    (void)fin.wait_idle();
+        try {
+            while (!stop.load(std::memory_order_relaxed)) {
+                std::unique_ptr<Fetched> w;
+                if (prefetching) {
+                    w = pf.take(stop);
+                    if (!w) break;  // stop requested
+                    if (w->rc == 0) {
+                        // the fetcher's "nothing ready" is as old as the proof that ran meanwhile, and a finish in flight may requeue
+                        // its task: the poll that counts as idle is one made now, by the lane, with nothing pending
+                        (void)fin.wait_idle();
+                        w.reset(new Fetched());
+                        w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
+                        w->claimed = Clock::now();
+                    }
+                } else {
                     w.reset(new Fetched());
                     w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
                     w->claimed = Clock::now();
                 }
-            } else {
-                w.reset(new Fetched());
-                w->rc = claim_once(&w->task, w->eb, sizeof w->eb);
-                w->claimed = Clock::now();
-            }
-            if (w->rc < 0) {
-                set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + w->eb);
-                fatal_seen = true;
-                break;
-            }
-            if (w->rc == 0) {
-                // a finish still in flight may requeue its task (retry): only a poll made with nothing pending counts as idle
-                if (fin.wait_idle()) continue;
-                if (max_idle_polls >= 0 && ++idle >= max_idle_polls) {
-                    // out of idle polls.  A task the fetcher holds is not idleness: its completion may release dependants that no
-                    // other lane is left to claim, so the lane runs it and goes on polling (serially from here) until idle again
-                    if (std::unique_ptr<Fetched> left = stop_fetcher()) {
-                        if (!run_claimed(*left)) {
-                            fatal_seen = true;
-                            break;
-                        }
-                        continue;
-                    }
+                if (w->rc < 0) {
+                    set_fatal(std::string("[BENTO-WF-107] Failed to request_work: ") + w->eb);
+                    fatal_seen = true;
                     break;
                 }
-                // sleep poll_time in slices so a stop request is honoured promptly
-                auto until = Clock::now() + std::chrono::duration<double>(cfg.poll_time);
-                while (!stop.load(std::memory_order_relaxed) && Clock::now() < until)
-                    std::this_thread::sleep_for(std::chrono::duration<double>(std::min(cfg.poll_time, 0.05)));
-                continue;
+                if (w->rc == 0) {
+                    // a finish still in flight may requeue its task (retry): only a poll made with nothing pending counts as idle
+                    if (fin.wait_idle()) continue;
+                    if (max_idle_polls >= 0 && ++idle >= max_idle_polls) {
+                        // out of idle polls.  A task the fetcher holds is not idleness: its completion may release dependants that no
+                        // other lane is left to claim, so the lane runs it and goes on polling (serially from here) until idle again
+                        if (std::unique_ptr<Fetched> left = stop_fetcher()) {
+                            if (!run_claimed(*left)) {
+                                fatal_seen = true;
+                                break;
+                            }
+                            continue;
+                        }
+                        break;
+                    }
+                    // sleep poll_time in slices so a stop request is honoured promptly
+                    auto until = Clock::now() + std::chrono::duration<double>(cfg.poll_time);
+                    while (!stop.load(std::memory_order_relaxed) && Clock::now() < until)
+                        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(cfg.poll_time, 0.05)));
+                    continue;
+                }
+                if (!run_claimed(*w)) {
+                    fatal_seen = true;
+                    break;
+                }
             }
-            if (!run_claimed(*w)) {
-                fatal_seen = true;
-                break;
+        } catch (const std::exception& e) {  // bad_alloc while claiming: the lane ends, its threads are still joined below
+            try {
+                set_fatal(std::string("[BENTO-WF-107] Failed to request_work: exception in the lane loop: ") + e.what());
+            } catch (...) {
+                stop.store(1);
             }
+            fatal_seen = true;
         }
         // stop request or fatal error: a task the fetcher claimed is still run (not lost), unless the task db itself is failing
         if (std::unique_ptr<Fetched> left = stop_fetcher())
