@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libbx_hip_hal.so")
+CMD = os.path.join(HERE, "cmd")
+AGENT_BIN = os.path.join(HERE, "bin", "bx-agent")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
@@ -109,7 +111,25 @@ def build(force=False, verbose=True):
             print(f"built {LIB} from {len(objs)} objects")
     elif verbose:
         print(f"{LIB} up to date")
+    build_agent_binary(verbose)
     return LIB
+
+
+def build_agent_binary(verbose=True):
+    """boundless_amd/bin/bx-agent: the worker process (cmd/bx_agent_main.cpp) — plain C++ on the library's C ABI, no device code."""
+    src = os.path.join(CMD, "bx_agent_main.cpp")
+    os.makedirs(os.path.dirname(AGENT_BIN), exist_ok=True)
+    newest = max(os.path.getmtime(src), os.path.getmtime(LIB), _deps_mtime())
+    if os.path.exists(AGENT_BIN) and os.path.getmtime(AGENT_BIN) >= newest:
+        return AGENT_BIN
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", f"-I{INC}", src, "-o", AGENT_BIN, f"-L{os.path.dirname(LIB)}", "-lbx_hip_hal",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath-link,/opt/rocm/lib", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building bx-agent failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {AGENT_BIN}")
+    return AGENT_BIN
 
 
 if __name__ == "__main__":
