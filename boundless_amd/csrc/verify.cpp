@@ -9,10 +9,15 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bx_circuit.h"
+#include "../../include/bx_prover.h"
 #include "circuit.hpp"
 #include "fp.hpp"
 #include "poseidon2_params.hpp"
@@ -121,6 +126,19 @@ namespace bx {
 bool verifier_ctx_contains(const bx_verifier_ctx* v, uint32_t po2, const uint32_t root[8]);  // control_id.cpp
 }
 namespace {
+
+// threads that share the 50 queries of one verification: bx_verify_set_threads, else BX_VERIFY_THREADS, else min(4, cores)
+std::atomic<int> g_verify_threads{0};
+int verify_threads() {
+    int n = g_verify_threads.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (const char* e = getenv("BX_VERIFY_THREADS")) {
+        n = atoi(e);
+        if (n >= 1 && n <= 64) return n;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    return hw >= 4 ? 4 : hw >= 1 ? (int)hw : 1;
+}
 
 void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ, const bx_verifier_ctx* vctx) {
     HostPoseidon2 h;
@@ -313,8 +331,21 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ, cons
     }
     // ---- queries ----
     const uint32_t w16 = rou(4), w16_inv = fp_inv(w16), inv16 = fp_inv(fp_encode(16u));
-    for (int q = 0; q < BX_QUERIES; ++q) {
-        size_t pos = T.random_bits(ilog2u(D)) % D;
+    // The queries commit nothing to the transcript, so their positions do not depend on what they open: all are drawn first, and
+    // — every opening having a length fixed by the shape — each query's words are at a known offset.  The queries are then
+    // checked independently, on a few threads (bx_verify_set_threads); the verdict is the one of the first failing query in seal
+    // order, exactly what reading the seal front to back reports.
+    size_t positions[BX_QUERIES];
+    for (int q = 0; q < BX_QUERIES; ++q) positions[q] = T.random_bits(ilog2u(D)) % D;
+    size_t per_query = 0;
+    for (int g = 0; g < 4; ++g) per_query += trees[g].cols + 8 * (size_t)(trees[g].layers - trees[g].top_layer);
+    for (const Round& r : rounds) per_query += r.tree.cols + 8 * (size_t)(r.tree.layers - r.tree.top_layer);
+    const size_t queries_at = rd.pos;
+    auto check_query = [&](int q) {
+        Reader rd{seal, words};  // this query's own cursor (shadows the stream's)
+        rd.pos = queries_at + (size_t)q * per_query;
+        if (rd.pos > rd.n) throw Fail{"seal truncated"};
+        size_t pos = positions[q];
         const Fp4 y = from_base(fp_pow(rou(po2 + 2), pos));  // evaluation point of row `pos` (coset shift lives in the coefficients)
         // DEEP quotient from the opened rows
         std::vector<Fp4> num(n_combos, f4_zero());
@@ -338,7 +369,7 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ, cons
         }
         // FRI chain
         size_t domain = D;
-        for (Round& r : rounds) {
+        for (const Round& r : rounds) {
             const size_t rows = domain / BX_FRI_FOLD;
             const size_t group = pos % rows, quot = pos / rows;
             const uint32_t* vals = r.tree.verify_open(rd, h, group);
@@ -371,7 +402,54 @@ void verify(const uint32_t* seal, size_t words, const bx_circuit_ops* circ, cons
             }
             VCHECK(eq(acc, goal), "final polynomial does not match the last FRI fold");
         }
+    };
+    {
+        int threads = verify_threads();
+        if (threads > BX_QUERIES) threads = BX_QUERIES;
+        std::string errs[BX_QUERIES];
+        bool failed[BX_QUERIES] = {false};
+        std::atomic<int> first_bad{BX_QUERIES};
+        auto worker = [&](int t) {
+            for (int q = t; q < BX_QUERIES; q += threads) {
+                if (q > first_bad.load(std::memory_order_relaxed)) break;  // an earlier query already decides the verdict
+                try {
+                    check_query(q);
+                } catch (const Fail& f) {
+                    failed[q] = true;
+                    try {
+                        errs[q] = f.msg;
+                    } catch (...) {
+                    }
+                } catch (const std::exception& e) {
+                    failed[q] = true;
+                    try {
+                        errs[q] = e.what();
+                    } catch (...) {
+                    }
+                }
+                if (failed[q]) {
+                    int cur = first_bad.load();
+                    while (q < cur && !first_bad.compare_exchange_weak(cur, q)) {
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+        } catch (...) {  // no more threads to be had: the calling thread checks what nobody was started for
+            const int started = (int)pool.size() + 1;
+            for (auto& th : pool) th.join();
+            pool.clear();
+            for (int t = started; t < threads; ++t) worker(t);
+        }
+        worker(0);
+        for (auto& th : pool) th.join();
+        for (int q = 0; q < BX_QUERIES; ++q)
+            if (failed[q]) throw Fail{errs[q].empty() ? "query check failed" : errs[q]};
     }
+    rd.pos = queries_at + (size_t)BX_QUERIES * per_query;
+    if (rd.pos > rd.n) throw Fail{"seal truncated"};
     VCHECK(rd.pos == rd.n, "trailing words after the last query");
     if (!vctx) {
         const char* ce = circ->check_code(circ->user, &shape, trees[0].root);
@@ -455,6 +533,11 @@ extern "C" const char* bx_poseidon2_default_params(uint32_t* rc213, uint32_t* di
     return nullptr;
 }
 
+extern "C" const char* bx_verify_set_threads(int threads) {
+    if (threads < 0 || threads > 64) return "bx_verify_set_threads: 0 (default) .. 64";
+    g_verify_threads.store(threads);
+    return nullptr;
+}
 extern "C" const char* bx_verify_segment(const uint32_t* seal, size_t seal_words) {
     return bx_verify_segment_with_circuit(seal, seal_words, nullptr);
 }

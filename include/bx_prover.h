@@ -153,6 +153,11 @@ const char* bx_merkle_query_gather(bx_ctx* ctx, bx_buf out, bx_buf matrix, bx_bu
  * circuit knows its IDs — a table for w_code = 16, a cached host computation otherwise; bx_circuit.h has the explicit
  * VerifierContext form).  Returns NULL when the seal is accepted, otherwise a message (thread-local storage) naming the first failed check. */
 const char* bx_verify_segment(const uint32_t* seal, size_t seal_words);
+/* Host threads that share the 50 queries of ONE verification (each query is independent once the transcript has been replayed):
+ * 0 = the default — BX_VERIFY_THREADS from the environment, else min(4, cores); 1 = the calling thread alone.  The verdict and its
+ * text do not depend on it (the first failing query in seal order decides).  A 2^18 seal: 9 ms on one thread, 3 ms on four — the
+ * verification of a join's result is on the critical path of a job's join tail. */
+const char* bx_verify_set_threads(int threads);
 
 #ifdef __cplusplus
 }

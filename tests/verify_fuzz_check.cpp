@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "../boundless_amd/csrc/circuit.hpp"
@@ -104,9 +105,21 @@ int main(int argc, char** argv) {
         // exact-size heap copy so that a read one word past the end is an ASan report
         uint32_t* heap = (uint32_t*)malloc(m.size() * 4 + (m.empty() ? 1 : 0));
         memcpy(heap, m.data(), m.size() * 4);
-        const char* e = (it & 1) ? bx_verify_segment(heap, m.size()) : bx_verify_segment_with_context(heap, m.size(), nullptr, good);
+        // the verdict — and its text — must not depend on how many threads share the queries: one thread reads the seal front to
+        // back, several check the queries independently and report the first failing one in seal order
+        std::string verdict[2];
+        const int threads[2] = {1, 1 + (int)(rnd() % 7)};
+        for (int v = 0; v < 2; ++v) {
+            if (bx_verify_set_threads(threads[v])) return 2;
+            const char* e = (it & 1) ? bx_verify_segment(heap, m.size()) : bx_verify_segment_with_context(heap, m.size(), nullptr, good);
+            verdict[v] = e ? e : "";
+        }
         free(heap);
-        if (!e) {
+        if (verdict[0] != verdict[1]) {
+            printf("mutation %ld: '%s' on one thread, '%s' on %d\n", it, verdict[0].c_str(), verdict[1].c_str(), threads[1]);
+            return 1;
+        }
+        if (verdict[0].empty()) {
             ++accepted;
             printf("mutation %ld accepted\n", it);
         }
