@@ -149,8 +149,82 @@ static int planned_job_phase(int prefetch) {
     return 0;
 }
 
+// Third phase: bx_agent_stop in the middle of a planned job, with fetchers and the requeue monitor running: poll_work returns, no
+// task is left 'running' (what a fetcher had claimed is run before its lane leaves), and a second poll_work finishes the job.
+static int stop_and_resume_phase(void) {
+    bx_mem_store* store = nullptr;
+    bx_mem_taskdb* db = nullptr;
+    if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;
+    bx_hot_store_ops sops = bx_mem_store_ops(store);
+    bx_taskdb_ops tops = bx_mem_taskdb_ops(db);
+    const int K = 120;
+    for (int i = 0; i < K; ++i) {
+        uint8_t wire[BX_SEGMENT_WIRE_BYTES];
+        bx_segment_encode((uint64_t)i, 10, 9000 + (uint64_t)i, wire);
+        std::string key = "job:halt:segments:" + std::to_string(i);
+        if (sops.set_ex(sops.user, key.c_str(), wire, sizeof wire, 0, nullptr, 0) != 0) return 1;
+    }
+    bx_job_plan plan;
+    memset(&plan, 0, sizeof plan);
+    plan.prove_retries = plan.join_retries = plan.resolve_retries = plan.finalize_retries = 50;
+    uint64_t created = 0;
+    if (bx_plan_job(db, "halt", K, &plan, &created, nullptr)) return 1;
+    bx_agent_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.inflight = 2;
+    cfg.n_devices = 3;
+    cfg.devices[0] = 0, cfg.devices[1] = 1, cfg.devices[2] = 2;
+    cfg.synthetic = 1;
+    cfg.poll_time = 0.001;
+    cfg.join_po2 = 9;
+    cfg.prefetch = 1;
+    cfg.monitor_requeue = 1;
+    cfg.requeue_poll_interval = 0.001;
+    snprintf(cfg.also_streams, sizeof cfg.also_streams, "aux");
+    bx_segment_prover_ops pops{nullptr, seal_words, prove, nullptr, nullptr};
+    bx_agent* agent = nullptr;
+    if (bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) return 1;
+    uint64_t first = 0, second = 0;
+    std::thread stopper([agent] {
+        std::this_thread::sleep_for(std::chrono::milliseconds(40));
+        bx_agent_stop(agent);
+    });
+    const char* e = bx_agent_poll_work(agent, -1, &first);  // no idle limit: only the stop ends it
+    stopper.join();
+    if (e) {
+        fprintf(stderr, "stop phase: %s\n", e);
+        return 1;
+    }
+    bx_job_info job;
+    if (bx_mem_taskdb_job_info(db, "halt", &job)) return 1;
+    if (job.running != 0 || job.failed != 0 || job.done != first || job.done + job.ready + job.pending != created) {
+        fprintf(stderr, "after the stop: running %llu failed %llu done %llu (agent %llu) ready %llu pending %llu of %llu\n", (unsigned long long)job.running,
+                (unsigned long long)job.failed, (unsigned long long)job.done, (unsigned long long)first, (unsigned long long)job.ready,
+                (unsigned long long)job.pending, (unsigned long long)created);
+        return 1;
+    }
+    if (bx_agent_destroy(agent)) return 1;
+    agent = nullptr;
+    if (bx_agent_create(&cfg, &sops, &tops, &pops, &agent)) return 1;  // a fresh agent: its stop flag is clear
+    if (const char* e2 = bx_agent_poll_work(agent, 5, &second)) {
+        fprintf(stderr, "resume phase: %s\n", e2);
+        return 1;
+    }
+    if (bx_mem_taskdb_job_info(db, "halt", &job)) return 1;
+    if (job.state != BX_JOB_DONE || first + second != created) {
+        fprintf(stderr, "after the resume: state %d, %llu + %llu of %llu\n", job.state, (unsigned long long)first, (unsigned long long)second,
+                (unsigned long long)created);
+        return 1;
+    }
+    if (bx_agent_destroy(agent)) return 1;
+    bx_mem_taskdb_destroy(db);
+    bx_mem_store_destroy(store);
+    printf("stop and resume ok: %llu tasks before the stop, %llu after\n", (unsigned long long)first, (unsigned long long)second);
+    return 0;
+}
+
 int main() {
-    if (planned_job_phase(0) || planned_job_phase(1)) return 1;
+    if (planned_job_phase(0) || planned_job_phase(1) || stop_and_resume_phase()) return 1;
     bx_mem_store* store = nullptr;
     bx_mem_taskdb* db = nullptr;
     if (bx_mem_store_create(&store) || bx_mem_taskdb_create(&db)) return 1;
