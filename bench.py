@@ -31,6 +31,7 @@ rank 0 joins them: the job's only collective);
 
 The JSON line also carries
   single_proof_ms   wall clock of a lone proof (the reference's agent proves one segment at a time per process), no HIP events around it;
+                    .spin_wait = the same with the host thread busy-waiting on its stream (the one-proof-at-a-time latency mode);
   pcie_inclusive    untimed extra at N=1: the same workload with 80 MB per segment over PCIe, two deep (`value` stays inputs-resident);
   per_rank, backend one row per rank (rank, device, proofs, seconds) and the backend's world size: whether RCCL saw N ranks, and balance;
   roofline      the NTT/LDE entry point named by BASELINE's metric (`roofline.dominant` = the job's dominant kernel, hash_rows, against
@@ -648,6 +649,20 @@ def main():
             sv.prove_segment(Segment.synthetic(index=2 * 10**6 + k, po2=args.po2))
             ts.append(1e3 * (time.perf_counter() - t1))
         single_ms = {"min": round(min(ts[1:]), 3), "median": round(sorted(ts[1:])[1], 3), "runs": [round(x, 3) for x in ts[1:]]}
+        # the same with the host thread busy-waiting on its stream (BX_WAIT=spin / wait_blocking = 0): the latency mode of a process
+        # that proves one segment at a time — its ~10 round trips per proof no longer pay the sleep-poll's wake-up, at the price of
+        # one busy core.  Skipped when the run was started with a policy of its own.
+        if not os.environ.get("BX_WAIT") and "wait_blocking" not in os.environ.get("BX_TUNABLES", ""):
+            try:
+                sv.hal.set_tunable("wait_blocking", 0)
+                ts = []
+                for k in range(4):
+                    t1 = time.perf_counter()
+                    sv.prove_segment(Segment.synthetic(index=3 * 10**6 + k, po2=args.po2))
+                    ts.append(1e3 * (time.perf_counter() - t1))
+                single_ms["spin_wait"] = {"min": round(min(ts[1:]), 3), "median": round(sorted(ts[1:])[1], 3), "runs": [round(x, 3) for x in ts[1:]]}
+            finally:
+                sv.hal.set_tunable("wait_blocking", 2)
     barrier()
 
     # Isolated probe (untimed, rank 0 only): with several segments in flight the HIP-event durations of the timed region
