@@ -178,6 +178,18 @@ def verify_seal(seal_words, circuit=None, ctx=None):
         raise HalError(msg.decode())
 
 
+def set_verify_threads(threads):
+    """bx_verify_set_threads: host threads that share the 50 queries of one verification (0 = default: BX_VERIFY_THREADS, else
+    min(4, cores); 1 = the calling thread alone).  The verdict does not depend on it."""
+    lib = load_library()
+    _declare(lib)
+    lib.bx_verify_set_threads.restype = C.c_char_p
+    lib.bx_verify_set_threads.argtypes = [C.c_int]
+    msg = lib.bx_verify_set_threads(int(threads))
+    if msg:
+        raise HalError(msg.decode())
+
+
 def synthetic_control_id_host(po2, w_code):
     """The built-in circuit's control ID for (po2, w_code) computed on the host (include/bx_circuit.h); no GPU."""
     lib = load_library()

@@ -215,3 +215,37 @@ def test_zk_noise_rows_are_seeded_and_change_nothing_the_verifier_checks():
     assert np.array_equal(a[:8], c[:8]) and np.array_equal(a[:8], d[:8])  # header + public words: the statement
     assert np.array_equal(a[8:8 + 256], c[8:8 + 256])  # the code group is public and not blinded: same top layer
     assert not np.array_equal(a[8 + 256:8 + 512], c[8 + 256:8 + 512])  # the data commitment differs
+
+
+def test_the_verdict_does_not_depend_on_the_number_of_verification_threads():
+    """bx_verify_set_threads: the queries of one seal are checked independently on n threads; the error reported is that of the
+    first failing query in seal order — the same text a front-to-back read gives (tests/verify_fuzz_check.cpp fuzzes this under
+    the sanitizers; here a few hand-made cases through the Python binding)."""
+    from boundless_amd.prover import set_verify_threads
+
+    seal, _ = ol.prove_segment(11, 4, 12, 4, 77)
+    cases = [seal.copy() for _ in range(5)]
+    cases[1][len(seal) - 3] ^= 1             # the last query's last Merkle path
+    cases[2][len(seal) // 2] ^= 1            # somewhere in the middle of the queries
+    cases[3] = seal[: len(seal) - 40].copy()  # truncated inside the last query
+    cases[4] = np.concatenate([seal, seal[:8]])  # trailing words
+    verdicts = {}
+    try:
+        for n in (1, 2, 3, 7, 50, 64):
+            set_verify_threads(n)
+            row = []
+            for c in cases:
+                try:
+                    verify_seal(c)
+                    row.append("")
+                except HalError as e:
+                    row.append(str(e))
+            verdicts[n] = row
+    finally:
+        set_verify_threads(0)
+    assert verdicts[1][0] == "" and all(v for v in verdicts[1][1:])
+    assert "trailing words" in verdicts[1][4] and "truncated" in verdicts[1][3]
+    for n, row in verdicts.items():
+        assert row == verdicts[1], n
+    with pytest.raises(HalError, match="0 .default. .. 64"):
+        set_verify_threads(65)
