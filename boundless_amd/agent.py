@@ -291,6 +291,12 @@ class TaskDb:
         """taskdb `clear_completed_jobs` (4_clear_completed_streams.sql): drops every row of every done job; returns the jobs cleared."""
         n = C.c_uint64()
         _check(self._lib.bx_mem_taskdb_clear_completed_jobs(self._h, C.byref(n)))
+        if n.value:  # rows() lists what is still in the table
+            alive, info = {}, _JobInfo()
+            for j, _ in self._ids:
+                if j not in alive:
+                    alive[j] = self._lib.bx_mem_taskdb_job_info(self._h, j.encode(), C.byref(info)) is None
+            self._ids = [(j, t) for j, t in self._ids if alive[j]]
         return n.value
 
     def __del__(self):

@@ -319,7 +319,9 @@ def test_clear_completed_jobs_drops_done_jobs_only_and_the_rest_keeps_working():
     assert lib.failed("bad", "1", "boom")
     assert lib.done("run", "0", "null") and lib.done("run", "1", "null")  # its first join (task 3) is ready now
     before = {t: lib.db.task("run", t) for t in ["0", "1", "2", "3", "4", "resolve", "finalize"]}
+    assert len(lib.db.rows()) == 4 * 7
     assert lib.clear_completed_jobs() == 2 and lib.clear_completed_jobs() == 0
+    assert sorted({r.job_id for r in lib.db.rows()}) == ["bad", "run"] and len(lib.db.rows()) == 2 * 7
     for job in ("done-1", "done-2"):
         with pytest.raises(HalError, match="no such job"):
             lib.db.job(job)
