@@ -297,6 +297,11 @@ def job_main(args, widths):
         base = {}
         for d, cnt in a.lane_stats():
             base[d] = base.get(d, 0) + cnt
+        if args.jobs > 1:
+            def make_aux():  # the deployment's aux agent (compose.yml: `agent -t aux`): one lane that serves the finalize tasks as they become ready
+                return ag.Agent(prover=None, device=devices[0], inflight=1, widths=widths, poll_time=0.001, verify=True, terms=args.terms,
+                                degree=args.degree, store=a.store, taskdb=a.taskdb, task_stream="aux")
+            return batch_of_jobs(args, a, submit, K, n, lanes, widths, make_aux)
         ids = submit("timed", K)
         t0 = time.perf_counter()
         done = a.poll_work(max_idle_polls=2)
@@ -342,6 +347,56 @@ def job_main(args, widths):
         print(json.dumps(out))
     finally:
         a.close()
+
+
+def batch_of_jobs(args, a, submit, K, n, lanes, widths, make_aux):
+    """`--job K --jobs M`: M planned jobs submitted at once (a broker batch of M orders, each a K-segment execution).  The task db
+    hands out the oldest ready task of the OLDEST job (9_request_work.sql:139-141: job-level FIFO), so orders complete one after
+    the other instead of all at the end: the line reports when each job's finalize task was done."""
+    M = args.jobs
+    names = [f"order-{j}" for j in range(M)]
+    import threading
+
+    ids = {j: submit(j, K) for j in names}
+    total = sum(len(v) for v in ids.values())
+    aux = make_aux()
+    aux_done = []
+    th = threading.Thread(target=lambda: aux_done.append(aux.poll_work(max_idle_polls=None)))
+    try:
+        t0 = time.perf_counter()
+        th.start()
+        done = a.poll_work(max_idle_polls=2)
+        deadline = time.perf_counter() + 30
+        while any(a.taskdb.job(j)["state"] == "running" for j in names) and time.perf_counter() < deadline:
+            time.sleep(0.001)  # the last finalize is the aux agent's
+        dt = time.perf_counter() - t0
+    finally:
+        aux.stop()
+        th.join()
+        aux.close()
+    done += sum(aux_done)
+    if done != total or any(a.taskdb.job(j)["state"] != "done" for j in names):
+        raise RuntimeError(f"batch: {done} of {total} tasks done")
+    first = min(a.taskdb.task(j, "0").started_s for j in names)
+    rows = []
+    for j in names:
+        t = [a.taskdb.task(j, x) for x in ids[j]]
+        rows.append({"job": j, "first_claim_s": round(min(r.started_s for r in t if r.started_s > 0) - first, 4),
+                     "done_s": round(a.taskdb.task(j, "finalize").updated_s - first, 4)})
+    end = max(r["done_s"] for r in rows)
+    out = {"metric": "segment-proofs/sec @ 2^20 cycles", "value": M * K / end, "unit": "segment-proofs/s", "n_gpus": n, "steps": 1, "warmup": 1,
+           "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 (BabyBear Montgomery)",
+           "data": "synthetic", "join": "synthetic stand-in",
+           "config": {"workload": f"a batch of {M} jobs of {K} 2^{args.po2}-cycle synthetic segments each, all submitted before the clock starts: per job {K} Prove "
+                                  f"tasks, {K - 1} stand-in Join tasks (2^{args.join_po2}), resolve, finalize; every seal CPU-verified; widths {'/'.join(map(str, widths))}",
+                      "po2": args.po2, "join_po2": args.join_po2, "segments_proved": M * K, "segments_in_flight_per_gpu": lanes,
+                      "queue": "one in-memory task db; request_work = the oldest ready task of the oldest job (9_request_work.sql:139-141)",
+                      "parallelism": f"one process, {n} device(s) x {lanes} lanes + one aux lane (finalize), no collective"},
+           "batch": {"jobs": rows, "batch_s": round(end, 4), "mean_job_latency_s": round(sum(r["done_s"] for r in rows) / M, 4),
+                     "first_job_done_s": rows[0]["done_s"], "segments_per_s": round(M * K / end, 3),
+                     "note": "value = all segments / time until the last job's finalize; with claims in plain creation order (every job's proves "
+                             "before any job's joins) every job would finish near batch_s"}}
+    print(json.dumps(out))
 
 
 def job_dist_main(args, widths):
@@ -451,6 +506,8 @@ def main():
     ap.add_argument("--degree", type=int, default=0, help="synthetic circuit: factors per term (0 = default)")
     ap.add_argument("--job", type=int, default=0, help="prove ONE planned job of this many segments (bx_plan_job: proves -> stand-in joins -> resolve -> finalize) through the "
                     "native agent on --gpus devices; reports prove-phase rate, join-tail latency and end-to-end seconds, labelled \"join\": \"synthetic stand-in\"")
+    ap.add_argument("--jobs", type=int, default=1, help="--job: submit this many such jobs at once (a broker batch: BASELINE configs[4]'s shape) and report when each one "
+                    "finished — the task db serves the oldest job first, as the reference's request_work does (9_request_work.sql:139-141)")
     ap.add_argument("--join-po2", type=int, default=18, help="--job: size of the stand-in join proofs (18 = the reference's recursion proofs)")
     ap.add_argument("--lift", action="store_true", help="--job: every Prove task also runs the stand-in `lift` leg (prove.rs:60-113): a second synthetic proof of 2^--join-po2 "
                     "cycles seeded by the segment seal; the joins consume the lifted receipts")
