@@ -76,7 +76,7 @@ def test_pending_ready_transitions_follow_the_reference_sql():
         db.plan_job("typo", 1 << 40)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 37])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 37] + [6, 7, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 257])
 def test_plan_job_creates_the_planners_tasks_with_the_planners_dependencies(n):
     """bx_plan_job == driving Planner by hand the way the executor does: same task numbers, defs, streams and prerequisites."""
     db = ag.TaskDb()
