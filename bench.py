@@ -299,8 +299,7 @@ def job_main(args, widths):
             base[d] = base.get(d, 0) + cnt
         if args.jobs > 1:
             def make_aux():  # the deployment's aux agent (compose.yml: `agent -t aux`): one lane that serves the finalize tasks as they become ready
-                return ag.Agent(prover=None, device=devices[0], inflight=1, widths=widths, poll_time=0.001, verify=True, terms=args.terms,
-                                degree=args.degree, store=a.store, taskdb=a.taskdb, task_stream="aux")
+                return ag.Agent(no_prover=True, inflight=1, poll_time=0.001, verify=True, store=a.store, taskdb=a.taskdb, task_stream="aux")
             return batch_of_jobs(args, a, submit, K, n, lanes, widths, make_aux)
         ids = submit("timed", K)
         t0 = time.perf_counter()

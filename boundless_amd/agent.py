@@ -77,7 +77,7 @@ class _AgentConfig(C.Structure):
                 ("task_stream", C.c_char * 64), ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16), ("synthetic", C.c_int32),
                 ("cons_terms", C.c_uint32), ("cons_degree", C.c_uint32), ("po2_min", C.c_uint32), ("po2_max", C.c_uint32),
                 ("max_shapes", C.c_uint32), ("join_po2", C.c_uint32), ("also_streams", C.c_char * 128), ("lift_po2", C.c_uint32), ("prefetch", C.c_int32), ("monitor_requeue", C.c_int32),
-                ("requeue_poll_interval", C.c_double)]
+                ("requeue_poll_interval", C.c_double), ("no_prover", C.c_int32)]
 
 
 def _lib():
@@ -350,18 +350,19 @@ class Agent:
     def __init__(self, prover=None, device=0, inflight=None, widths=(16, 256, 64), redis_ttl=8 * 60 * 60, poll_time=1.0,
                  verify=True, store=None, taskdb=None, task_stream="prove", seal_cap=1 << 20, devices=None, synthetic=True,
                  terms=0, degree=0, po2_range=(0, 0), max_shapes=0, blob_prover=None, join_po2=0, also_streams="", lift_po2=0, prefetch=False,
-                 monitor_requeue=False, requeue_poll_interval=0.0):
+                 monitor_requeue=False, requeue_poll_interval=0.0, no_prover=False):
         self._lib = _lib()
         self.store = store or HotStore()
         self.taskdb = taskdb or TaskDb()
         self.prover = prover
-        injected = prover is not None or blob_prover is not None
+        injected = prover is not None or blob_prover is not None or no_prover
         cfg = _AgentConfig(device=device, inflight=inflight or (1 if injected else 3), w_code=widths[0],
                            w_data=widths[1], w_accum=widths[2], redis_ttl=redis_ttl, poll_time=poll_time, no_verify=int(not verify),
                            task_stream=task_stream.encode(), synthetic=int(bool(synthetic)), cons_terms=terms, cons_degree=degree,
                            po2_min=po2_range[0], po2_max=po2_range[1], max_shapes=max_shapes, join_po2=join_po2,
                            also_streams=also_streams.encode(), lift_po2=lift_po2, prefetch=int(bool(prefetch)),
-                           monitor_requeue=int(bool(monitor_requeue)), requeue_poll_interval=requeue_poll_interval)
+                           monitor_requeue=int(bool(monitor_requeue)), requeue_poll_interval=requeue_poll_interval,
+                           no_prover=int(bool(no_prover)))
         if devices:
             cfg.n_devices = len(devices)
             for i, d in enumerate(devices):

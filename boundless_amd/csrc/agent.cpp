@@ -1827,6 +1827,7 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
     if (!taskdb->request_work || !taskdb->update_task_done || !taskdb->update_task_failed || !taskdb->update_task_retry ||
         !taskdb->current_retries)
         return "bx_agent_create: task db ops incomplete";
+    if (cfg->no_prover) prover = nullptr;  // `prover: None` (lib.rs:242-252): whatever table was passed is not used
     if (prover && !prover->prove_blob && (!prover->prove_segment || !prover->seal_words)) return "bx_agent_create: prover ops incomplete";
     const bool opaque = prover && prover->prove_blob;
     if (!opaque && !cfg->synthetic)
@@ -1887,7 +1888,11 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
             a->lanes.emplace_back(new Lane());
             a->lanes.back()->device = a->cfg.devices[l / a->cfg.inflight];
         }
-        if (prover) {
+        if (a->cfg.no_prover) {
+            // Agent::new gives only the prove / join / coproc worker types a prover (lib.rs:242-252); an aux agent has none, needs no
+            // GPU, and a Prove or Join task that reaches it fails with the reference's "Missing prover" errors
+            a->prover = bx_segment_prover_ops{nullptr, nullptr, nullptr, nullptr, nullptr};
+        } else if (prover) {
             a->prover = *prover;
         } else {
             a->hip = true;

@@ -283,6 +283,10 @@ typedef struct bx_agent_config {
                               * their timeout_secs back through update_task_retry, so another lane (another GPU) picks up what a hung
                               * lane or a dead process had claimed.  Needs bx_taskdb_ops::requeue_tasks; 0 (default) = off */
     double requeue_poll_interval; /* seconds; 0 = 5 (lib.rs:148-150) */
+    int32_t no_prover;       /* 1 = the agent has no prover, like the reference's agents of every worker type but prove / join / coproc
+                              * (`prover: None`, lib.rs:242-252): it needs no GPU, the `prover` argument of bx_agent_create is ignored, the
+                              * Resolve / Finalize stand-ins are served (an aux agent beside the GPU agents), and a Prove or Join task that
+                              * reaches it fails with "[BENTO-PROVE-002] Missing prover from prove task" / "Missing prover from join task" */
 } bx_agent_config;
 
 typedef struct bx_agent bx_agent;

@@ -291,3 +291,36 @@ def test_the_lift_leg_of_the_prove_task_as_a_stand_in():
         assert f'task_operations_total{{task_name="prove",operation_type="lift",status="success"}} {n}' in a.metrics_text()
     finally:
         a.close()
+
+
+def test_an_agent_without_a_prover_serves_the_aux_tasks_and_refuses_proofs_with_the_references_errors():
+    """`prover: None` (bento/crates/workflow/src/lib.rs:242-252): only the prove / join / coproc worker types get a prover; an aux
+    agent (cfg.no_prover) needs no GPU, finishes the job's finalize task, and a Prove or Join task that reaches such an agent fails with
+    "[BENTO-PROVE-002] Missing prover from prove task" (prove.rs:41-45) / "Missing prover from join task" (join.rs:51-55)."""
+    store, db = ag.HotStore(), ag.TaskDb()
+    gpu = ag.Agent(prover=FakeProver(), verify=False, poll_time=0.002, inflight=2, join_po2=11, store=store, taskdb=db)
+    aux = ag.Agent(no_prover=True, verify=False, poll_time=0.002, inflight=1, store=store, taskdb=db, task_stream="aux")
+    try:
+        for i in range(4):
+            store.set_key_with_expiry(f"job:N:segments:{i}", ag.serialize_segment(Segment.synthetic(i, po2=13)), 600)
+        ids = db.plan_job("N", 4)
+        assert gpu.poll_work(max_idle_polls=3) == len(ids) - 1 and db.task("N", "finalize").state == "ready"
+        assert aux.poll_work(max_idle_polls=3) == 1 and db.job("N")["state"] == "done"
+        assert "receipts/stark/N.synthetic" in store.keys()
+        # proofs that reach the prover-less agent
+        store.set_key_with_expiry("job:M:segments:0", ag.serialize_segment(Segment.synthetic(0, po2=13)), 600)
+        db.create_task("M", "0", {"Prove": {"index": 0}}, max_retries=0, stream="aux")
+        assert aux.poll_work(max_idle_polls=3) == 0
+        row = db.task("M", "0")
+        assert row.state == "failed" and row.error == "[BENTO-WF-115] Prove failed: [BENTO-PROVE-002] Missing prover from prove task"
+        assert "job:M:segments:0" in store.keys()  # nothing was consumed
+        for k in (1, 2):
+            store.set_key_with_expiry(f"job:M2:synthetic_receipts:{k}", ag.serialize_receipt(SegmentReceipt(seal=fake_seal(11, k), index=k, po2=11)), 600)
+        db.create_task("M2", "3", {"Join": {"idx": 3, "left": 1, "right": 2}}, max_retries=0, stream="aux")
+        assert aux.poll_work(max_idle_polls=3) == 0
+        assert db.task("M2", "3").error == "[BENTO-WF-119] Join failed: Missing prover from join task"
+        with pytest.raises(HalError, match="prover"):
+            ag.Agent(no_prover=True, synthetic=False, store=store, taskdb=db)  # still the synthetic key scheme: must be asked for
+    finally:
+        gpu.close()
+        aux.close()
