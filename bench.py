@@ -55,7 +55,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r04"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
+PROFILE_ROUND = "r05"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU issue model used throughout (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 units; measured in profiles/r01_microbench2_instr_cost.jsonl):
 # a wave64 instruction of the cheap integer class issues in 2 cycles per SIMD, one of the multiply class (v_mul_lo/hi_u32, v_mad_u64_u32,
@@ -63,12 +63,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GOPS = 39321.6  # = 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes: multiply-class lane-ops per second (informational)
 
 
-_replayed = {}  # profile file -> csrc hash it was collected on (None when the file predates the stamps)
+_replayed = {}  # profile file -> device-code stamp it was collected on (None when the file predates the stamps)
 
 
 def _profile(name):
     """profiles/<PROFILE_ROUND>_<name>, or an earlier round's file while this round's has not been collected yet"""
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(p):
             return p
@@ -76,23 +76,24 @@ def _profile(name):
 
 
 def _load_profile(name):
-    """A committed PMC summary this line replays; remembers which sources it was collected on (boundless_amd.build.csrc_hash)."""
+    """A committed PMC summary this line replays; remembers which device code it was collected on (boundless_amd.build.device_code_hash)."""
     path = _profile(name)
     j = json.load(open(path))
-    _replayed[os.path.basename(path)] = j.get("csrc_sha") if isinstance(j, dict) else None
+    _replayed[os.path.basename(path)] = j.get("device_code_sha") if isinstance(j, dict) else None
     return j
 
 
 def replayed_profiles():
-    """Which figures of this line were not measured in this run, and whether the library that ran is the one they describe."""
-    from boundless_amd.build import csrc_hash
+    """Which figures of this line were not measured in this run, and whether the library that ran carries the device code they describe."""
+    from boundless_amd.build import csrc_hash, device_code_hash
 
-    cur = csrc_hash()
-    return {"csrc_sha": cur, "library_sha": csrc_hash(device_only=False), "files": dict(_replayed),
+    cur = device_code_hash()
+    return {"device_code_sha": cur, "library_sha": csrc_hash(device_only=False), "files": dict(_replayed),
             "profile_stale": any(v != cur for v in _replayed.values()) if _replayed else False,
             "note": "roofline.traffic, valu_view and roofline_job replay rocprofv3 --pmc passes committed under profiles/ (counters cannot be "
-                    "collected inside a timed run); profile_stale = at least one of them was collected on other DEVICE sources (*.hip, headers, tables) than "
-                    "the ones that just ran; library_sha covers the host-only sources too"}
+                    "collected inside a timed run); the stamp is the SHA-256 of the library's .hip_fatbin section (the gfx950 code objects): "
+                    "profile_stale = at least one replayed file was collected on other DEVICE CODE than the library that just ran carries; a "
+                    "host-only edit leaves it unchanged (tests/test_profile_stamp_cpu.py); library_sha = hash of all source text, host side included"}
 
 
 def _valu_per_wave():

@@ -324,7 +324,7 @@ template <int SKIP>
 static const char* launch_passA_multi(bx_ctx* c, R16Args a, size_t count, uint32_t cpw) {
     a.cols = (uint32_t)count;
     a.cpw = cpw;
-    size_t lds = ((size_t)4096 + 256) * 4;
+    size_t lds = ((size_t)4096 + 256) * 4 * 2;  // two tiles, alternating by column
     unsigned groups = (unsigned)((count + cpw - 1) / cpw);
     hipLaunchKernelGGL((ntt_passA_fwd12_multi_kernel<SKIP>), dim3(a.tiles * groups), dim3(256), lds, c->stream, a);
     BX_LAUNCH_CHECK(c);

@@ -40,6 +40,11 @@ struct R16Args {
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t i) { return i + (i >> 4); }
 
+// raw buffer descriptor over `bytes` bytes from a wave-uniform pointer (gfx950: DATA_FORMAT word 0x00020000, stride 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t col_rsrc(const uint32_t* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p), 0, bytes, 0x00020000);
+}
+
 // Butterflies.  Canonical in, canonical out by default; two conditional subtractions per butterfly can be dropped where the
 // value is consumed by a twiddle product next (a lazy Montgomery product accepts operands < 2P: 2P * P < 2.42 P^2):
 //   DIF (inverse):  b' = (a - b) * w   — the difference feeds the product directly: a - b + P in (0, 2P), no v_min;
@@ -129,30 +134,42 @@ __device__ __forceinline__ void tw_load(uint32_t (&tw)[16], const uint32_t* __re
         }
     }
 }
-template <int K, bool INV, bool S0ZERO, int SKIP>
+// IN_LAZY (forward only): the registers arrive in [0, 2P) (the previous step left its last stage uncorrected); the "a" operands of
+// the first stage are reduced here, where they are consumed — the "b" operands feed a product and need nothing.  OUT_LAZY
+// (forward only): the last stage leaves both outputs in [0, 2P) for a consumer that reduces on use (the next step, or the twist
+// product of pass A).  Together: 8 conditional subtractions per step boundary instead of 16.
+template <int K, bool INV, bool S0ZERO, int SKIP, bool IN_LAZY = false, bool OUT_LAZY = false>
 __device__ __forceinline__ void step_compute_tw(uint32_t (&x)[16], const uint32_t (&tw)[16]) {
+    static_assert(!(INV && (IN_LAZY || OUT_LAZY)), "lazy step boundaries are implemented for the forward (DIT) butterflies only");
+    static_assert(!(IN_LAZY && S0ZERO), "a step with trivial first twiddles adds its b operands: they must arrive canonical");
     constexpr int U = 16 >> K, E = 1 << K;
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t* xu = &x[w * E];
+        if (IN_LAZY) {
+#pragma unroll
+            for (int j = 0; j < E; j += 2) xu[j] = fp_reduce(xu[j]);
+        }
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const int k = INV ? K - kk : kk + 1;
             if (k <= SKIP) continue;
             const int half = 1 << (k - 1);
+            const bool last = kk == K - 1;
 #pragma unroll
             for (int jj = 0; jj < half; ++jj) {
                 if (S0ZERO && jj == 0) {
 #pragma unroll
                     for (int j = 0; j < E; j += 2 * half) {
-                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_one<false, true>(xu[j], xu[j + half]);
+                        if (!INV && OUT_LAZY && last) bfly_one<true, true>(xu[j], xu[j + half]);
+                        else if (!INV && BX_DIT_LAZY_B(last, j, half)) bfly_one<false, true>(xu[j], xu[j + half]);
                         else bfly_one(xu[j], xu[j + half]);
                     }
                 } else {
                     const uint32_t wv = tw[w * E + half - 1 + jj];
 #pragma unroll
                     for (int j = jj; j < E; j += 2 * half) {
-                        if (!INV && BX_DIT_LAZY_B(kk == K - 1, j, half)) bfly_tw<INV, true, true>(xu[j], xu[j + half], wv);
+                        if (!INV && ((OUT_LAZY && last) || BX_DIT_LAZY_B(last, j, half))) bfly_tw<INV, true, true>(xu[j], xu[j + half], wv);
                         else bfly_tw<INV>(xu[j], xu[j + half], wv);
                     }
                 }
@@ -235,9 +252,25 @@ __device__ __forceinline__ void glb_get(uint32_t (&x)[16], const R16Args& a, con
         }
         return;
     }
-    // 32-bit offsets from wave-uniform bases keep one VGPR per address
-    const uint32_t* sp = PASS_A ? src + (tile_off >> a.expand) : src + tile_off;
     const int rsh = a.row_shift + s0;
+    if (!PASS_A) {
+        // pass B: buffer loads — ONE per-lane byte offset per unit in voffset, the row of register `mid` in the scalar offset, so
+        // a load needs no vector address arithmetic (the 64-bit per-element form cost ~5 multiply-class VALU instructions per
+        // element: 13 % of the pass's issue cycles).  The descriptor covers the rest of the column from the tile's first word.
+        const __amdgpu_buffer_rsrc_t rs = col_rsrc(src + tile_off, (uint32_t)((a.in_col_stride - tile_off) * 4));
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+            uint32_t base_row, t;
+            unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+            const uint32_t vo = ((base_row << a.row_shift) + t) << 2;
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid)
+                x[w * E + mid] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (uint32_t)mid << (rsh + 2), 0);
+        }
+        return;
+    }
+    // 32-bit offsets from wave-uniform bases keep one VGPR per address
+    const uint32_t* sp = src + (tile_off >> a.expand);
 #pragma unroll
     for (int w = 0; w < U; ++w) {
         uint32_t base_row, t;
@@ -246,7 +279,7 @@ __device__ __forceinline__ void glb_get(uint32_t (&x)[16], const R16Args& a, con
 #pragma unroll
         for (int mid = 0; mid < E; ++mid) {
             const uint32_t off = ob + ((uint32_t)mid << rsh);
-            x[w * E + mid] = sp[PASS_A ? (off >> a.expand) : off];
+            x[w * E + mid] = sp[off >> a.expand];
         }
     }
     if (PASS_A && INV) {
@@ -287,6 +320,18 @@ __device__ __forceinline__ void glb_put(const uint32_t (&x)[16], const R16Args& 
     }
     uint32_t* dp = dst + tile_off;
     const int rsh = a.row_shift + s0;
+    if (!PASS_A) {  // buffer stores: per-lane offset per unit + scalar row offset (see glb_get)
+        const __amdgpu_buffer_rsrc_t rs = col_rsrc(dp, (uint32_t)((a.out_col_stride - tile_off) * 4));
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+            uint32_t base_row, t;
+            unit_coords<K>(w, s0, a.lt, tid, nt, base_row, t);
+            const uint32_t vo = ((base_row << a.row_shift) + t) << 2;
+#pragma unroll
+            for (int mid = 0; mid < E; ++mid) __builtin_amdgcn_raw_buffer_store_b32(x[w * E + mid], rs, vo, (uint32_t)mid << (rsh + 2), 0);
+        }
+        return;
+    }
     const bool tw = PASS_A && !INV && a.twist != nullptr;
     const uint32_t* tp = tw ? a.twist + tile_off : nullptr;
 #pragma unroll
@@ -330,25 +375,30 @@ __device__ __forceinline__ void fwd_first(uint32_t (&x)[16], uint32_t (&twn)[16]
     tw_load<K, true, SKIP>(tw0, ltw, 0, a.lt, tid, nt);
     glb_get<K, false, PASS_A>(x, a, src, tile_off, 0, tid, nt);
     if (!only) prefetch_dispatch(twn, ltw, a.lr, 4, a.lt, tid, nt);
-    step_compute_tw<K, false, true, SKIP>(x, tw0);
     if (only) {
+        step_compute_tw<K, false, true, SKIP>(x, tw0);
         glb_put<K, false, PASS_A>(x, a, dst, tile_off, 0, tid, nt);
     } else {
+        step_compute_tw<K, false, true, SKIP, false, true>(x, tw0);  // lazy out: the next step reduces what it adds
         lds_put<K>(x, s, 0, a.lt, tid, nt);
         __syncthreads();
     }
 }
+// A step's regrouping writes the very LDS words its own thread read (same K, same s0): only the barrier AFTER the writes is
+// needed — the next step reads other threads' words.
 template <int K, bool PASS_A>
 __device__ __forceinline__ void fwd_next(uint32_t (&x)[16], uint32_t (&twc)[16], const R16Args& a, uint32_t* s, const uint32_t* ltw,
                                          uint32_t* dst, size_t tile_off, int s0, bool last, uint32_t tid, uint32_t nt) {
     lds_get<K>(x, s, s0, a.lt, tid, nt);
     uint32_t twn[16];
     if (!last) prefetch_dispatch(twn, ltw, a.lr, s0 + 4, a.lt, tid, nt);
-    step_compute_tw<K, false, false, 0>(x, twc);
     if (last) {
+        // pass A's twist product takes operands in [0, 2P): leave the last stage lazy there
+        if (PASS_A && a.twist != nullptr) step_compute_tw<K, false, false, 0, true, true>(x, twc);
+        else step_compute_tw<K, false, false, 0, true, false>(x, twc);
         glb_put<K, false, PASS_A>(x, a, dst, tile_off, s0, tid, nt);
     } else {
-        __syncthreads();  // every thread has finished reading the previous regrouping
+        step_compute_tw<K, false, false, 0, true, true>(x, twc);
         lds_put<K>(x, s, s0, a.lt, tid, nt);
         __syncthreads();
 #pragma unroll
@@ -389,7 +439,8 @@ __global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
     // column-fastest order makes every workgroup in flight hit addresses 2^m words apart and hot-spots HBM channels:
     // measured 13 % slower).  Pass B additionally keeps tiles that share a 128-byte line on one XCD (block b is observed
     // on XCD b % 8; speed only).
-    const uint32_t bt = blockIdx.x % a.tiles, col = blockIdx.x / a.tiles;
+    const uint32_t tl = (uint32_t)__builtin_ctz(a.tiles);  // tiles is a power of two
+    const uint32_t bt = blockIdx.x & (a.tiles - 1u), col = blockIdx.x >> tl;
     const uint32_t tile = (!PASS_A && (a.tiles % 8u == 0u)) ? (bt % 8u) * (a.tiles / 8u) + bt / 8u : bt;
     const size_t tile_off = (size_t)tile * a.tile_stride;
     const uint32_t* src = a.in + (size_t)col * a.in_col_stride;
@@ -444,8 +495,7 @@ __global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
                 tw_load<4, true, 0>(twn, ltw, 0, a.lt, tid, nt);
             }
             step_compute_tw<4, true, false, 0>(x, twc);
-            __syncthreads();
-            lds_put<4>(x, s, 4 * si, a.lt, tid, nt);
+            lds_put<4>(x, s, 4 * si, a.lt, tid, nt);  // the words this thread just read: no barrier before the writes
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 16; ++i) twc[i] = twn[i];
@@ -470,7 +520,7 @@ __global__ __launch_bounds__(256) void ntt_passA_fwd12_multi_kernel(R16Args a) {
     a.lr = 12;
     a.lrows = 12;
     a.lt = 0;
-    const uint32_t tile = blockIdx.x % a.tiles, colg = blockIdx.x / a.tiles;
+    const uint32_t tile = blockIdx.x & (a.tiles - 1u), colg = blockIdx.x >> (uint32_t)__builtin_ctz(a.tiles);  // power of two
     const size_t tile_off = (size_t)tile << 12;
     uint32_t tw0[16], tw1[16], tw2[16], f[16];
     tw_load<4, true, SKIP>(tw0, ltw, 0, 0, tid, nt);
@@ -483,28 +533,46 @@ __global__ __launch_bounds__(256) void ntt_passA_fwd12_multi_kernel(R16Args a) {
         for (int mid = 0; mid < 16; ++mid) f[mid] = tp[tid + 256u * mid];
     }
     const uint32_t c0 = colg * a.cpw;
+    // Two LDS tiles, alternating by column: column c's first regrouping then cannot overtake another wave's last reads of column
+    // c - 1 (those are in the other tile), and a regrouping that rewrites the words its own thread read needs no barrier before
+    // it — two barriers per column instead of four.  Step boundaries are lazy (see step_compute_tw); the twist product takes
+    // the last stage's outputs unreduced.
     for (uint32_t c = 0; c < a.cpw && c0 + c < a.cols; ++c) {
         const uint32_t* src = a.in + (size_t)(c0 + c) * a.in_col_stride;
         uint32_t* dst = a.out + (size_t)(c0 + c) * a.out_col_stride + tile_off;
+        uint32_t* sc = s + (c & 1u) * (4096u + 256u);
         uint32_t x[16];
-        glb_get<4, false, true>(x, a, src, tile_off, 0, tid, nt);
-        step_compute_tw<4, false, true, SKIP>(x, tw0);
-        if (c) __syncthreads();  // the previous column's last regrouping has been read by everyone
-        lds_put<4>(x, s, 0, 0, tid, nt);
-        __syncthreads();
-        lds_get<4>(x, s, 4, 0, tid, nt);
-        step_compute_tw<4, false, false, 0>(x, tw1);
-        __syncthreads();
-        lds_put<4>(x, s, 4, 0, tid, nt);
-        __syncthreads();
-        lds_get<4>(x, s, 8, 0, tid, nt);
-        step_compute_tw<4, false, false, 0>(x, tw2);
-        if (has_twist) {
+        // buffer loads / stores: the per-lane byte offset is loop-invariant, the column and the row of register `mid` are scalar
+        if (a.expand == 2) {
+            const __amdgpu_buffer_rsrc_t rs = col_rsrc(src + (tile_off >> 2), 4096u);
+            const __attribute__((ext_vector_type(4))) uint32_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16u, 0, 0);
 #pragma unroll
-            for (int mid = 0; mid < 16; ++mid) dst[tid + 256u * mid] = fp_mul(x[mid], f[mid]);
+            for (int i = 0; i < 16; ++i) x[i] = v[i >> 2];
         } else {
+            const __amdgpu_buffer_rsrc_t rs = col_rsrc(src + tile_off, 16384u);
 #pragma unroll
-            for (int mid = 0; mid < 16; ++mid) dst[tid + 256u * mid] = x[mid];
+            for (int i = 0; i < 4; ++i) {
+                const __attribute__((ext_vector_type(4))) uint32_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 64u, 16u * i, 0);
+                x[4 * i] = v[0]; x[4 * i + 1] = v[1]; x[4 * i + 2] = v[2]; x[4 * i + 3] = v[3];
+            }
+        }
+        step_compute_tw<4, false, true, SKIP, false, true>(x, tw0);
+        lds_put<4>(x, sc, 0, 0, tid, nt);
+        __syncthreads();
+        lds_get<4>(x, sc, 4, 0, tid, nt);
+        step_compute_tw<4, false, false, 0, true, true>(x, tw1);
+        lds_put<4>(x, sc, 4, 0, tid, nt);
+        __syncthreads();
+        lds_get<4>(x, sc, 8, 0, tid, nt);
+        const __amdgpu_buffer_rsrc_t rd = col_rsrc(dst, 16384u);
+        if (has_twist) {
+            step_compute_tw<4, false, false, 0, true, true>(x, tw2);
+#pragma unroll
+            for (int mid = 0; mid < 16; ++mid) __builtin_amdgcn_raw_buffer_store_b32(fp_mul(x[mid], f[mid]), rd, tid * 4u, 1024u * mid, 0);
+        } else {
+            step_compute_tw<4, false, false, 0, true, false>(x, tw2);
+#pragma unroll
+            for (int mid = 0; mid < 16; ++mid) __builtin_amdgcn_raw_buffer_store_b32(x[mid], rd, tid * 4u, 1024u * mid, 0);
         }
     }
 }

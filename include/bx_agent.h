@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ------------------------------------------------------------------------------------------------ planner ---- */
 typedef struct bx_planner bx_planner;
@@ -321,6 +325,9 @@ uint32_t bx_agent_lane_count(const bx_agent* a);
 int32_t bx_agent_lane_device(const bx_agent* a, uint32_t lane);
 uint64_t bx_agent_lane_tasks_done(const bx_agent* a, uint32_t lane);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

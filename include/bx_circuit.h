@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BX_MAX_TAPS 8   /* back offsets per column */
 #define BX_MAX_COMBOS 16 /* distinct tap sets ("combos", as in upstream's TapSet) over the three trace groups + the check group */
@@ -126,6 +130,9 @@ const char* bx_verify_segment_with_context(const uint32_t* seal, size_t seal_wor
  * built-in table (w_code = 16, po2 9..24).  Seconds at po2 >= 18; results are cached per (po2, w_code). */
 const char* bx_synthetic_control_id_host(uint32_t po2, uint32_t w_code, uint32_t id_out[8]);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

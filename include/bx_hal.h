@@ -38,6 +38,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BX_P 2013265921u
 #define BX_DIGEST_WORDS 8
@@ -196,6 +200,9 @@ int bx_trace_level(void);
 /* Tunables (NTT pass split, tile sizes); name/value pairs documented in DESIGN.md.  Unknown names error. */
 const char* bx_set_tunable(bx_ctx* ctx, const char* name, long value);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

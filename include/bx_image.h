@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BX_PAGE_BYTES 1024u
 #define BX_PAGE_WORDS 256u
@@ -78,6 +82,9 @@ const char* bx_hash_fold_indexed(bx_ctx* ctx, bx_buf out_digests, bx_buf in_dige
  * bx_hash_rows hashes into page digests. */
 const char* bx_image_page_cells(bx_ctx* ctx, bx_buf out_matrix, bx_buf pages_raw, size_t n_pages);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

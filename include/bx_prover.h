@@ -70,6 +70,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct bx_prover bx_prover;
 
@@ -159,6 +163,9 @@ const char* bx_verify_segment(const uint32_t* seal, size_t seal_words);
  * verification of a join's result is on the critical path of a job's join tail. */
 const char* bx_verify_set_threads(int threads);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

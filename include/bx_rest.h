@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct bx_rest_client bx_rest_client;
 
@@ -49,6 +53,9 @@ bx_hot_store_ops bx_rest_hot_store_ops(bx_rest_client* c);
 uint64_t bx_rest_client_requests(const bx_rest_client* c);
 uint64_t bx_rest_client_connects(const bx_rest_client* c);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from boundless_amd.build import csrc_hash  # noqa: E402
+from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def col(row, *names):
@@ -60,7 +60,7 @@ def main(copies_csv, kernels_csv, dst, bytes_each=0):
                 cur = min(b, e)
         covered_total += cov
         dur_total += e - s
-    out = {"csrc_sha": csrc_hash(),
+    out = {"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(),
            "note": "rocprofv3 --kernel-trace --memory-copy-trace of bench.py --segment-bytes 80000000: the 8 MiB pieces of the segments' uploads "
                    "(host-to-device copies longer than 50 us, on the provers' copy streams) and the kernels running meanwhile",
            "pieces": len(big), "piece_bytes": 8 << 20, "pieces_per_segment": (-(-bytes_each // (8 << 20)) if bytes_each else None),

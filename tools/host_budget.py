@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from boundless_amd.build import csrc_hash  # noqa: E402
+from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def run(extra):
@@ -36,7 +36,7 @@ def run(extra):
 
 if __name__ == "__main__":
     STEPS = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "10"
-    res = {"csrc_sha": csrc_hash(), "what": __doc__.split("\n\n")[0], "command": f"bench.py --steps {STEPS} --warmup 3 --no-cpu-baseline [--cpus 2] --wait block|spin",
+    res = {"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(), "what": __doc__.split("\n\n")[0], "command": f"bench.py --steps {STEPS} --warmup 3 --no-cpu-baseline [--cpus 2] --wait block|spin",
            "cpus_allowed": len(os.sched_getaffinity(0)), "runs": {}}
     for cpus in (0, 2, 1):
         for wait in ("block", "poll", "spin"):

@@ -10,7 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from boundless_amd.build import csrc_hash  # noqa: E402
+from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def main(src, segments, dst):
@@ -23,7 +23,7 @@ def main(src, segments, dst):
         elif r["Counter_Name"] == "SQ_WAVES":
             waves[r["Kernel_Name"]] += float(r["Counter_Value"])
     total = sum(tot.values())
-    out = {"csrc_sha": csrc_hash(), "note": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES on bench.py ({segments} segments proved in the profiled process, warm-up and "
+    out = {"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(), "note": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES on bench.py ({segments} segments proved in the profiled process, warm-up and "
                    "isolated probe included); wave-level VALU instructions",
            "segments": segments, "valu_wave_insts_total": total, "per_segment": total / segments,
            "per_kernel_per_segment": {k[:60]: v / segments for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},

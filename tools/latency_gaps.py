@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from boundless_amd.build import csrc_hash  # noqa: E402
+from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def main(path, out):
@@ -30,7 +30,7 @@ def main(path, out):
     rows.sort()
     # proofs are separated by the longest idle gaps; take the kernels between occurrences of witness_code_kernel
     starts = [i for i, r in enumerate(rows) if "witness_code_kernel" in r[2]]
-    res = {"csrc_sha": csrc_hash(), "note": "one segment in flight; per proof (median over the proofs of the run)", "proofs": []}
+    res = {"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(), "note": "one segment in flight; per proof (median over the proofs of the run)", "proofs": []}
     for a, b in zip(starts[:-1], starts[1:]):
         seg = rows[a:b]
         busy_full = busy_small = idle = 0

@@ -13,7 +13,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from boundless_amd.build import csrc_hash  # noqa: E402
+from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def load(path, name):
@@ -36,7 +36,7 @@ def main():
         wb = write.get(k, 0.0) * 1024
         out[k] = {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / max(wc.get(k, n), 1),
                   "hbm_bytes_per_launch": fb / n + wb / max(wc.get(k, n), 1)}
-    json.dump({"csrc_sha": csrc_hash(), "note": "FETCH_SIZE doubled (gfx950 calibration), WRITE_SIZE as reported; separate --pmc passes", "kernels": out},
+    json.dump({"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(), "note": "FETCH_SIZE doubled (gfx950 calibration), WRITE_SIZE as reported; separate --pmc passes", "kernels": out},
               open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if "ntt" in k or "hash_rows" in k:

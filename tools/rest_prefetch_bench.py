@@ -50,7 +50,7 @@ def main():
                 print(json.dumps({"what": "HIP prover as a REST worker of the API stub; every segment GET delayed", "po2": args.po2, "segments": args.segments,
                                   "get_ms": args.get_ms, "lanes": lanes, "prefetch": prefetch, "done": done, "all_done": ok,
                                   "seconds": round(wall, 3), "proofs_per_s": round(args.segments / wall, 2),
-                                  "ms_per_proof_per_lane": round(wall / args.segments * lanes * 1e3, 1), "csrc_sha": build.csrc_hash()}), flush=True)
+                                  "ms_per_proof_per_lane": round(wall / args.segments * lanes * 1e3, 1), "device_code_sha": build.device_code_hash(), "csrc_sha": build.csrc_hash()}), flush=True)
             finally:
                 a.close()
                 w.close()
