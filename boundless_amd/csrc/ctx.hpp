@@ -51,6 +51,7 @@ struct bx_ctx {
     // NTT tables (device): stage table index 2^(s-1)+e -> w_{2^s}^{+-e} (Montgomery)
     uint32_t* d_tw_fwd = nullptr;
     uint32_t* d_tw_inv = nullptr;
+    uint2* d_tw_fwd_pair = nullptr;  // {d_tw_fwd[i], P - d_tw_fwd[i]}: the two twiddles of a fused-reduction butterfly (ntt_r16.hpp)
     std::map<bx::TwistKey, uint32_t*> twist;
     std::map<int, bx::ZkTab> zk;
     std::map<int, uint32_t*> zk_full;  // n -> 3^bitrev_n(i), i < 2^n (fused interpolate + zk_shift)
@@ -94,6 +95,10 @@ struct bx_ctx {
     long ntt_cols_per_wg = 8;  // forward pass A (2^12 tiles): columns sharing one load of the tile's twist + twiddles
     long ntt_group_cols = 0;   // forward transform: columns per pass-A + pass-B group (0 = all columns per pass)
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
+    // forward passes with fused-reduction butterflies (ntt_r16.hpp): bit 0 = multi-column pass A, bit 1 = pass B.  Off by default:
+    // 21 % fewer VALU instructions, but every one of them a v_mad_u64_u32 / v_mul_lo_u32 — measured 6 % / 8 % / 13 % SLOWER than
+    // the canonical kernels with bit 0 / bit 1 / both set (profiles/r05_lde_fused_ab.jsonl); kept selectable and parity-tested
+    long ntt_fused = 0;
     long hash_rows_block = 256;
     long fold_deep = 2;              // large Merkle layers: up to this many levels per launch, depth first per lane (1 = one launch per layer)
     long dev_draws = 0;  // 1 = the prover draws the FRI challenges (which depend only on a Merkle root) on the device (bx_transcript_step): three blocking

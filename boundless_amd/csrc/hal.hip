@@ -462,6 +462,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
         c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
+    } else if (!strcmp(name, "ntt_fused")) {
+        BX_REQUIRE(c, value >= 0 && value <= 3, "ntt_fused out of range [0,3] (bit 0: pass A, bit 1: pass B)");
+        c->ntt_fused = value;
     } else if (!strcmp(name, "scan_lookback")) {
         c->scan_lookback = value != 0;
     } else if (!strcmp(name, "eval_x4")) {

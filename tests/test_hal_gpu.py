@@ -21,6 +21,9 @@ def hal():
     h.close()
 
 
+oracle_P = 2013265921
+
+
 def rnd(seed, n):
     return ol.random_elems(np.random.default_rng(seed), n)
 
@@ -163,6 +166,32 @@ def test_lde_columns_per_workgroup(hal, oracle, cpw, count):
         assert np.array_equal(io.view(), ref2)
     finally:
         hal.set_tunable("ntt_cols_per_wg", 8)
+
+
+@pytest.mark.parametrize("fused", [1, 2, 3])
+@pytest.mark.parametrize("bits,count", [(14, 3), (16, 5), (17, 2), (18, 9), (19, 2), (20, 3)])
+def test_lde_fused_reduction_kernels_are_bit_exact(hal, oracle, fused, bits, count):
+    """Tunable ntt_fused (off by default, ntt_r16.hpp): the forward passes with fused-reduction butterflies — registers hold arbitrary
+    u32 residues, memory holds canonical words — give the oracle's words for every pass-B geometry they cover (2^8 ... 2^12 rows),
+    with either pass or both in that form, for the expanding LDE and for the in-place evaluate; extreme inputs (0, P - 1) included."""
+    hal.set_tunable("ntt_fused", fused)
+    try:
+        n = 1 << bits
+        x = rnd(bits * 10 + fused, n * count)
+        x[:n] = 0
+        x[n:2 * n] = oracle_P - 1
+        out = hal.alloc(4 * n * count)
+        hal.batch_expand_into_evaluate_ntt(out, hal.copy_from(x), count, 2)
+        ref = np.zeros(4 * n * count, np.uint32)
+        oracle.bxo_batch_expand_into_evaluate_ntt(ref, x, count, n, 2)
+        assert np.array_equal(out.view(), ref)
+        io = hal.copy_from(x)
+        hal.batch_evaluate_ntt(io, count, 0)
+        ref2 = x.copy()
+        oracle.bxo_batch_evaluate_ntt(ref2, count, n, 0)
+        assert np.array_equal(io.view(), ref2)
+    finally:
+        hal.set_tunable("ntt_fused", 0)
 
 
 def test_ntt_linearity_full_size(hal):

@@ -59,6 +59,29 @@ __global__ __launch_bounds__(256) void k_bfly(uint32_t* out, int iters, uint32_t
     if (acc == 0x12345u) out[0] = acc;
 }
 
+// the fused-reduction butterfly of ntt_r16.hpp: u = REDC(a R + b w), d = REDC(a R + b (P - w)) — 7 multiply-class instructions
+template <int ILP>
+__global__ __launch_bounds__(256) void k_bfly_fused(uint32_t* out, int iters, uint32_t seed, uint32_t p_arg, uint32_t npi_arg) {
+    const uint32_t R = 268435454u;
+    uint32_t a[ILP], b[ILP], w[ILP], wn[ILP];
+#pragma unroll
+    for (int j = 0; j < ILP; ++j) { a[j] = (threadIdx.x * 7u + j * 11u + seed) % P; b[j] = (threadIdx.x * 13u + j * 5u + seed) % P; w[j] = (seed * (j + 3u) + 99u) % P; wn[j] = P - w[j]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+            const uint64_t t0 = (uint64_t)a[j] * R;
+            const uint64_t tu = t0 + (uint64_t)b[j] * w[j], td = t0 + (uint64_t)b[j] * wn[j];
+            const uint32_t mu = (uint32_t)tu * NEG_P_INV, md = (uint32_t)td * NEG_P_INV;
+            a[j] = (uint32_t)((tu + (uint64_t)mu * P) >> 32);
+            b[j] = (uint32_t)((td + (uint64_t)md * P) >> 32);
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; ++j) acc ^= a[j] ^ b[j];
+    if (acc == 0x12345u) out[0] = acc;
+}
+
 template <class K, class... A>
 static double time_kernel(K kernel, int blocks, int iters, A... extra) {
     uint32_t* d;
@@ -90,7 +113,7 @@ static void run(const char* name, K kernel, int blocks, double* base) {
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
-    for (int wps : {8, 4}) {
+    for (int wps : {8, 4, 2}) {
         const int blocks = prop.multiProcessorCount * wps;
         printf("{\"waves_per_simd\":%d}\n", wps);
         double base = 0;
@@ -112,6 +135,13 @@ int main() {
             const double bf_per_simd = (double)blocks * 4 * iters * 8 / 1024.0;
             printf("{\"seq\":\"non-lazy DIT butterfly (6 mul-class + 5 cheap), constants as %s\",\"ns_per_wave_butterfly_per_simd\":%.3f,\"model_ns_at_1.9_1.05\":16.65}\n",
                    args ? "kernel arguments (SGPR)" : "literals", ms * 1e6 / bf_per_simd);
+        }
+        {
+            const double bf8 = (double)blocks * 4 * iters * 8 / 1024.0, bf16 = (double)blocks * 4 * iters * 16 / 1024.0;
+            printf("{\"seq\":\"fused-reduction butterfly (7 mul-class), 8 independent per wave\",\"ns_per_wave_butterfly_per_simd\":%.3f}\n",
+                   time_kernel(k_bfly_fused<8>, blocks, iters, P, NEG_P_INV) * 1e6 / bf8);
+            printf("{\"seq\":\"fused-reduction butterfly (7 mul-class), 16 independent per wave\",\"ns_per_wave_butterfly_per_simd\":%.3f}\n",
+                   time_kernel(k_bfly_fused<16>, blocks, iters, P, NEG_P_INV) * 1e6 / bf16);
         }
     }
     return 0;
