@@ -496,6 +496,8 @@ def main():
     ap.add_argument("--wait", choices=("block", "spin", "poll"), default=None, help="how host threads wait for their stream (BX_WAIT; library default: poll = hipEventQuery + usleep)")
     ap.add_argument("--native-agent", action="store_true", help="second N>1 design: ONE process, no torch.distributed; the native agent (include/bx_agent.h) runs "
                     "--inflight lanes on each of --gpus devices, all claiming from one task db; value = segments/s through the whole feed loop")
+    ap.add_argument("--inject-child-failure", action="store_true", help="test hook (tests/test_fullsize_gpu.py): the native-agent child that rank 0 spawns at N > 1 is "
+                    "given a device that does not exist, so it fails at once; the primary line must still come out and no rank may hang")
     ap.add_argument("--no-native-agent-extra", action="store_true", help="N>1 under torchrun: skip the untimed native-agent run that rank 0 spawns after the timed region")
     ap.add_argument("--no-live-profile", action="store_true", help="do not bracket the entry points with HIP events in the timed region (measures what those events cost: "
                     "an event record is a barrier packet between two kernels; the per-kernel figures then come from the isolated probe only)")
@@ -787,17 +789,58 @@ def main():
         # HIP events on the HAL stream; agrees with the rocprofv3 summary of `--inflight 1`); the in-region figure (agrees
         # with the rocprofv3 summary of the default command) is reported beside it.
         def ntt_valu_view(r):
-            # VALU-issue view of the same launch: wave-instructions per output element of the two LDE kernels from the
-            # committed PMC counts (pass A multi-column: 8192 elements per wave, pass B: 1024 elements per wave)
+            # VALU-issue view of the same launch.  Instruction COUNTS per wave come from the committed PMC pass (SQ_INSTS_VALU / SQ_WAVES;
+            # pass A multi-column: 8192 output elements per wave, pass B: 1024), their split into issue classes from the static mix of
+            # the two kernels' gfx950 text (tools/isa_mix.py; pass B is straight-line code, so its static count must equal the PMC's).
+            # Two yardsticks: (1) `frac_weighted_issue` = the class-weighted bound VERDICT r04 asked for (2 cycles per cheap, 4 per
+            # multiply-class instruction at 2.4 GHz) — NOT reachable: profiles/r05_microbench5_class_mix.jsonl shows that in a MIXED
+            # stream every VALU instruction issues at ~1.75 ns whatever its class; (2) `frac_of_mixed_stream_rate` = against the rate a
+            # bare loop of the same butterflies reaches on this chip (profiles/r05_microbench4_operand_kinds.jsonl), which is the bound.
             try:
                 pmc = _valu_per_wave()
-                a = [v for k, v in pmc.items() if "ntt_passA_fwd12_multi_kernel" in k][0] / 8192.0
-                b = [v for k, v in pmc.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0] / 1024.0
+                ia = [v for k, v in pmc.items() if "ntt_passA_fwd12_multi_kernel" in k][0]
+                ib = [v for k, v in pmc.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0]
+                a, b = ia / 8192.0, ib / 1024.0
                 out_elems = r["achieved_bytes_per_launch"] / 4.0 / 1.25
-                rate = out_elems * (a + b) / (r["avg_ms_per_launch"] * 1e-3)
-                r["valu_view"] = {"wave_insts_per_output_element": round(a + b, 4), "wave_insts_per_s": rate,
-                                  "issue_peak_mul": 1024 * 2.4e9 / 4, "issue_peak_cheap": 1024 * 2.4e9 / 2,
-                                  "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3)}
+                secs = r["avg_ms_per_launch"] * 1e-3
+                rate = out_elems * (a + b) / secs
+                view = {"wave_insts_per_output_element": round(a + b, 4), "wave_insts_per_s": rate,
+                        "valu_insts_per_wave": {"pass_a_8_columns": ia, "pass_b": ib},
+                        "ns_per_wave_inst_per_simd": round(1024.0 / rate * 1e9, 4),
+                        "issue_peak_mul": 1024 * 2.4e9 / 4, "issue_peak_cheap": 1024 * 2.4e9 / 2,
+                        "frac_of_mul_class_peak": round(rate / (1024 * 2.4e9 / 4), 3)}
+                try:
+                    mix = _load_profile("lde_isa_mix.json")["kernels"]
+                    ma = [v for k, v in mix.items() if "ntt_passA_fwd12_multi_kernel<2, false>" in k][0]
+                    mb = [v for k, v in mix.items() if "ntt_r16_kernel<false, false, 0, 10, 4" in k][0]
+                    fa = ma["mul_class_insts"] / ma["valu_insts"]
+                    fb = mb["mul_class_insts"] / mb["valu_insts"]
+                    cyc = a * (4 * fa + 2 * (1 - fa)) + b * (4 * fb + 2 * (1 - fb))  # SIMD cycles per output element, per wave-lane group
+                    view.update({"static_mix": {"pass_a": {"mul_class_insts": ma["mul_class_insts"], "cheap_insts": ma["cheap_insts"],
+                                                           "note": "whole kernel text (prologue + one trip of each column-loop variant)"},
+                                                "pass_b": {"mul_class_insts": mb["mul_class_insts"], "cheap_insts": mb["cheap_insts"],
+                                                           "static_valu_insts": mb["valu_insts"], "pmc_valu_insts_per_wave": ib}},
+                                 "weighted_issue_cycles_per_output_element": round(cyc, 4),
+                                 "frac_weighted_issue": round(out_elems * cyc / secs / (1024 * 2.4e9), 3)})
+                except Exception:
+                    pass
+                try:
+                    ref_ns = None
+                    for ln in open(_profile("microbench4_operand_kinds.jsonl")):
+                        d = json.loads(ln)
+                        if "waves_per_simd" in d and ref_ns is not None:
+                            break  # the first block is 8 waves per SIMD
+                        if d.get("seq", "").startswith("non-lazy DIT butterfly") and "literals" in d["seq"]:
+                            ref_ns = d["ns_per_wave_butterfly_per_simd"] / 11.0
+                    if ref_ns:
+                        view.update({"mixed_stream_ns_per_wave_inst": round(ref_ns, 4),
+                                     "frac_of_mixed_stream_rate": round(ref_ns / (1024.0 / rate * 1e9), 3)})
+                except Exception:
+                    pass
+                if r.get("traffic"):
+                    view["traffic_GBps"] = round(r["traffic"] / secs / 1e9, 1)
+                    view["traffic_frac_of_hbm_peak"] = round(r["traffic"] / secs / 1e9 / HBM_PEAK_GBPS, 3)
+                r["valu_view"] = view
             except Exception:
                 pass
             return r
@@ -952,7 +995,9 @@ def main():
                     time.sleep(0.05)
                 cmd = [sys.executable, os.path.abspath(__file__), "--native-agent", "--gpus", str(world), "--steps", str(max(2, args.steps // 2)),
                        "--warmup", "1", "--po2", str(args.po2), "--widths", args.widths, "--inflight", str(args.inflight)]
-                if args.device is not None:
+                if args.inject_child_failure:
+                    cmd += ["--device", "99"]
+                elif args.device is not None:
                     cmd += ["--device", str(args.device)]
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                          "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}

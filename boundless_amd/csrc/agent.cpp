@@ -822,6 +822,12 @@ struct bx_agent {
         std::condition_variable cv;
         std::unique_ptr<Fetched> slot;
         bool quitting = false;
+        bool dead = false;  // the fetcher thread gave up (it could not even allocate a mailbox entry): take() must not wait for it
+        void fetcher_died() {
+            std::lock_guard<std::mutex> l(mu);
+            dead = true;
+            cv.notify_all();
+        }
         void put(std::unique_ptr<Fetched> w) {
             std::lock_guard<std::mutex> l(mu);
             slot = std::move(w);
@@ -835,7 +841,7 @@ struct bx_agent {
         std::unique_ptr<Fetched> take(std::atomic<int>& stop_flag) {  // lane side; nullptr = stop was requested while waiting
             std::unique_lock<std::mutex> l(mu);
             while (!slot) {
-                if (stop_flag.load(std::memory_order_relaxed)) return nullptr;
+                if (dead || stop_flag.load(std::memory_order_relaxed)) return nullptr;
                 // system_clock on purpose: a steady-clock wait is pthread_cond_clockwait, which the ThreadSanitizer of this
                 // toolchain does not intercept (it then reports the re-lock inside the wait as a double lock)
                 cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
@@ -1329,7 +1335,10 @@ struct bx_agent {
                             w->fetched = true;
                         }
                     } catch (const std::exception& e) {
-                        if (!w) return;  // not even the mailbox entry could be allocated: the lane will see a stop
+                        if (!w) {  // not even the mailbox entry could be allocated: tell the lane, which then ends like on a stop
+                            pf.fetcher_died();
+                            return;
+                        }
                         if (w->rc != 1) {
                             w->rc = -1;
                             snprintf(w->eb, sizeof w->eb, "exception in the fetcher: %s", e.what());
@@ -1668,7 +1677,10 @@ const char* bx_plan_job(bx_mem_taskdb* t, const char* job, uint64_t n_segments, 
                     const char* pre[1] = {m.c_str()};
                     e = bx_mem_taskdb_create_task_ex(t, join_stream.c_str(), job, "resolve",
                                                      ("{\"Resolve\":{\"max_idx\":" + m + ",\"union_max_idx\":null}}").c_str(), pre, 1,
-                                                     plan.resolve_retries, plan.resolve_timeout);  // x assumption_count, which is 1 here
+                                                     plan.resolve_retries, plan.resolve_timeout);
+                    // DEVIATION from executor.rs:179-205: the reference multiplies resolve_timeout by assumption_count =
+                    // assumptions + keccak requests, which is 0 for a job like this one — a timeout of 0 s, i.e. a row its
+                    // requeue monitor would put back at once.  This planner keeps resolve_timeout x 1.
                     created += !e;
                     if (!e) {
                         const char* pre2[1] = {"resolve"};
@@ -1979,7 +1991,10 @@ const char* bx_agent_poll_work(bx_agent* a, int64_t max_idle_polls, uint64_t* ta
                 const double interval = a->cfg.requeue_poll_interval > 0 ? a->cfg.requeue_poll_interval : 5.0;
                 while (!monitor_quit.load(std::memory_order_relaxed) && !a->stop.load(std::memory_order_relaxed)) {
                     char eb[256] = {0};
-                    (void)a->taskdb.requeue_tasks(a->taskdb.user, 100, eb, sizeof eb);  // an error is retried at the next tick, as in the reference
+                    // an error is retried at the next tick, as in the reference, which logs both outcomes (lib.rs:536-551)
+                    const int n = a->taskdb.requeue_tasks(a->taskdb.user, 100, eb, sizeof eb);
+                    if (n < 0) fprintf(stderr, "[bx_agent] requeue monitor: requeue_tasks failed: %s\n", eb);
+                    else if (n > 0) fprintf(stderr, "[bx_agent] requeue monitor: %d task(s) requeued after their timeout\n", n);
                     auto until = Clock::now() + std::chrono::duration<double>(interval);
                     while (!monitor_quit.load(std::memory_order_relaxed) && !a->stop.load(std::memory_order_relaxed) && Clock::now() < until)
                         std::this_thread::sleep_for(std::chrono::duration<double>(std::min(interval, 0.02)));

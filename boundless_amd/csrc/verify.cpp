@@ -132,10 +132,12 @@ std::atomic<int> g_verify_threads{0};
 int verify_threads() {
     int n = g_verify_threads.load(std::memory_order_relaxed);
     if (n > 0) return n;
-    if (const char* e = getenv("BX_VERIFY_THREADS")) {
-        n = atoi(e);
-        if (n >= 1 && n <= 64) return n;
-    }
+    static const int from_env = [] {  // read once: getenv is not safe against a concurrent setenv (e.g. from Python)
+        const char* e = getenv("BX_VERIFY_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= 64 ? v : 0;
+    }();
+    if (from_env) return from_env;
     unsigned hw = std::thread::hardware_concurrency();
     return hw >= 4 ? 4 : hw >= 1 ? (int)hw : 1;
 }

@@ -191,7 +191,9 @@ typedef struct bx_job_plan {
                            * top levels another agent joins from the subtree roots (one process per GPU: the roots cross GPUs, the
                            * segments never do) */
     int32_t prove_timeout, join_timeout, resolve_timeout, finalize_timeout; /* timeout_secs of the tasks created; <= 0 = the
-                           * agent's defaults 30 / 10 / 120 / 10 (bento/crates/workflow/src/lib.rs:108-136) */
+                           * agent's defaults 30 / 10 / 120 / 10 (bento/crates/workflow/src/lib.rs:108-136).  The resolve row gets
+                           * resolve_timeout x 1: the reference multiplies by its assumption count (executor.rs:179-205), which is 0
+                           * for a job without assumptions or keccak requests — a deliberate deviation, a 0 s timeout requeues at once */
 } bx_job_plan;
 /* root_task (may be NULL) receives the task number whose receipt is the job's root: the last join, or task 0 for a single segment. */
 const char* bx_plan_job(bx_mem_taskdb* t, const char* job_id, uint64_t n_segments, const bx_job_plan* plan /* NULL = defaults */,

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize: a gpu test at BASELINE.json's full sizes that also spends about a minute in the CPU oracle "
+                                       "(part of `-m gpu`; deselect locally with -m 'gpu and not fullsize')")
 
 
 @pytest.fixture(scope="session")

@@ -206,6 +206,50 @@ def test_default_multi_rank_bench_path_static_split_is_bit_exact(tmp_path):
     assert sum(na["segments_per_device"].values()) == na["config"]["segments_proved"] and na["value"] > 0
 
 
+def _run_bench_ranks(ranks, extra, timeout=900):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--dist-backend", "gloo", "--device", "0",
+           "--no-cpu-baseline", "--no-agent-mode"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]), time.time() - t0
+
+
+def test_world_size_8_path_of_the_drivers_command_on_one_gpu():
+    """The first real 8-GPU run of `bench.py --gpus 8` must not be the first time HEAD's N = 8 path executes: eight
+    torch.distributed ranks (gloo) share the ONE GPU of the test box — rendezvous, static split, barriers, max over ranks, one row per
+    rank, and the native-agent child that rank 0 spawns over eight device slots while the other ranks wait on the c10d store.  Then
+    the same with that child made to fail at once: the primary line still comes out, the failure is reported in it, nobody hangs.
+    Not a scaling measurement (compose.yml:113 runs one agent per GPU; here all eight sit on one)."""
+    steps, lanes = 2, 1
+    extra = ["--po2", "12", "--widths", "4,12,4", "--warmup", "1", "--steps", str(steps), "--inflight", str(lanes)]
+    out, _ = _run_bench_ranks(8, extra)
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["segments_proved"] == 8 * steps * lanes
+    assert out["backend"] == {"name": "gloo", "world_size": 8}
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and all(r["proofs"] == steps * lanes for r in out["per_rank"])
+    na = out["native_agent"]
+    assert "error" not in na, na
+    assert na["n_gpus"] == 8 and sum(na["segments_per_device"].values()) == na["config"]["segments_proved"] and na["value"] > 0
+    bad, seconds = _run_bench_ranks(8, extra + ["--inject-child-failure"])
+    assert bad["n_gpus"] == 8 and bad["value"] > 0 and len(bad["per_rank"]) == 8
+    assert "error" in bad["native_agent"], bad["native_agent"]
+    assert seconds < 300, f"a failing native-agent child held the ranks for {seconds:.0f}s"
+
+
 def test_rccl_rendezvous_barrier_and_all_reduce_of_the_multi_rank_path(tmp_path):
     """The driver's N > 1 command uses the default backend (nccl = RCCL), which two ranks cannot share one GPU for.  What a
     one-GPU box can run of it is one rank with the process group forced on: RCCL initialises on the device, the barriers of

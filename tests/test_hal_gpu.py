@@ -169,7 +169,7 @@ def test_lde_columns_per_workgroup(hal, oracle, cpw, count):
 
 
 @pytest.mark.parametrize("fused", [1, 2, 3])
-@pytest.mark.parametrize("bits,count", [(14, 3), (16, 5), (17, 2), (18, 9), (19, 2), (20, 3)])
+@pytest.mark.parametrize("bits,count", [(14, 3), (16, 5), (18, 9), (19, 2), (20, 3), (21, 2), (22, 1)])
 def test_lde_fused_reduction_kernels_are_bit_exact(hal, oracle, fused, bits, count):
     """Tunable ntt_fused (off by default, ntt_r16.hpp): the forward passes with fused-reduction butterflies — registers hold arbitrary
     u32 residues, memory holds canonical words — give the oracle's words for every pass-B geometry they cover (2^8 ... 2^12 rows),

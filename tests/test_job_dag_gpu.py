@@ -5,6 +5,8 @@ children's seals), so the rollup seal commits to every seal below it: recomputin
 every one of the 31 proofs of the job word for word.  Reference flow: executor.rs:566-698 (planner -> task rows), join.rs:18-113,
 resolve.rs, finalize.rs; prerequisites bento/crates/taskdb/migrations/1_taskdb.sql:197-228,296-306.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -186,5 +188,94 @@ def test_prove_tasks_with_the_stand_in_lift_leg_on_the_gpu():
         rollup = ag.deserialize_receipt(a.store.get("receipts/stark/LG.synthetic"))
         assert np.array_equal(rollup.seal, seals[root])
         assert f'task_operations_total{{task_name="prove",operation_type="lift",status="success"}} {n}' in a.metrics_text()
+    finally:
+        a.close()
+
+
+class _RecordingStore:
+    """The library's in-memory hot store behind a `bx_hot_store_ops` table whose SETEX also keeps a copy of the values of chosen keys:
+    a planned job unlinks every intermediate receipt as soon as its parent has joined it, and this test wants to look at three of them.
+    Test-side only (ctypes callbacks that forward to the native function pointers); the product's store and agent are unchanged."""
+
+    def __init__(self, watch):
+        import ctypes as C
+
+        from boundless_amd import agent as ag
+
+        self.inner = ag.HotStore()
+        self.watch, self.seen = set(watch), {}
+        io = self.inner.ops
+        GET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t)
+        FREE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))
+        SET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t)
+        UNLINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t)
+        get, free, set_ex, unlink = GET(io.get), FREE(io.free_value), SET(io.set_ex), UNLINK(io.unlink)
+        user = io.user
+
+        def rec_set(_u, key, value, n, ttl, errbuf, cap):
+            k = key.decode()
+            if k in self.watch:
+                self.seen[k] = C.string_at(value, n)
+            return set_ex(user, key, value, n, ttl, errbuf, cap)
+
+        self._keep = (GET(lambda _u, k, v, n, e, c: get(user, k, v, n, e, c)), FREE(lambda _u, p: free(user, p)), SET(rec_set),
+                      UNLINK(lambda _u, k, e, c: unlink(user, k, e, c)))
+        self.ops = ag._HotStoreOps(None, *[C.cast(f, C.c_void_p) for f in self._keep])
+        for name in ("get", "set_key_with_expiry", "unlink", "keys"):
+            setattr(self, name, getattr(self.inner, name))
+
+
+@pytest.mark.fullsize
+def test_batch_of_64_segments_at_2_20_cycles_through_the_native_agent():
+    """BASELINE.json configs[2] at the metric's size: 64 independent 2^20-cycle segments (16/256/64) planned as one job
+    (bento/crates/taskdb/src/planner/mod.rs:91-116) and work-stolen by the three lanes of the native agent, verification on: 64 Prove
+    + 63 stand-in Join (2^18 synthetic proofs, NOT recursion proofs) + Resolve + Finalize = 129 tasks.  Every receipt is verified by
+    the agent before it is stored (a failure would fail its task and the job), the job ends `done`, the lanes' counts add up, and
+    three stored receipts are the oracle's word for word: the Prove seals of segments 0 and 1 — the first join's two inputs — and
+    that join's output, seeded by the hash of both.  (The whole chain of 127 oracle proofs would take half an hour; the small-size
+    tests above check it in full.)  Deselect locally with -m "gpu and not fullsize"."""
+    from boundless_amd import agent as ag
+    from boundless_amd.planner import Planner
+    from boundless_amd.prover import Segment
+
+    n, lanes, widths, seg_po2, join_po2 = 64, 3, (16, 256, 64), 20, 18
+    p = Planner()
+    for _ in range(n):
+        p.enqueue_segment()
+    p.finish()
+    tasks = [p.get_task(k) for k in range(p.task_count())]
+    first_join = next(t for t in tasks if t.command == "Join" and tuple(t.depends_on) == (0, 1))
+    watch = [f"job:B:synthetic_receipts:{i}" for i in (0, 1, first_join.task_number)]
+    store = _RecordingStore(watch)
+    a = ag.Agent(prover=None, device=0, inflight=lanes, widths=widths, poll_time=0.002, join_po2=join_po2, also_streams="aux", store=store,
+                 verify=True)
+    try:
+        a.prewarm(seg_po2)
+        a.prewarm(join_po2)
+        segs = [Segment.synthetic(i, po2=seg_po2) for i in range(n)]
+        for s in segs:
+            store.set_key_with_expiry(f"job:B:segments:{s.index}", ag.serialize_segment(s), 600)
+        ids = a.taskdb.plan_job("B", n)
+        assert len(ids) == 129
+        assert a.poll_work(max_idle_polls=5) == 129
+        assert a.taskdb.job("B")["state"] == "done"
+        per_lane = [d for _, d in a.lane_stats()]
+        assert len(per_lane) == lanes and sum(per_lane) == 129 and min(per_lane) > 0
+        text = a.metrics_text()
+        assert f'task_operations_total{{task_name="join",operation_type="join_receipts",status="success"}} {n - 1}' in text
+        assert 'status="failed"' not in text and 'status="error"' not in text
+        rollup = ag.deserialize_receipt(store.get("receipts/stark/B.synthetic"))
+        assert rollup.po2 == join_po2
+        rollup.verify_integrity()
+        assert sorted(store.keys()) == sorted([f"job:B:synthetic_receipts:{rollup.index}", "receipts/stark/B.synthetic"])
+        assert sorted(store.seen) == sorted(watch)
+        got = {k: ag.deserialize_receipt(v) for k, v in store.seen.items()}
+        ol.lib().bxo_set_threads(min(os.cpu_count() or 1, 16))
+        s0, _ = ol.prove_segment(seg_po2, *widths, segs[0].seed)
+        assert np.array_equal(got[watch[0]].seal, s0), "Prove seal of segment 0 differs from the oracle's"
+        s1, _ = ol.prove_segment(seg_po2, *widths, segs[1].seed)
+        assert np.array_equal(got[watch[1]].seal, s1), "Prove seal of segment 1 differs from the oracle's"
+        j, _ = ol.prove_segment(join_po2, *widths, ag.join_seed(s0, s1))
+        assert got[watch[2]].po2 == join_po2 and np.array_equal(got[watch[2]].seal, j), "first join's output differs from the oracle's"
     finally:
         a.close()

@@ -180,7 +180,11 @@ def main():
     else:
         res = analyse(a.src, a.kernel)
     if a.json:
-        print(json.dumps(res, indent=1))
+        from boundless_amd.build import device_code_hash
+
+        print(json.dumps({"device_code_sha": device_code_hash(), "note": "static per-wave instruction counts of a straight-line pass over each "
+                          "kernel's gfx950 text (tools/isa_mix.py); `loops` = the body of each backward branch (the multi-column pass A runs "
+                          "its column loop `cpw` times); classes as in profiles/r01_microbench2_instr_cost.jsonl", "kernels": res}, indent=1))
         return
     for name, d in res.items():
         print(f"{name}\n   mul {d['mul_class_insts']}  cheap {d['cheap_insts']}  weighted cycles {d['weighted_issue_cycles']}  "
