@@ -14,14 +14,19 @@ from boundless_amd.build import csrc_hash, device_code_hash  # noqa: E402
 
 
 def main(src, segments, dst):
-    segments = int(segments)
     tot = collections.defaultdict(float)
     waves = collections.defaultdict(float)
+    proofs = set()
     for r in csv.DictReader(open(src)):
         if r["Counter_Name"] == "SQ_INSTS_VALU":
             tot[r["Kernel_Name"]] += float(r["Counter_Value"])
+            if "eval_check_kernel" in r["Kernel_Name"]:
+                proofs.add(r.get("Dispatch_Id"))
         elif r["Counter_Name"] == "SQ_WAVES":
             waves[r["Kernel_Name"]] += float(r["Counter_Value"])
+    # "auto": every proof launches eval_check exactly once, so the run counts its own segments (the hand-passed number went stale
+    # when bench.py's lone-proof section grew from 4 to 8 proofs)
+    segments = len(proofs) if segments == "auto" else int(segments)
     total = sum(tot.values())
     out = {"device_code_sha": device_code_hash(), "csrc_sha": csrc_hash(), "note": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES on bench.py ({segments} segments proved in the profiled process, warm-up and "
                    "isolated probe included); wave-level VALU instructions",

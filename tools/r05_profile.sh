@@ -19,9 +19,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py "$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $O/r05_bench_pmc_traffic.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-# 3. VALU instructions of the whole job, per segment: steps 2 x 3 lanes + warm-up 3 + 4 lone proofs + 1 isolated probe = 14 segments
+# 3. VALU instructions of the whole job, per segment (the tool counts the proofs of the run by their eval_check launches)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra > /dev/null 2>&1
-python tools/job_valu.py "$(find $O/pmc_valu -name '*counter_collection.csv' | head -1)" 14 $O/r05_job_valu_insts.json
+python tools/job_valu.py "$(find $O/pmc_valu -name '*counter_collection.csv' | head -1)" auto $O/r05_job_valu_insts.json
 rm -rf $O/pmc_valu
 # 4. the stall side of the two LDE kernels, bench.py with one segment in flight (VERDICT r04 item 2 ii): separate passes of <= 8 SQ counters
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
@@ -32,6 +32,10 @@ for P in "$P1" "$P2"; do i=$((i+1))
 done
 python tools/pmc_stalls.py $O/r05_lde_stall_counters.json "ntt_passA_fwd12_multi_kernel,ntt_r16_kernel<false, false,hash_rows_kernel" $(find $O/pmcs1 $O/pmcs2 -name '*counter_collection.csv' 2>/dev/null)
 rm -rf $O/pmcs1 $O/pmcs2
+#    ... and the clock each kernel runs at under the package power limit (GRBM_GUI_ACTIVE over the 8 XCDs / dispatch duration)
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/clk -o pmc -- $B --inflight 1 > /dev/null 2>&1
+python tools/pmc_clock.py "$(find $O/clk -name '*counter_collection.csv' | head -1)" $O/r05_kernel_clocks.json "ntt_,hash_rows,eval_check,hash_fold_deep,witness_derive" > /dev/null
+rm -rf $O/clk
 # 5. one planned job of 64 segments (stand-in joins: 2^18 synthetic proofs, NOT recursion proofs), and the world-size-8 dry runs on the one GPU
 for l in 3 1; do python bench.py --job 64 --inflight $l 2>/dev/null | tail -1; done > $O/r05_job64.jsonl
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1 --master-port 29651 bench.py --gpus 8 --dist-backend gloo --device 0 --inflight 1 --steps 3 --warmup 1 2>/dev/null | grep '^{' | tail -1 > $O/r05_ws8_gloo_1gpu.json
