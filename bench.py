@@ -39,6 +39,12 @@ The JSON line also carries
                 stream over the timed region, against the 8 TB/s HBM peak (DESIGN.md §4 explains why this path is
                 VALU-issue-bound); measured by an isolated probe (one segment alone) because concurrent streams stretch the
                 in-region durations; `roofline_in_region` is the concurrent figure;
+                `roofline.valu_view` = the same launch seen from the VALU: instructions per wave (PMC) and their static class mix
+                (profiles/r05_lde_isa_mix.json), `frac_weighted_issue` (the class-weighted bound, 2 / 4 cycles per instruction — not
+                attainable in a mixed stream) next to `frac_of_mixed_stream_rate` (against the rate a bare loop of the same
+                butterflies issues at, profiles/r05_microbench4_operand_kinds.jsonl), and `traffic_GBps` on counter bytes;
+  replayed_profiles  which committed PMC summaries the line replays and `profile_stale`: whether they were collected on the DEVICE CODE
+                the library that just ran carries (SHA-256 of its .hip_fatbin section, boundless_amd.build.device_code_hash);
   kernels       the same for every HAL entry point in the timed region, from the HIP events of ONE lane per rank (bracketing
                 every entry point of every lane costs 0.9 % of the rate; `live_profile` says what was bracketed);
   cpu_baseline  the CPU oracle (kind "port": the reference's Rust CPU HAL cannot be built here) timed on this
