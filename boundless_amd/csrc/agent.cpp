@@ -33,6 +33,10 @@
 #include "../../include/bx_agent.h"
 #include "../../include/bx_circuit.h"
 
+namespace bx {
+bool verifier_ctx_contains(const bx_verifier_ctx* v, uint32_t po2, const uint32_t root[8]);  // control_id.cpp
+}
+
 namespace {
 
 using Clock = std::chrono::steady_clock;
@@ -758,8 +762,13 @@ struct bx_agent {
         // goes into the agent's verifier context
         uint32_t id[8];
         const char* ce = bx_prover_control_id(p, id);
-        if (!ce) ce = bx_synthetic_circuit()->check_code(nullptr, &shape, id);
+        bool known = false;  // a buffer set re-created after an eviction: its ID was validated when it was first made
         if (!ce) {
+            std::shared_lock<std::shared_mutex> r(vctx_mu);
+            known = bx::verifier_ctx_contains(vctx, po2, id);
+        }
+        if (!ce && !known) ce = bx_synthetic_circuit()->check_code(nullptr, &shape, id);  // may be seconds of host work off the table
+        if (!ce && !known) {
             std::unique_lock<std::shared_mutex> w(vctx_mu);
             ce = bx_verifier_ctx_add_control_id(vctx, po2, id);
         }
