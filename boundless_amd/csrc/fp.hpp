@@ -61,6 +61,30 @@ BX_HD uint32_t fp_mul_lazy(uint32_t a, uint32_t b) { return fp_mad_lazy(a, b, 0u
 // x in [0, 2P) -> canonical
 BX_HD uint32_t fp_reduce(uint32_t x) { return umin(x, x - P); }
 
+// Fused-reduction radix-2 butterfly (ntt_r16.hpp, tunable ntt_fused): u = REDC(a R + b w), d = REDC(a R + b wn) with R = MONT_ONE =
+// 2^32 mod P and wn = P - w, i.e. u == a + b w 2^-32 and d == a - b w 2^-32 (mod P) — the Montgomery butterfly with its addition and
+// subtraction inside the reductions.  a, b may be ANY u32 and w, wn <= P - 1: a R + b w + m P <= (2^32 - 1)(R + 2P - 1) =
+// (2^32 - 1)^2 < 2^64 because R + 2P = 2^32 exactly; the results are < 2^32 (not < 2P): see reduce_any().
+BX_HD void bfly_fused(uint32_t& a, uint32_t& b, uint32_t w, uint32_t wn) {
+    const uint64_t t0 = (uint64_t)a * MONT_ONE;
+    const uint64_t tu = t0 + (uint64_t)b * w, td = t0 + (uint64_t)b * wn;
+    const uint32_t mu = (uint32_t)tu * NEG_P_INV, md = (uint32_t)td * NEG_P_INV;
+#if defined(BX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+    if ((((unsigned __int128)a * MONT_ONE + (unsigned __int128)b * w + (unsigned __int128)mu * P) >> 64) != 0 ||
+        (((unsigned __int128)a * MONT_ONE + (unsigned __int128)b * wn + (unsigned __int128)md * P) >> 64) != 0) {
+        fprintf(stderr, "bfly_fused: 64-bit overflow (a=%u b=%u w=%u wn=%u)\n", a, b, w, wn);
+        abort();
+    }
+#endif
+    a = (uint32_t)((tu + (uint64_t)mu * P) >> 32);
+    b = (uint32_t)((td + (uint64_t)md * P) >> 32);
+}
+// any u32 -> canonical: x < 2^32 = 2P + R with R < P, so at most one subtraction of 2P and one of P
+BX_HD uint32_t reduce_any(uint32_t x) {
+    x = umin(x, x - 2u * P);
+    return umin(x, x - P);
+}
+
 // Montgomery product a*b*2^-32 mod P, canonical, for canonical inputs: the lazy result is < P^2/2^32 + P < 1.47 P,
 // so one conditional subtraction finishes it (5 instructions; every 32-bit integer VALU op issues at the same rate on
 // gfx950, see profiles/r01_microbench_valu.jsonl, so instruction count is what matters).

@@ -231,18 +231,8 @@ __device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) {
     asm volatile("" : "+s"(v));
     return v;
 }
-__device__ __forceinline__ void bfly_fused(uint32_t& a, uint32_t& b, uint32_t w, uint32_t wn) {
-    const uint64_t t0 = (uint64_t)a * MONT_ONE;
-    const uint64_t tu = t0 + (uint64_t)b * w, td = t0 + (uint64_t)b * wn;
-    const uint32_t mu = (uint32_t)tu * NEG_P_INV, md = (uint32_t)td * NEG_P_INV;
-    a = (uint32_t)((tu + (uint64_t)mu * P) >> 32);
-    b = (uint32_t)((td + (uint64_t)md * P) >> 32);
-}
-// any u32 -> canonical: x < 2^32 = 2P + R with R < P
-__device__ __forceinline__ uint32_t reduce_any(uint32_t x) {
-    x = umin(x, x - 2u * P);
-    return umin(x, x - P);
-}
+// bfly_fused() and reduce_any() themselves live in fp.hpp (host + device), where tests/host_arith_check.cpp pushes every extreme
+// operand through them with 128-bit reference arithmetic.
 // PLAIN1: stage 1 is the plain add / subtract of canonical inputs (all its twiddles are 1)
 template <int K, bool S0ZERO, int SKIP, bool PLAIN1>
 __device__ __forceinline__ void step_compute_fused(uint32_t (&x)[16], const uint32_t (&tw)[16], const uint32_t (&twn)[16]) {

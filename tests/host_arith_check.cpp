@@ -55,6 +55,48 @@ static int check_cons_sum() {
     return 0;
 }
 
+// NTT butterflies of ntt_r16.hpp.  (1) the fused-reduction butterfly takes ANY u32 operands (its own BX_CHECK_BOUNDS assertion
+// watches the 64-bit accumulators) and returns the right residues; chains of them stay correct with no reduction in between;
+// reduce_any() canonicalises any word.  (2) the lazy canonical forward butterfly as the kernels use it across a step boundary: the
+// "a" operand is reduced where it is consumed, the "b" operand and both outputs are in [0, 2P) and never wrap.
+static int check_ntt_butterflies() {
+    const uint32_t edge[] = {0u, 1u, 2u, P - 1u, P, P + 1u, 2u * P - 1u, 2u * P, 2u * P + 1u, 0x7FFFFFFFu, 0x80000000u, 0xFFFFFFFEu, 0xFFFFFFFFu, MONT_ONE, P - MONT_ONE};
+    const uint32_t wedge[] = {0u, 1u, 2u, MONT_ONE, P - MONT_ONE, P / 2, P / 2 + 1, P - 2u, P - 1u};
+    const int ne = (int)(sizeof edge / sizeof edge[0]), nw = (int)(sizeof wedge / sizeof wedge[0]);
+    for (int iter = 0; iter < 400000; ++iter) {
+        const uint64_t r = rnd64(), r2 = rnd64();
+        uint32_t a = iter < ne * ne * nw ? edge[iter % ne] : (iter & 1) ? edge[r % ne] : (uint32_t)r;
+        uint32_t b = iter < ne * ne * nw ? edge[(iter / ne) % ne] : (iter & 2) ? edge[(r >> 8) % ne] : (uint32_t)(r >> 32);
+        const uint32_t w = iter < ne * ne * nw ? wedge[(iter / (ne * ne)) % nw] : (iter & 4) ? wedge[r2 % nw] : (uint32_t)((r2 >> 8) % P);
+        const uint32_t wn = w ? P - w : 0u;  // P - 0 = P is not a table entry: the stage tables hold w in [1, P)
+        if (w == 0) continue;
+        const uint32_t wu = redc_exact((u128)(a % P) * MONT_ONE + (u128)(b % P) * w);
+        const uint32_t wd = redc_exact((u128)(a % P) * MONT_ONE + (u128)(b % P) * wn);
+        uint32_t u = a, d = b;
+        bfly_fused(u, d, w, wn);
+        REQUIRE(u % P == wu && d % P == wd);
+        REQUIRE(reduce_any(u) == wu && reduce_any(d) == wd && reduce_any(a) == a % P);
+        // four more stages on the unreduced outputs (any u32 in, any u32 out), against the canonical chain
+        uint32_t cu = wu, cd = wd;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t wk = (uint32_t)(rnd64() % (P - 1)) + 1u;
+            bfly_fused(u, d, wk, P - wk);
+            const uint32_t t = fp_mul(cd, wk), nu = fp_add(cu, t), nd = fp_sub(cu, t);
+            cu = nu;
+            cd = nd;
+            REQUIRE(u % P == cu && d % P == cd);
+        }
+        // lazy canonical butterfly across a step boundary: a, b in [0, 2P) as the previous step's last stage left them
+        const uint32_t la = a % (2u * P), lb = b % (2u * P);
+        const uint32_t ar = fp_reduce(la);                 // IN_LAZY: the operand that is added is reduced where it is consumed
+        const uint32_t t = fp_mul(lb, w);                  // the multiplied operand is taken as it is
+        const uint64_t su = (uint64_t)ar + t, sd = (uint64_t)ar + P - t;
+        REQUIRE(t < P && su < 2ull * P && sd < 2ull * P && sd > 0);  // OUT_LAZY outputs fit the word and stay below 2P
+        REQUIRE((uint32_t)su % P == fp_add(la % P, fp_mul(lb % P, w)) && (uint32_t)sd % P == fp_sub(la % P, fp_mul(lb % P, w)));
+    }
+    return 0;
+}
+
 // LazyExtAcc (mix_poly_coeffs, batch_evaluate_any, eval_check's mixing): sum_k w_k * x_k against f4_scale + f4_add, for term
 // counts around every fold boundary, worst-case magnitudes (weights +-P/2, x = P - 1) and random operands
 static int check_lazy_ext_acc() {
@@ -86,6 +128,7 @@ static int check_lazy_ext_acc() {
 
 int main() {
     if (check_lazy_ext_acc()) return 1;
+    if (check_ntt_butterflies()) return 1;
     if (check_cons_sum<64, 4>() || check_cons_sum<48, 3>() || check_cons_sum<16, 3>() || check_cons_sum<32, 3>() || check_cons_sum<8, 2>() || check_cons_sum<5, 1>() ||
         check_cons_sum<7, 4>() || check_cons_sum<64, 5>() || check_cons_sum<1, 1>() || check_cons_sum<25, 2>())
         return 1;
