@@ -19,6 +19,9 @@ LIB = os.path.join(HERE, "lib", "libbx_hip_hal.so")
 CMD = os.path.join(HERE, "cmd")
 AGENT_BIN = os.path.join(HERE, "bin", "bx-agent")
 ARCH = "gfx950"
+# hipcc derives a "compilation unit id" from the source file's PATH and puts it into a device symbol (__hip_cuid_<id>), so the same
+# sources built in another directory gave another code object — and another device_code_hash() stamp.  _compile() therefore passes
+# -cuid=<file name>: unique per translation unit, independent of where the tree lives (tests/test_profile_stamp_cpu.py).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          "-ffp-contract=off", f"-I{INC}", f"-I{CSRC}"]
 
@@ -109,6 +112,11 @@ def device_code_hash(lib=None):
     return hashlib.sha256(sec).hexdigest()[:16]
 
 
+def cuid_flag(src):
+    """-cuid for one translation unit: its file name (letters and digits), not its path"""
+    return "-cuid=bx" + "".join(ch for ch in os.path.basename(src) if ch.isalnum())
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -127,7 +135,7 @@ def _compile(src, force, hdr_mtime):
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime):
         return obj, False
-    cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-c", path, "-o", obj]
+    cmd = ["hipcc", "-x", "hip"] + FLAGS + [cuid_flag(src), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

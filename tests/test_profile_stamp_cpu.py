@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _compile(tree, out):
     src = os.path.join(tree, "boundless_amd", "csrc", "circuit.hip")
     flags = [f for f in b.FLAGS if not f.startswith("-I")] + [f"-I{tree}/include", f"-I{tree}/boundless_amd/csrc"]
-    r = subprocess.run(["hipcc", "-x", "hip"] + flags + ["-c", src, "-o", out], capture_output=True, text=True)
+    r = subprocess.run(["hipcc", "-x", "hip"] + flags + [b.cuid_flag(src), "-c", src, "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return b.device_code_hash(out)
 
@@ -28,6 +28,11 @@ def test_device_code_stamp_ignores_host_only_edits(tmp_path):
     obj = str(tmp_path / "circuit.o")
     base = _compile(tree, obj)
     assert base == _compile(tree, obj), "the device code object is not reproducible"
+
+    # 0. the same sources in another directory give the same code object (hipcc's path-derived cuid is switched off in build.FLAGS)
+    tree2 = str(tmp_path / "elsewhere" / "deeper" / "tree")
+    shutil.copytree(tree, tree2)
+    assert _compile(tree2, str(tmp_path / "circuit2.o")) == base, "the device-code stamp depends on the build directory"
 
     # 1. a host-only declaration in bx_prover.h (what staled every r04 profile): text hash would change, the code object does not
     hdr = os.path.join(tree, "include", "bx_prover.h")

@@ -56,7 +56,7 @@ def compile_asm(src):
 
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     flags = [f for f in b.FLAGS if f != "-fPIC"]
-    cmd = ["hipcc", "-x", "hip"] + flags + ["-S", "--cuda-device-only", src, "-o", out]
+    cmd = ["hipcc", "-x", "hip"] + flags + [b.cuid_flag(src), "-S", "--cuda-device-only", src, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
