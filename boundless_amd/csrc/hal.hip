@@ -348,6 +348,20 @@ extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) try {
     out->len = words;
     return nullptr;
 } BX_ABI_CATCH(c, "bx_alloc")
+extern "C" const char* bx_alloc_zeroed(bx_ctx* c, size_t words, bx_buf* out) try {
+    if (!c) return "bx_alloc_zeroed: null ctx";
+    BX_REQUIRE(c, out != nullptr, "bx_alloc_zeroed: null out");
+    BX_HIP(c, hipSetDevice(c->device));
+    void* p = nullptr;
+    BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
+    if (hipMemsetAsync(p, 0, (words ? words : 1) * 4, c->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return set_msg(c, "bx_alloc_zeroed: clearing the allocation failed");
+    }
+    out->dptr = p;
+    out->len = words;
+    return nullptr;
+} BX_ABI_CATCH(c, "bx_alloc_zeroed")
 extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;

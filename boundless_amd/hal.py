@@ -62,6 +62,7 @@ def load_library():
         "bx_device_name": [ctx, C.c_char_p, sz],
         "bx_set_stream": [ctx, C.c_void_p],
         "bx_alloc": [ctx, sz, C.POINTER(BxBuf)],
+        "bx_alloc_zeroed": [ctx, sz, C.POINTER(BxBuf)],
         "bx_release": [ctx, BxBuf],
         "bx_h2d": [ctx, BxBuf, C.c_void_p, sz],
         "bx_d2h": [ctx, C.c_void_p, BxBuf, sz],
@@ -215,6 +216,12 @@ class HipHal:
 
     alloc_elem = alloc
     alloc_u32 = alloc
+
+    def alloc_zeroed(self, words):
+        """Hal::alloc_extelem_zeroed / alloc_elem_init(.., 0): cleared on the ctx's stream (eltwise_zeroize_elem is not a clear)."""
+        raw = BxBuf()
+        self._check(self.lib.bx_alloc_zeroed(self.ctx, words, C.byref(raw)))
+        return Buffer(self, raw)
 
     def alloc_extelem(self, n):
         return self.alloc(EXT_SIZE * n)

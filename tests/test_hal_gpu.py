@@ -32,6 +32,22 @@ def c(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
+def adversarial_columns(n):
+    """Extreme columns of n rows for the NTT kernels (the default kernels carry values in [0, 2P) across their LDS regroupings, so
+    the words that sit at the ends of every intermediate range must go through the COMPILED kernels, not only through the host
+    check of the arithmetic source): all 0, all P - 1, an impulse at row 0, an impulse at row n - 1, alternating 0 / P - 1."""
+    z = np.zeros(n, np.uint32)
+    top = np.full(n, oracle_P - 1, np.uint32)
+    first, last, alt = z.copy(), z.copy(), z.copy()
+    first[0] = oracle_P - 1
+    last[n - 1] = oracle_P - 1
+    alt[1::2] = oracle_P - 1
+    return np.concatenate([z, top, first, last, alt])
+
+
+N_ADV = 5
+
+
 # ------------------------------------------------------------------ NTT family
 @pytest.fixture(params=[1, 0], ids=["r16", "v1"])
 def ntt_path(hal, request):
@@ -42,10 +58,14 @@ def ntt_path(hal, request):
 
 
 @pytest.mark.parametrize("bits", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
-@pytest.mark.parametrize("count", [1, 3])
+@pytest.mark.parametrize("count", [1, 3, "3+adv"])
 def test_interpolate_zkshift_lde_bitreverse(hal, oracle, ntt_path, bits, count):
     n = 1 << bits
-    x = rnd(100 + bits, n * count)
+    if count == "3+adv":  # three random columns, then the five extreme ones
+        count = 3 + N_ADV
+        x = np.concatenate([rnd(100 + bits, n * 3), adversarial_columns(n)])
+    else:
+        x = rnd(100 + bits, n * count)
     ref = x.copy()
     io = hal.copy_from(x)
     hal.batch_interpolate_ntt(io, count)
@@ -62,6 +82,18 @@ def test_interpolate_zkshift_lde_bitreverse(hal, oracle, ntt_path, bits, count):
     hal.batch_bit_reverse(io, count)
     oracle.bxo_batch_bit_reverse(ref, count, n)
     assert np.array_equal(io.view(), ref), "batch_bit_reverse"
+    if count > 3:  # the fused interpolate + zk_shift entry point and the in-place evaluate on the same extreme columns
+        io2 = hal.copy_from(x)
+        hal.batch_interpolate_zk(io2, count)
+        ref2 = x.copy()
+        oracle.bxo_batch_interpolate_ntt(ref2, count, n)
+        oracle.bxo_zk_shift(ref2, count, n)
+        assert np.array_equal(io2.view(), ref2), "batch_interpolate_zk"
+        io3 = hal.copy_from(x)
+        hal.batch_evaluate_ntt(io3, count, 0)
+        ref3 = x.copy()
+        oracle.bxo_batch_evaluate_ntt(ref3, count, n, 0)
+        assert np.array_equal(io3.view(), ref3), "batch_evaluate_ntt"
 
 
 @pytest.mark.parametrize("bits,expand", [(4, 0), (9, 0), (11, 0), (14, 0), (6, 2), (12, 2), (14, 2), (15, 1)])
@@ -100,13 +132,18 @@ def test_ntt_full_size_vs_oracle_and_roundtrip(hal, oracle, fast, block_log, til
     hal.set_tunable("ntt_tile_a_log", tile_a)
     hal.set_tunable("ntt_tile_b_log", tile_b)
     try:
-        n, count = 1 << 20, 2
-        x = rnd(2020, n * count)
+        n, count = 1 << 20, 2 + N_ADV
+        x = np.concatenate([rnd(2020, n * 2), adversarial_columns(n)])  # two random columns + all-0, all-(P-1), two impulses, 0/P-1
         ref = x.copy()
         io = hal.copy_from(x)
         hal.batch_interpolate_ntt(io, count)
         oracle.bxo_batch_interpolate_ntt(ref, count, n)
         assert np.array_equal(io.view(), ref)
+        zk = hal.copy_from(x)
+        hal.batch_interpolate_zk(zk, count)
+        ref_zk = ref.copy()
+        oracle.bxo_zk_shift(ref_zk, count, n)
+        assert np.array_equal(zk.view(), ref_zk)
         out = hal.alloc(4 * n * count)
         hal.batch_expand_into_evaluate_ntt(out, io, count, 2)
         lde = out.view()
@@ -528,6 +565,13 @@ def test_eltwise_and_gather(hal, oracle):
     hal.eltwise_zeroize_elem(zb)
     oracle.bxo_eltwise_zeroize(z, n)
     assert np.array_equal(zb.view(), z)
+    # alloc_zeroed (Hal::alloc_extelem_zeroed): zeros even when the allocator hands back memory that was just dirtied and freed
+    for _ in range(3):
+        d = hal.copy_from(np.full(1 << 20, 0xDEADBEEF, np.uint32))
+        d.free()
+        zz = hal.alloc_zeroed(1 << 20)
+        assert not zz.view().any()
+        zz.free()
     count, to_add = 1000, 5
     e = rnd(3, 4 * count * to_add)
     so = hal.alloc(4 * count)
