@@ -102,6 +102,53 @@ def replayed_profiles():
                     "host-only edit leaves it unchanged (tests/test_profile_stamp_cpu.py); library_sha = hash of all source text, host side included"}
 
 
+def plain_hal_probe(args, sv, product_ms):
+    """Untimed extra (rank 0): wall clock of one lone proof sequenced by the test-side driver tests/plain_hal_prover.c over the plain
+    entry points of SURVEY.md section 8(b2) — one bx_hash_fold per layer, bx_poly_divide per combo and point, bx_batch_evaluate_any
+    per group, separate bx_zk_shift, bx_gather_sample per opened row and path digest — and the same with ONE extension entry point
+    swapped in at a time.  The driver has its own host transcript; its seal must equal bx_prove_segment's."""
+    import numpy as np
+
+    from boundless_amd.prover import Segment
+
+    tests = os.path.join(ROOT, "tests")
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+    try:
+        import plain_hal
+    except Exception as e:  # no gcc on this box: say so instead of failing the line
+        return {"error": f"tests/plain_hal_prover.c could not be built: {e}"}
+    seg = Segment.synthetic(index=4 * 10**6, po2=args.po2)
+    want = sv.prove_segment(seg).seal
+
+    def timed(flags):
+        pp = plain_hal.PlainHalProver(sv.hal.device, po2=args.po2, widths=tuple(int(x) for x in args.widths.split(",")),
+                                      terms=args.terms, degree=args.degree, flags=flags)
+        try:
+            ts, equal = [], True
+            for _ in range(4):
+                seal, ms = pp.prove(seg.seed)
+                ts.append(ms)
+                equal = equal and bool(np.array_equal(seal, want))
+            return {"min": round(min(ts[1:]), 3), "median": round(sorted(ts[1:])[1], 3), "calls": int(pp.calls), "seal_equals_bx_prove_segment": equal}
+        finally:
+            pp.close()
+
+    out = timed(0)
+    out["ratio_to_bx_prove_segment"] = round(out["min"] / product_ms, 3) if product_ms else None
+    ext = {}
+    for flag, name in sorted(plain_hal.EXT_NAMES.items()):
+        r = timed(flag)
+        r["saves_ms"] = round(out["min"] - r["min"], 3)
+        ext[name] = r
+    out["with_one_extension"] = ext
+    out["with_all_extensions"] = timed(plain_hal.EXT_ALL)
+    out["note"] = ("one lone proof through the section-8(b2) entry points only, sequenced outside the library with its own host transcript; "
+                   "with_one_extension = the same with that extension entry point replacing its plain call sequence; every device buffer but "
+                   "`combos` (bx_alloc_zeroed per proof) is allocated up front, which risc0-zkp's prover does not do")
+    return out
+
+
 def _valu_per_wave():
     """VALU instructions per wave, per kernel name: this round's job-level PMC pass, else round 1's opbench pass"""
     try:
@@ -508,6 +555,7 @@ def main():
     ap.add_argument("--no-live-profile", action="store_true", help="do not bracket the entry points with HIP events in the timed region (measures what those events cost: "
                     "an event record is a barrier packet between two kernels; the per-kernel figures then come from the isolated probe only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plain-hal", action="store_true", help="skip the untimed `single_proof_ms.plain_hal` extra (one proof through the plain Hal entry points, tests/plain_hal_prover.c)")
     ap.add_argument("--no-agent-mode", action="store_true", help="skip the untimed native-agent (feed loop) measurement")
     ap.add_argument("--cpu-sample-po2", type=int, default=20, help="size of the oracle proof timed for cpu_baseline (default: the metric's 2^20, ~40 s of CPU)")
     ap.add_argument("--terms", type=int, default=0, help="synthetic circuit: product terms per constraint (0 = default)")
@@ -728,6 +776,11 @@ def main():
                 single_ms["spin_wait"] = {"min": round(min(ts[1:]), 3), "median": round(sorted(ts[1:])[1], 3), "runs": [round(x, 3) for x in ts[1:]]}
             finally:
                 sv.hal.set_tunable("wait_blocking", 2)
+        # the same segment proved from OUTSIDE the library through the plain Hal-trait entry points only (tests/plain_hal_prover.c:
+        # what a Rust `impl Hal for HipHal` shim driven by risc0-zkp's own prover gets), then with each extension entry point of
+        # bx_hal.h swapped in alone: what every extension is worth
+        if not args.no_plain_hal:
+            single_ms["plain_hal"] = plain_hal_probe(args, sv, single_ms["min"])
     barrier()
 
     # Isolated probe (untimed, rank 0 only): with several segments in flight the HIP-event durations of the timed region
