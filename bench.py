@@ -102,6 +102,39 @@ def replayed_profiles():
                     "host-only edit leaves it unchanged (tests/test_profile_stamp_cpu.py); library_sha = hash of all source text, host side included"}
 
 
+def relaunch_one_process_per_gpu(n):
+    """exec `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench.py: --gpus {n} without a launcher: re-executing as one process per GPU: {' '.join(cmd[1:])}\n")
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def rendezvous_only(args):
+    """Test hook (tests/test_dist_cpu.py): rendezvous, one all-reduce that counts the ranks, rank 0 prints what the launcher gave it;
+    needs no GPU with --dist-backend gloo.  Proves that `--gpus N` reached N processes."""
+    import torch
+
+    from boundless_amd.dist import init_distributed, sum_over_ranks
+
+    rank, world, local_rank, dist = init_distributed(args.dist_backend, force=args.force_dist)
+    seen = int(round(sum_over_ranks(1, dist)))
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_counted": seen, "flag_gpus": args.gpus,
+                          "backend": None if dist is None else dist.get_backend()}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def plain_hal_probe(args, sv, product_ms):
     """Untimed extra (rank 0): wall clock of one lone proof sequenced by the test-side driver tests/plain_hal_prover.c over the plain
     entry points of SURVEY.md section 8(b2) — one bx_hash_fold per layer, bx_poly_divide per combo and point, bx_batch_evaluate_any
@@ -571,6 +604,7 @@ def main():
                     "(pinned staging slot -> copy stream -> HBM) and handed to witgen like a preflight trace; 0 = header only.  The reference's 2^20-cycle segment is ~80 MB (executor.rs:45)")
     ap.add_argument("--two-deep", action="store_true", help="with --segment-bytes: a feeder thread per lane submits segment k+1 (bx_prover_submit_segment) while segment k is proved")
     ap.add_argument("--no-pcie-extra", action="store_true", help="skip the untimed PCIe-inclusive leg (80 MB segments) of the default N=1 run")
+    ap.add_argument("--rendezvous-only", action="store_true", help="test hook: rendezvous + one all-reduce counting the ranks, print {n_gpus, ranks_counted} and exit (no GPU needed with --dist-backend gloo)")
     ap.add_argument("--dump", type=str, default=None, help="directory: every rank writes rank{r}.npz with the segment indices it claimed in the timed region and their seals (parity tests of the N>1 path)")
     args = ap.parse_args()
     widths = tuple(int(x) for x in args.widths.split(","))
@@ -582,6 +616,17 @@ def main():
         return job_main(args, widths)
     if args.native_agent:
         return native_agent_main(args, widths)
+    # `--gpus N` means N: one process per GPU.  Started without a launcher the line would silently measure ONE GPU under an N = 8 flag
+    # (VERDICT r05 weak #7), so plain `python bench.py --gpus N` re-executes itself under torch.distributed.run, and a launcher whose
+    # world size disagrees with the flag is an error.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return relaunch_one_process_per_gpu(args.gpus)
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} processes; they must agree "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if args.rendezvous_only:
+        return rendezvous_only(args)
 
     import resource
     import threading

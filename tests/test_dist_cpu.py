@@ -169,3 +169,31 @@ def test_a_job_sharded_over_two_ranks_joins_its_subtree_roots_after_one_all_gath
     assert by_rank[1]["keys_left"] == ["job:dj-r1:synthetic_receipts:6"]
     assert sorted(by_rank[0]["keys_left"]) == sorted(["job:dj-r0:synthetic_receipts:6", "job:dj-top:synthetic_receipts:2", "receipts/stark/dj-top.synthetic"])
     assert by_rank[0]["root_receipt_bytes"] == 4 * (3 + 16)
+
+
+def _bench(argv, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it must not measure one GPU under an N = 2 flag: it
+    re-executes itself under torch.distributed.run with one process per GPU.  --rendezvous-only + gloo: no GPU needed."""
+    r = _bench(["--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "re-executing as one process per GPU" in r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks_counted": 2, "flag_gpus": 2, "backend": "gloo"}
+    # N = 1 stays one plain process, no process group
+    r = _bench(["--gpus", "1", "--rendezvous-only"])
+    assert r.returncode == 0 and "re-executing" not in r.stderr
+    assert json.loads(r.stdout.splitlines()[-1]) == {"rendezvous_only": True, "n_gpus": 1, "ranks_counted": 1, "flag_gpus": 1, "backend": None}
+
+
+def test_bench_refuses_a_launcher_whose_world_size_disagrees_with_gpus():
+    r = _bench(["--gpus", "8", "--dist-backend", "gloo", "--rendezvous-only"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 8 but the launcher started WORLD_SIZE=1" in (r.stderr + r.stdout)
