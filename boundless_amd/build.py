@@ -130,6 +130,20 @@ def _deps_mtime():
     return m
 
 
+EXPORTS = os.path.join(CSRC, "exports.map")
+FLAGS_STAMP = os.path.join(OBJ, "flags.stamp")
+
+
+def _flags_fingerprint():
+    """What every object depends on besides its sources: the compile flags, the per-TU -cuid scheme and the compiler.  Stored next to
+    the objects; a tree whose objects were built with other flags (e.g. before -fvisibility=hidden or the path-independent -cuid) is
+    rebuilt from scratch instead of keeping objects whose device_code_hash() differs from a clean build's."""
+    import hashlib
+
+    flags = [f for f in FLAGS if not f.startswith("-I")]  # include paths name where the tree lives (it moves: the GPU box gets a copy)
+    return hashlib.sha256("\n".join(flags + [cuid_flag(s) for s in sources()] + [ARCH]).encode()).hexdigest()
+
+
 def _compile(src, force, hdr_mtime):
     obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
     path = os.path.join(CSRC, src)
@@ -148,11 +162,17 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hdr = _deps_mtime()
     srcs = sources()
+    fp = _flags_fingerprint()
+    if not (os.path.exists(FLAGS_STAMP) and open(FLAGS_STAMP).read().strip() == fp):
+        force = True  # objects of unknown or different flags
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB):
-        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}",
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(fp + "\n")
+    # the link also depends on the version script (which symbols are exported)
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(EXPORTS):
+        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", f"-Wl,--version-script={EXPORTS}",
                "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -51,7 +51,6 @@ struct bx_ctx {
     // NTT tables (device): stage table index 2^(s-1)+e -> w_{2^s}^{+-e} (Montgomery)
     uint32_t* d_tw_fwd = nullptr;
     uint32_t* d_tw_inv = nullptr;
-    uint2* d_tw_fwd_pair = nullptr;  // {d_tw_fwd[i], P - d_tw_fwd[i]}: the two twiddles of a fused-reduction butterfly (ntt_r16.hpp)
     std::map<bx::TwistKey, uint32_t*> twist;
     std::map<int, bx::ZkTab> zk;
     std::map<int, uint32_t*> zk_full;  // n -> 3^bitrev_n(i), i < 2^n (fused interpolate + zk_shift)
@@ -82,6 +81,19 @@ struct bx_ctx {
     int scan_next = 0;
     long scan_lookback = 1;  // poly_divide / prefix_products: single-pass decoupled look-back kernels (0 = the three-phase kernels)
 
+    // Deferred Hal::gather_sample calls (poly.hip).  MerkleTreeProver::prove issues one gather per opened row and one per path digest:
+    // ~5 000 launches of a few words each per proof, 3.7 us of host time apiece on an idle GPU (19 of the 70 ms of a proof driven
+    // through the plain trait calls, profiles/r06_plain_hal.json).  A small gather is therefore queued as a 32-byte descriptor and
+    // the queue is launched as ONE kernel by whatever touches the ctx next (BX_ENTER at the top of every entry point, OpScope,
+    // stream_wait, the staged copies, bx_get_stream), which keeps the stream order the caller sees.  A gather that reads or writes
+    // memory an already queued one writes flushes first.  Off while profiling / tracing (per-call events), or with gather_defer = 0.
+    std::vector<uint32_t> gq;  // 8 words per descriptor: dst lo/hi, src + idx lo/hi, size, stride, 0, 0
+    size_t gq_n = 0;
+    uint32_t* d_gq = nullptr;
+    uintptr_t gq_dst_lo = 0, gq_dst_hi = 0, gq_src_lo = 0, gq_src_hi = 0;  // bounding intervals of what the queue writes / reads
+    long gather_defer = 1;
+    static constexpr size_t GQ_MAX = 8192;
+
     // scratch (grown on demand)
     uint32_t* d_scratch = nullptr;
     size_t scratch_words = 0;
@@ -95,10 +107,6 @@ struct bx_ctx {
     long ntt_cols_per_wg = 8;  // forward pass A (2^12 tiles): columns sharing one load of the tile's twist + twiddles
     long ntt_group_cols = 0;   // forward transform: columns per pass-A + pass-B group (0 = all columns per pass)
     long ntt_tile_b_wide = 1;  // grow the pass-B tile (up to 2^14) so that rows are at least 16 words wide
-    // forward passes with fused-reduction butterflies (ntt_r16.hpp): bit 0 = multi-column pass A, bit 1 = pass B.  Off by default:
-    // 21 % fewer VALU instructions, but every one of them a v_mad_u64_u32 / v_mul_lo_u32 — measured 6 % / 8 % / 13 % SLOWER than
-    // the canonical kernels with bit 0 / bit 1 / both set (profiles/r05_lde_fused_ab.jsonl); kept selectable and parity-tested
-    long ntt_fused = 0;
     long hash_rows_block = 256;
     long fold_deep = 2;              // large Merkle layers: up to this many levels per launch, depth first per lane (1 = one launch per layer)
     long dev_draws = 0;  // 1 = the prover draws the FRI challenges (which depend only on a Merkle root) on the device (bx_transcript_step): three blocking
@@ -159,6 +167,12 @@ const char* abi_caught(bx_ctx* c, const char* fn) noexcept;
         if (_e != hipSuccess) return bx::set_err((c), #call, _e, __FILE__, __LINE__); \
     } while (0)
 #define BX_LAUNCH_CHECK(c) BX_HIP(c, hipGetLastError())
+// top of every entry point that touches the device: select it, and launch the gathers queued by earlier bx_gather_sample calls
+#define BX_ENTER(c)                                          \
+    do {                                                     \
+        BX_HIP(c, hipSetDevice((c)->device));                \
+        if ((c)->gq_n) BX_TRY(bx::gather_flush(c));          \
+    } while (0)
 #define BX_REQUIRE(c, cond, msg)                  \
     do {                                          \
         if (!(cond)) return bx::set_msg((c), msg); \
@@ -225,6 +239,7 @@ struct OpScope {
 
 // internal launchers shared between translation units (each returns NULL or an error string)
 const char* ensure_scratch(bx_ctx* c, size_t words);
+const char* gather_flush(bx_ctx* c);  // poly.hip: launch the queued gather_sample descriptors (no-op when the queue is empty)
 constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
 constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;
 constexpr uint32_t FLAG_SLOTS = 4u;

@@ -61,7 +61,8 @@ BX_HD uint32_t fp_mul_lazy(uint32_t a, uint32_t b) { return fp_mad_lazy(a, b, 0u
 // x in [0, 2P) -> canonical
 BX_HD uint32_t fp_reduce(uint32_t x) { return umin(x, x - P); }
 
-// Fused-reduction radix-2 butterfly (ntt_r16.hpp, tunable ntt_fused): u = REDC(a R + b w), d = REDC(a R + b wn) with R = MONT_ONE =
+// Fused-reduction radix-2 butterfly (the round-5 experiment now kept as tools/experiments/r05_ntt_fused_reduction.patch; the host
+// checker tests/host_arith_check.cpp still exercises the arithmetic): u = REDC(a R + b w), d = REDC(a R + b wn) with R = MONT_ONE =
 // 2^32 mod P and wn = P - w, i.e. u == a + b w 2^-32 and d == a - b w 2^-32 (mod P) — the Montgomery butterfly with its addition and
 // subtraction inside the reductions.  a, b may be ANY u32 and w, wn <= P - 1: a R + b w + m P <= (2^32 - 1)(R + 2P - 1) =
 // (2^32 - 1)^2 < 2^64 because R + 2P = 2^32 exactly; the results are < 2^32 (not < 2P): see reduce_any().

@@ -82,6 +82,7 @@ static const char* trace_set(int level) {
 }
 
 OpScope::OpScope(bx_ctx* ctx, const char* n, double b) : c(ctx), name(n), bytes(b) {
+    if (c->gq_n) (void)gather_flush(c);  // queued gathers go first (a failure is sticky: the launch check of this op reports it)
     if (trace_level() > 0) {
         traced = true;
         trace_push(name);
@@ -236,6 +237,7 @@ extern "C" const char* bx_init(int device, bx_ctx** out) try {
 
 namespace bx {
 hipError_t stream_wait(bx_ctx* c) {
+    if (c->gq_n && gather_flush(c) != nullptr) return hipErrorLaunchFailure;
     if (!((c->wait_blocking == 2 || (c->wait_blocking == 1 && c->wait_poll)) && c->wait_ev))
         return hipStreamSynchronize(c->stream);  // sleeps on the interrupt or busy-polls, per the device's schedule flag
     hipError_t e = hipEventRecord(c->wait_ev, c->stream);
@@ -263,6 +265,7 @@ void apply_wait_policy(bx_ctx* c) {
 }
 const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
     BX_REQUIRE(c, words <= dst.len && words <= bx_ctx::UP_WORDS, "h2d_staged: copy too large");
+    if (c->gq_n) BX_TRY(gather_flush(c));
     if (!words) return nullptr;
     if (c->up_used + words > bx_ctx::UP_WORDS) {  // wrap: earlier copies may still be reading the ring
         BX_HIP(c, stream_wait(c));
@@ -276,6 +279,7 @@ const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words)
 }
 const char* d2h_batch_add(bx_ctx* c, size_t* used, bx_buf src, size_t words, const uint32_t** host) {
     BX_REQUIRE(c, words <= src.len && *used + words <= bx_ctx::STAGE_WORDS, "d2h_batch_add: the pinned landing area is full");
+    if (c->gq_n) BX_TRY(gather_flush(c));
     *host = c->h_stage + *used;
     if (words) BX_HIP(c, hipMemcpyAsync(c->h_stage + *used, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
     *used += (words + 3) & ~(size_t)3;
@@ -303,6 +307,7 @@ extern "C" const char* bx_free(bx_ctx* c) try {
     ntt_free_tables(c);
     if (c->d_p2) (void)hipFree(c->d_p2);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_gq) (void)hipFree(c->d_gq);
     for (int b = 0; b < 2; ++b)
         if (c->d_scan[b]) (void)hipFree(c->d_scan[b]);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
@@ -336,12 +341,15 @@ extern "C" const char* bx_set_stream(bx_ctx* c, void* s) try {
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return nullptr;
 } BX_ABI_CATCH(c, "bx_set_stream")
-extern "C" void* bx_get_stream(bx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" void* bx_get_stream(bx_ctx* c) {
+    if (c && c->gq_n) (void)gather_flush(c);  // the caller is about to enqueue work of its own behind ours
+    return c ? (void*)c->stream : nullptr;
+}
 
 extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) try {
     if (!c) return "bx_alloc: null ctx";
     BX_REQUIRE(c, out != nullptr, "bx_alloc: null out");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     void* p = nullptr;
     BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
     out->dptr = p;
@@ -351,7 +359,7 @@ extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) try {
 extern "C" const char* bx_alloc_zeroed(bx_ctx* c, size_t words, bx_buf* out) try {
     if (!c) return "bx_alloc_zeroed: null ctx";
     BX_REQUIRE(c, out != nullptr, "bx_alloc_zeroed: null out");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     void* p = nullptr;
     BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
     if (hipMemsetAsync(p, 0, (words ? words : 1) * 4, c->stream) != hipSuccess) {
@@ -365,7 +373,7 @@ extern "C" const char* bx_alloc_zeroed(bx_ctx* c, size_t words, bx_buf* out) try
 extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     BX_HIP(c, stream_wait(c));
     BX_HIP(c, hipFree(b.dptr));
     return nullptr;
@@ -373,7 +381,7 @@ extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
 extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) try {
     if (!c) return "bx_h2d: null ctx";
     BX_REQUIRE(c, words <= dst.len, "bx_h2d: copy larger than the buffer");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src, words * 4, hipMemcpyHostToDevice, c->stream));
     BX_HIP(c, stream_wait(c));  // src may be pageable and freed by the caller right after
     return nullptr;
@@ -381,7 +389,7 @@ extern "C" const char* bx_h2d(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t
 extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words) try {
     if (!c) return "bx_d2h: null ctx";
     BX_REQUIRE(c, words <= src.len, "bx_d2h: copy larger than the buffer");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (words == 0) return sync_and_check_flag(c);
     if (words <= bx_ctx::STAGE_WORDS) {
         BX_HIP(c, hipMemcpyAsync(c->h_stage, src.dptr, words * 4, hipMemcpyDeviceToHost, c->stream));
@@ -395,23 +403,25 @@ extern "C" const char* bx_d2h(bx_ctx* c, uint32_t* dst, bx_buf src, size_t words
 extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) try {
     if (!c) return "bx_d2d: null ctx";
     BX_REQUIRE(c, words <= src.len && words <= dst.len, "bx_d2d: copy larger than a buffer");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src.dptr, words * 4, hipMemcpyDeviceToDevice, c->stream));
     return nullptr;
 } BX_ABI_CATCH(c, "bx_d2d")
 extern "C" const char* bx_sync(bx_ctx* c) try {
     if (!c) return "bx_sync: null ctx";
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     return sync_and_check_flag(c);
 } BX_ABI_CATCH(c, "bx_sync")
 
 extern "C" const char* bx_timer_start(bx_ctx* c) try {
     if (!c) return "bx_timer_start: null ctx";
+    BX_ENTER(c);
     BX_HIP(c, hipEventRecord(c->t0, c->stream));
     return nullptr;
 } BX_ABI_CATCH(c, "bx_timer_start")
 extern "C" const char* bx_timer_stop(bx_ctx* c, float* ms) try {
     if (!c) return "bx_timer_stop: null ctx";
+    BX_ENTER(c);
     BX_HIP(c, hipEventRecord(c->t1, c->stream));
     BX_HIP(c, hipEventSynchronize(c->t1));
     BX_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
@@ -476,9 +486,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
         c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
-    } else if (!strcmp(name, "ntt_fused")) {
-        BX_REQUIRE(c, value >= 0 && value <= 3, "ntt_fused out of range [0,3] (bit 0: pass A, bit 1: pass B)");
-        c->ntt_fused = value;
+    } else if (!strcmp(name, "gather_defer")) {
+        BX_ENTER(c);
+        c->gather_defer = value != 0;
     } else if (!strcmp(name, "scan_lookback")) {
         c->scan_lookback = value != 0;
     } else if (!strcmp(name, "eval_x4")) {
@@ -503,7 +513,7 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
     } else if (!strcmp(name, "wait_blocking")) {
         BX_REQUIRE(c, value >= 0 && value <= 2, "wait_blocking must be 0 (busy-poll), 1 (sleep until the completion interrupt) or 2 (sleep-poll an event)");
         c->wait_blocking = value;
-        BX_HIP(c, hipSetDevice(c->device));
+        BX_ENTER(c);
         apply_wait_policy(c);
     } else if (!strcmp(name, "wait_poll_us")) {
         BX_REQUIRE(c, value >= 1 && value <= 10000, "wait_poll_us out of range [1, 10000]");

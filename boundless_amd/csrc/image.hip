@@ -51,7 +51,7 @@ extern "C" const char* bx_image_page_cells(bx_ctx* c, bx_buf out, bx_buf raw, si
     BX_REQUIRE(c, raw.len >= n * BX_PAGE_WORDS && out.len >= n * 2 * BX_PAGE_WORDS, "image_page_cells: buffer too small");
     BX_REQUIRE(c, n <= (1u << BX_MERKLE_DEPTH) + 1u, "image_page_cells: more pages than the address space holds");
     if (n == 0) return nullptr;
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "image_page_cells", 12.0 * BX_PAGE_WORDS * (double)n);
     hipLaunchKernelGGL(page_cells_kernel, dim3((unsigned)((n + 63) / 64), BX_PAGE_WORDS / 64), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
                        (const uint32_t*)raw.dptr, (uint32_t)n);

@@ -228,20 +228,11 @@ const char* ntt_init_tables(bx_ctx* c) {
     BX_HIP(c, hipMalloc(&c->d_tw_inv, n * 4));
     BX_HIP(c, hipMemcpy(c->d_tw_fwd, f.data(), n * 4, hipMemcpyHostToDevice));
     BX_HIP(c, hipMemcpy(c->d_tw_inv, r.data(), n * 4, hipMemcpyHostToDevice));
-    // the fused-reduction butterflies multiply by the root and by its negative (ntt_r16.hpp): interleaved, one 8-byte load each
-    std::vector<uint32_t> pr(2 * n, 0);
-    for (size_t i = 1; i < n; ++i) {
-        pr[2 * i] = f[i];
-        pr[2 * i + 1] = P - f[i];
-    }
-    BX_HIP(c, hipMalloc(&c->d_tw_fwd_pair, n * 8));
-    BX_HIP(c, hipMemcpy(c->d_tw_fwd_pair, pr.data(), n * 8, hipMemcpyHostToDevice));
     return nullptr;
 }
 void ntt_free_tables(bx_ctx* c) {
     if (c->d_tw_fwd) (void)hipFree(c->d_tw_fwd);
     if (c->d_tw_inv) (void)hipFree(c->d_tw_inv);
-    if (c->d_tw_fwd_pair) (void)hipFree(c->d_tw_fwd_pair);
     for (auto& kv : c->twist) (void)hipFree(kv.second);
     for (auto& kv : c->zk) {
         (void)hipFree(kv.second.lo);
@@ -329,42 +320,21 @@ static const char* launch_r16_geom(bx_ctx* c, R16Args a, size_t count) {
     BX_LAUNCH_CHECK(c);
     return nullptr;
 }
-template <int SKIP, bool FUSED = false>
+template <int SKIP>
 static const char* launch_passA_multi(bx_ctx* c, R16Args a, size_t count, uint32_t cpw) {
     a.cols = (uint32_t)count;
     a.cpw = cpw;
     size_t lds = ((size_t)4096 + 256) * 4 * 2;  // two tiles, alternating by column
     unsigned groups = (unsigned)((count + cpw - 1) / cpw);
-    hipLaunchKernelGGL((ntt_passA_fwd12_multi_kernel<SKIP, FUSED>), dim3(a.tiles * groups), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL((ntt_passA_fwd12_multi_kernel<SKIP>), dim3(a.tiles * groups), dim3(256), lds, c->stream, a);
     BX_LAUNCH_CHECK(c);
     return nullptr;
-}
-template <int LR, int LT>
-static const char* launch_passB_fused(bx_ctx* c, R16Args a, size_t count) {
-    const uint32_t tile_elems = 1u << (LR + LT);
-    const size_t lds = ((size_t)tile_elems + (tile_elems >> 4)) * 4;
-    a.cols = (uint32_t)count;
-    BX_REQUIRE(c, (size_t)a.tiles * count < ((size_t)1 << 31), "ntt: too many workgroups in one launch");
-    BX_TRY(allow_lds(c, (ntt_passB_fwd_fused_kernel<LR, LT>), lds));
-    hipLaunchKernelGGL((ntt_passB_fwd_fused_kernel<LR, LT>), dim3(a.tiles * (unsigned)count), dim3(tile_elems / 32), lds, c->stream, a);
-    BX_LAUNCH_CHECK(c);
-    return nullptr;
-}
-// The fused-reduction kernels cover the hot forward shapes: pass A = the multi-column 2^12 kernel (tunable ntt_fused bit 0), pass B
-// = one of the tile geometries below (bit 1; LDE of po2 18 .. 22 segments with the default tunables).  Memory holds canonical words
-// between the passes, so either pass may run in either form; everything else runs the canonical kernels.
-static bool fused_geometry_b(int lr, int lt) {
-    return (lr == 8 && lt == 5) || (lr == 9 && lt == 4) || (lr == 10 && lt == 4) || (lr == 11 && lt == 3) || (lr == 12 && lt == 2);
 }
 // hot geometries (BASELINE sizes 2^20 / 2^22, default tunables) get a compile-time specialisation
 template <bool INV, bool PASS_A, int SKIP>
 static const char* launch_r16(bx_ctx* c, const R16Args& a, size_t count) {
     if (PASS_A && !INV && a.lr == 12 && a.lrows == 12 && a.lt == 0 && c->ntt_cols_per_wg > 1 && count > 1 &&
         (a.expand == 0 || a.expand == 2)) {
-        if (a.twist != nullptr && (c->ntt_fused & 1)) {  // fused-reduction butterflies (a.tw_pair set by fast_pass_a)
-            if (SKIP == 2) return launch_passA_multi<2, true>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
-            if (SKIP == 0) return launch_passA_multi<0, true>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
-        }
         if (SKIP == 2) return launch_passA_multi<2>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
         if (SKIP == 0) return launch_passA_multi<0>(c, a, count, (uint32_t)c->ntt_cols_per_wg);
     }
@@ -393,7 +363,7 @@ static const char* fast_pass_a(bx_ctx* c, bool inv, uint32_t* out, const uint32_
     if (!aligned16(out) || !aligned16(in) || (((size_t)1 << m) >> expand) % 4 != 0) return nullptr;
     if (!(skip == 0 || (skip == 2 && !inv))) return nullptr;
     R16Args a;
-    a.out = out; a.in = in; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.tw_pair = c->d_tw_fwd_pair; a.twist = twist; a.scale = scale;
+    a.out = out; a.in = in; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.twist = twist; a.scale = scale;
     // the final store of the inverse pass A applies `post` only in its 16-words-per-thread form (the last step is K = 4 at s0 = 0 whenever m_hi >= 4)
     const bool can_post = inv && post && m_hi >= 4;
     a.post = can_post ? post : nullptr;
@@ -426,6 +396,9 @@ static const char* fast_pass_b(bx_ctx* c, bool inv, uint32_t* io, size_t count, 
     int m_lo = m - m_hi;
     const int lt = pass_b_lt(c, m, m_hi);
     if (lt < 0) return nullptr;
+    // pass B addresses a column through a buffer descriptor with 32-bit byte offsets and a 32-bit num_records (ntt_r16.hpp glb_get /
+    // glb_put): a column must stay below 4 GiB, or loads past the wrap would return 0 and stores be dropped silently
+    BX_REQUIRE(c, (((size_t)1 << m) * 4) >> 32 == 0, "ntt: a column of 2^30 words or more does not fit pass B's 32-bit buffer offsets");
     R16Args a;
     a.out = io; a.in = io; a.tw = inv ? c->d_tw_inv : c->d_tw_fwd; a.twist = nullptr; a.scale = MONT_ONE;
     a.lr = m_lo; a.lrows = m_lo; a.lt = lt; a.expand = 0; a.row_shift = m_hi;
@@ -434,14 +407,6 @@ static const char* fast_pass_b(bx_ctx* c, bool inv, uint32_t* io, size_t count, 
     a.tiles = 1u << (m_hi - lt);
     *ok = true;
     if (inv) return launch_r16<true, false, 0>(c, a, count);
-    if ((c->ntt_fused & 2) && fused_geometry_b(m_lo, lt)) {  // fused-reduction butterflies, two half-row units per thread
-        a.tw_pair = c->d_tw_fwd_pair;
-        if (m_lo == 8) return launch_passB_fused<8, 5>(c, a, count);
-        if (m_lo == 9) return launch_passB_fused<9, 4>(c, a, count);
-        if (m_lo == 10) return launch_passB_fused<10, 4>(c, a, count);
-        if (m_lo == 11) return launch_passB_fused<11, 3>(c, a, count);
-        return launch_passB_fused<12, 2>(c, a, count);
-    }
     return launch_r16<false, false, 0>(c, a, count);
 }
 
@@ -593,7 +558,7 @@ static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count);
 extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_interpolate_zk: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_zk: io.len/count must be a power of two");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     const int m = ilog2(io.len / count);
     bool fused = false;
     {
@@ -609,7 +574,7 @@ extern "C" const char* bx_batch_interpolate_zk(bx_ctx* c, bx_buf io, size_t coun
 extern "C" const char* bx_batch_interpolate_ntt(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_interpolate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_interpolate_ntt: io.len/count must be a power of two");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_interpolate_ntt", 8.0 * (double)io.len);
     return inverse(c, (uint32_t*)io.dptr, count, ilog2(io.len / count));
 } BX_ABI_CATCH(c, "bx_batch_interpolate_ntt")
@@ -619,7 +584,7 @@ extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count,
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_evaluate_ntt: io.len/count must be a power of two");
     int m = ilog2(io.len / count);
     BX_REQUIRE(c, (int)expand_bits <= m, "batch_evaluate_ntt: expand_bits > log2(size)");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_evaluate_ntt", 8.0 * (double)io.len);
     return forward(c, (uint32_t*)io.dptr, (const uint32_t*)io.dptr, count, m, 0, (int)expand_bits);
 } BX_ABI_CATCH(c, "bx_batch_evaluate_ntt")
@@ -629,7 +594,7 @@ extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, 
     BX_REQUIRE(c, count > 0 && in.len % count == 0 && is_pow2(in.len / count), "batch_expand_into_evaluate_ntt: in.len/count must be a power of two");
     BX_REQUIRE(c, out.len == (in.len << expand_bits), "batch_expand_into_evaluate_ntt: out.len != in.len << expand_bits");
     BX_REQUIRE(c, out.dptr != in.dptr || expand_bits == 0, "batch_expand_into_evaluate_ntt: in-place expansion");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_expand_into_evaluate_ntt", 4.0 * (double)in.len + 4.0 * (double)out.len);
     int m = ilog2(out.len / count);
     return forward(c, (uint32_t*)out.dptr, (const uint32_t*)in.dptr, count, m, (int)expand_bits, (int)expand_bits);
@@ -638,7 +603,7 @@ extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, 
 extern "C" const char* bx_batch_bit_reverse(bx_ctx* c, bx_buf io, size_t count) try {
     if (!c) return "bx_batch_bit_reverse: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_bit_reverse: io.len/count must be a power of two");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_bit_reverse", 8.0 * (double)io.len);
     int n = ilog2(io.len / count);
     if (n == 0) return nullptr;
@@ -673,7 +638,7 @@ extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t
     BX_REQUIRE(c, count > 0 && io_ext.len % (4 * count) == 0 && is_pow2(io_ext.len / (4 * count)),
                "batch_bit_reverse_ext: io.len/(4*count) must be a power of two");
     BX_REQUIRE(c, ((uintptr_t)io_ext.dptr & 15) == 0, "batch_bit_reverse_ext: buffer must be 16-byte aligned");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_bit_reverse", 8.0 * (double)io_ext.len);
     const size_t elems = io_ext.len / 4;
     const int n = ilog2(elems / count);
@@ -691,7 +656,7 @@ extern "C" const char* bx_zk_shift(bx_ctx* c, bx_buf io, size_t count) try {
 } BX_ABI_CATCH(c, "bx_zk_shift")
 static const char* zk_shift_impl(bx_ctx* c, bx_buf io, size_t count) {
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "zk_shift: io.len/count must be a power of two");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "zk_shift", 8.0 * (double)io.len);
     int n = ilog2(io.len / count);
     ZkTab t;

@@ -25,7 +25,6 @@ struct R16Args {
     uint32_t* out;
     const uint32_t* in;
     const uint32_t* tw;     // stage table (forward or inverse roots)
-    const uint2* tw_pair = nullptr;  // fused-reduction passes: {tw[i], P - tw[i]}
     const uint32_t* twist;  // pass A only: per-element factor (nullptr = none)
     const uint32_t* post = nullptr;  // pass A inverse only: per-position factor applied on the final store
     uint32_t scale;         // pass A inverse without twist: 1/M
@@ -135,32 +134,6 @@ __device__ __forceinline__ void tw_load(uint32_t (&tw)[16], const uint32_t* __re
         }
     }
 }
-// the same slots from the interleaved table {w, P - w} of the fused-reduction butterflies: one 8-byte buffer load per twiddle,
-// the unit's `lo` in the per-lane offset and everything else in the scalar offset (no vector address arithmetic)
-template <int K, bool S0ZERO, int SKIP>
-__device__ __forceinline__ void tw_load_pair(uint32_t (&tw)[16], uint32_t (&tn)[16], const uint2* __restrict__ ltw, int s0, int lt, uint32_t tid,
-                                             uint32_t nt) {
-    constexpr int U = 16 >> K, E = 1 << K;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(ltw), 0, 8u << TW_LOG, 0x00020000);
-#pragma unroll
-    for (int w = 0; w < U; ++w) {
-        const uint32_t rl = (tid + nt * w) >> lt;
-        const uint32_t lo = S0ZERO ? 0u : (rl & ((1u << s0) - 1u));
-#pragma unroll
-        for (int k = 1; k <= K; ++k) {
-            if (k <= SKIP) continue;
-            const int half = 1 << (k - 1);
-#pragma unroll
-            for (int jj = 0; jj < half; ++jj) {
-                if (S0ZERO && jj == 0) continue;
-                const __attribute__((ext_vector_type(2))) uint32_t v =
-                    __builtin_amdgcn_raw_buffer_load_b64(rs, lo * 8u, ((1u << (s0 + k - 1)) + ((uint32_t)jj << s0)) * 8u, 0);
-                tw[w * E + half - 1 + jj] = v[0];
-                tn[w * E + half - 1 + jj] = v[1];
-            }
-        }
-    }
-}
 // IN_LAZY (forward only): the registers arrive in [0, 2P) (the previous step left its last stage uncorrected); the "a" operands of
 // the first stage are reduced here, where they are consumed — the "b" operands feed a product and need nothing.  OUT_LAZY
 // (forward only): the last stage leaves both outputs in [0, 2P) for a consumer that reduces on use (the next step, or the twist
@@ -200,69 +173,6 @@ __device__ __forceinline__ void step_compute_tw(uint32_t (&x)[16], const uint32_
                         else bfly_tw<INV>(xu[j], xu[j + half], wv);
                     }
                 }
-            }
-        }
-    }
-}
-
-// ---- fused-reduction butterflies (forward LDE, both passes) -------------------------------------------------------------------
-// EXPERIMENT, off by default (tunable ntt_fused): fewer instructions, measured slower — see the end of this comment.
-// On gfx950 a VALU instruction in a MIXED integer stream issues at ~1.75 ns per wave and SIMD whatever its class
-// (profiles/r05_microbench5_class_mix.jsonl: the 2-cycle rate of v_add/v_sub only exists in long runs of them), so the cost of a
-// butterfly is its instruction COUNT.  The canonical butterfly above is 8 - 11 instructions: a 3-instruction lazy product and
-// 5 - 8 additions and conditional subtractions that exist only because BabyBear leaves one spare bit in a 32-bit word.
-// Here every value is just a u32 with the right residue, and the sum / difference ride in the product's 64-bit accumulator:
-//     t0 = a * R            (R = 2^32 mod P = the Montgomery word of 1; 64-bit)
-//     u  = (t0 + b * w  + m  * P) / 2^32          d = (t0 + b * (P - w) + m' * P) / 2^32      (w = the Montgomery twiddle word)
-// i.e. REDC(a R + b w) = a + b w 2^-32 (mod P), the Montgomery butterfly with its additions inside the reduction.
-// 7 instructions (v_mad_u64_u32 x3, then [v_mul_lo_u32, v_mad_u64_u32] x2), no v_min, no corrections, no register copies.
-// Bounds: a, b may be ANY u32 and w <= P - 1: a R + b w + m P <= (2^32 - 1)(R + 2P - 1) = (2^32 - 1)^2 < 2^64 because
-// R + 2P = 2^32 exactly; the result is < 2^32 (not < 2P), so a value that leaves the pass is brought to [0, P) by reduce_any().
-// A stage whose twiddles are ALL 1 and whose inputs are canonical (stage 1 of pass B) stays a plain add / subtract (3
-// instructions).  Words stored to memory are canonical, so both passes remain bit-identical to the canonical kernels.
-// (A "drift" variant that adds a through the accumulator's 64-bit addend — u = (a + b w' + m P)/2^32 with plain-integer w' — saves
-// the a*R product but hipcc spends two v_mov per butterfly building the zero-extended pair: 8 instructions, and every stage
-// scales the array by 2^-32, which the twist table would have to undo.  Worse on count, and not kept.)
-// MEASURED (profiles/r05_lde_fused_ab.jsonl, r05_microbench4_operand_kinds.jsonl): as a bare arithmetic loop the fused butterfly
-// takes 14.6 ns per wave and SIMD against 19.2 ns for the 11-instruction canonical one — but the canonical kernels are mostly
-// LAZY butterflies (8 instructions, ~14 ns), and in the kernels the all-multiplier stream runs ~40 % slower per instruction than
-// the mixed one: the 2^22 x 256 LDE takes 3.68 ms canonical, 3.90 with pass A fused, 3.97 with pass B fused, 4.14 with both.
-__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-// bfly_fused() and reduce_any() themselves live in fp.hpp (host + device), where tests/host_arith_check.cpp pushes every extreme
-// operand through them with 128-bit reference arithmetic.
-// PLAIN1: stage 1 is the plain add / subtract of canonical inputs (all its twiddles are 1)
-template <int K, bool S0ZERO, int SKIP, bool PLAIN1>
-__device__ __forceinline__ void step_compute_fused(uint32_t (&x)[16], const uint32_t (&tw)[16], const uint32_t (&twn)[16]) {
-    static_assert(!PLAIN1 || (S0ZERO && SKIP == 0), "a plain first stage needs trivial twiddles");
-    constexpr int U = 16 >> K, E = 1 << K;
-#pragma unroll
-    for (int w = 0; w < U; ++w) {
-        uint32_t* xu = &x[w * E];
-#pragma unroll
-        for (int k = 1; k <= K; ++k) {
-            if (k <= SKIP) continue;
-            const int half = 1 << (k - 1);
-            if (PLAIN1 && k == 1) {
-#pragma unroll
-                for (int j = 0; j < E; j += 2) {
-                    const uint32_t u = xu[j] + xu[j + 1], d = xu[j] - xu[j + 1] + P;  // canonical in: both < 2P
-                    xu[j] = u;
-                    xu[j + 1] = d;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int jj = 0; jj < half; ++jj) {
-                const bool one = S0ZERO && jj == 0;
-                // a unit twiddle is hidden from the optimiser: knowing w == R it rewrites a R + b R as a 64-bit (a + b) times R,
-                // which costs more instructions (zero-extensions, a 64 x 32-bit product) than the butterfly it replaces
-                const uint32_t wv = one ? opaque_sgpr(MONT_ONE) : tw[w * E + half - 1 + jj];
-                const uint32_t wm = one ? opaque_sgpr(P - MONT_ONE) : twn[w * E + half - 1 + jj];
-#pragma unroll
-                for (int j = jj; j < E; j += 2 * half) bfly_fused(xu[j], xu[j + half], wv, wm);
             }
         }
     }
@@ -601,10 +511,8 @@ __global__ __launch_bounds__(MAXT) void ntt_r16_kernel(R16Args a) {
 // once and reused for `a.cpw` consecutive columns.  Cuts the twist re-reads (one 2^m-word table per column otherwise:
 // measured 0.9 GB fetched per launch for 0.2 GB of input) and ~60 address/load instructions per column.
 // 158 VGPRs = 3 waves per SIMD; forcing 4 (128 VGPRs, 34 spill instructions) or 5 measured 3 % / 18 % slower.
-// FUSED: the fused-reduction butterflies above (a.tw_pair = the stage table interleaved with its negatives); registers then hold arbitrary u32 residues,
-// which the twist product accepts as they are; its result is reduced once before the store.
-template <int SKIP, bool FUSED = false>
-__global__ __launch_bounds__(256, FUSED ? 4 : 1) void ntt_passA_fwd12_multi_kernel(R16Args a) {
+template <int SKIP>
+__global__ __launch_bounds__(256, 1) void ntt_passA_fwd12_multi_kernel(R16Args a) {
     extern __shared__ uint32_t lds[];
     uint32_t* s = lds;
     const uint32_t* __restrict__ ltw = a.tw;
@@ -615,14 +523,9 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void ntt_passA_fwd12_multi_kern
     const uint32_t tile = blockIdx.x & (a.tiles - 1u), colg = blockIdx.x >> (uint32_t)__builtin_ctz(a.tiles);  // power of two
     const size_t tile_off = (size_t)tile << 12;
     uint32_t tw0[16], tw1[16], tw2[16], f[16];
-    uint32_t tn0[16], tn1[16], tn2[16];
-    if (FUSED) {
-        tw_load_pair<4, true, SKIP>(tw0, tn0, a.tw_pair, 0, 0, tid, nt);  // wave-uniform (scalar registers)
-    } else {
-        tw_load<4, true, SKIP>(tw0, ltw, 0, 0, tid, nt);
-        tw_load<4, false, 0>(tw1, ltw, 4, 0, tid, nt);
-        tw_load<4, false, 0>(tw2, ltw, 8, 0, tid, nt);
-    }
+    tw_load<4, true, SKIP>(tw0, ltw, 0, 0, tid, nt);
+    tw_load<4, false, 0>(tw1, ltw, 4, 0, tid, nt);
+    tw_load<4, false, 0>(tw2, ltw, 8, 0, tid, nt);
     const bool has_twist = a.twist != nullptr;
     if (has_twist) {
         const uint32_t* tp = a.twist + tile_off;  // last step: thread owns rows tid + 256 * mid
@@ -653,30 +556,6 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void ntt_passA_fwd12_multi_kern
                 x[4 * i] = v[0]; x[4 * i + 1] = v[1]; x[4 * i + 2] = v[2]; x[4 * i + 3] = v[3];
             }
         }
-        if (FUSED) {
-            // stage 1 (when it is not skipped) has only unit twiddles and canonical inputs: plain add / subtract
-            // The twiddle pairs of steps 1 and 2 are re-read for every column (8-byte loads, L1 hits, no VALU work) instead of
-            // living in 60 registers across the column loop: four waves per SIMD instead of two.  The pointer is laundered
-            // through an empty asm so that hipcc does not hoist the loads back out of the loop.
-            const uint2* tpp = a.tw_pair;
-            asm volatile("" : "+s"(tpp));
-            step_compute_fused<4, true, SKIP, SKIP == 0>(x, tw0, tn0);
-            lds_put<4>(x, sc, 0, 0, tid, nt);
-            tw_load_pair<4, false, 0>(tw1, tn1, tpp, 4, 0, tid, nt);
-            __syncthreads();
-            lds_get<4>(x, sc, 4, 0, tid, nt);
-            step_compute_fused<4, false, 0, false>(x, tw1, tn1);
-            lds_put<4>(x, sc, 4, 0, tid, nt);
-            __builtin_amdgcn_sched_barrier(0);
-            tw_load_pair<4, false, 0>(tw2, tn2, tpp, 8, 0, tid, nt);
-            __syncthreads();
-            lds_get<4>(x, sc, 8, 0, tid, nt);
-            step_compute_fused<4, false, 0, false>(x, tw2, tn2);
-            const __amdgpu_buffer_rsrc_t rd = col_rsrc(dst, 16384u);
-#pragma unroll
-            for (int mid = 0; mid < 16; ++mid) __builtin_amdgcn_raw_buffer_store_b32(fp_mul(x[mid], f[mid]), rd, tid * 4u, 1024u * mid, 0);
-            continue;
-        }
         step_compute_tw<4, false, true, SKIP, false, true>(x, tw0);
         lds_put<4>(x, sc, 0, 0, tid, nt);
         __syncthreads();
@@ -694,120 +573,6 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void ntt_passA_fwd12_multi_kern
             step_compute_tw<4, false, false, 0, true, false>(x, tw2);
 #pragma unroll
             for (int mid = 0; mid < 16; ++mid) __builtin_amdgcn_raw_buffer_store_b32(x[mid], rd, tid * 4u, 1024u * mid, 0);
-        }
-    }
-}
-
-// Pass B of the forward transform with fused-reduction butterflies.  Tile = 2^LR rows x T = 2^LT adjacent positions; a thread owns TWO units of 16
-// elements with the same rows, T/2 positions apart: twiddles depend on the row only, so both units share one load of them (and of
-// their negatives), and the workgroup is half as large as the canonical kernel's for the same tile (2^14 elements: 512 threads,
-// two workgroups per CU at <= 128 VGPRs).  Stage 1 is the plain add / subtract of canonical inputs; the last step's outputs are
-// reduced to [0, P) and stored.  Global accesses are buffer loads / stores: one per-lane offset per unit,
-// the row in the scalar offset, the second unit T/2 words further (immediate).
-template <int K>
-__device__ __forceinline__ void b2_coords(int w, int s0, int lth, uint32_t tid, uint32_t nt, uint32_t& base_row, uint32_t& tl) {
-    unit_coords<K>(w, s0, lth, tid, nt, base_row, tl);  // units enumerated over (row group, position within the half row)
-}
-template <int K, int LT>
-__device__ __forceinline__ void b2_lds_put(const uint32_t (&x)[16], uint32_t* __restrict__ s, int s0, uint32_t h, uint32_t tid, uint32_t nt) {
-    constexpr int U = 16 >> K, E = 1 << K;
-#pragma unroll
-    for (int w = 0; w < U; ++w) {
-        uint32_t base_row, tl;
-        b2_coords<K>(w, s0, LT - 1, tid, nt, base_row, tl);
-        const uint32_t ib = (base_row << LT) | (tl + (h << (LT - 1)));
-        const int sh = s0 + LT;
-        if (sh >= 4) {
-            const uint32_t pb = lds_phys(ib), step = (1u << sh) + (1u << (sh - 4));
-#pragma unroll
-            for (int mid = 0; mid < E; ++mid) s[pb + (uint32_t)mid * step] = x[w * E + mid];
-        } else {
-#pragma unroll
-            for (int mid = 0; mid < E; ++mid) s[lds_phys(ib + ((uint32_t)mid << sh))] = x[w * E + mid];
-        }
-    }
-}
-template <int K, int LT>
-__device__ __forceinline__ void b2_lds_get(uint32_t (&x)[16], const uint32_t* __restrict__ s, int s0, uint32_t h, uint32_t tid, uint32_t nt) {
-    constexpr int U = 16 >> K, E = 1 << K;
-#pragma unroll
-    for (int w = 0; w < U; ++w) {
-        uint32_t base_row, tl;
-        b2_coords<K>(w, s0, LT - 1, tid, nt, base_row, tl);
-        const uint32_t ib = (base_row << LT) | (tl + (h << (LT - 1)));
-        const int sh = s0 + LT;
-        if (sh >= 4) {
-            const uint32_t pb = lds_phys(ib), step = (1u << sh) + (1u << (sh - 4));
-#pragma unroll
-            for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[pb + (uint32_t)mid * step];
-        } else {
-#pragma unroll
-            for (int mid = 0; mid < E; ++mid) x[w * E + mid] = s[lds_phys(ib + ((uint32_t)mid << sh))];
-        }
-    }
-}
-template <int LR, int LT>
-__global__ __launch_bounds__(1 << (LR + LT - 5), 4) void ntt_passB_fwd_fused_kernel(R16Args a) {
-    static_assert(LR >= 5 && LR <= 13 && LT >= 1 && LR + LT <= 14 && LR + LT >= 11, "tile geometry");
-    extern __shared__ uint32_t lds[];
-    uint32_t* s = lds;
-    constexpr uint32_t nt = 1u << (LR + LT - 5);
-    constexpr int NS = (LR + 3) / 4, KL = LR - 4 * (NS - 1);  // steps; stages of the last step
-    const uint32_t tid = threadIdx.x;
-    const uint32_t tl_ = (uint32_t)__builtin_ctz(a.tiles);
-    const uint32_t bt = blockIdx.x & (a.tiles - 1u), col = blockIdx.x >> tl_;
-    const uint32_t tile = (a.tiles % 8u == 0u) ? (bt % 8u) * (a.tiles / 8u) + bt / 8u : bt;  // tiles sharing a 128-byte line on one XCD
-    const size_t tile_off = (size_t)tile << LT;
-    const __amdgpu_buffer_rsrc_t rs = col_rsrc(a.in + (size_t)col * a.in_col_stride + tile_off, (uint32_t)((a.in_col_stride - tile_off) * 4));
-    const int rsh = a.row_shift;
-    uint32_t xa[16], xb[16], tw[16], tn[16];
-    {   // step 0: rows hi * 16 + mid straight from global memory
-        uint32_t base_row, tl;
-        b2_coords<4>(0, 0, LT - 1, tid, nt, base_row, tl);
-        const uint32_t vo = ((base_row << rsh) + tl) << 2;
-#pragma unroll
-        for (int mid = 0; mid < 16; ++mid) xa[mid] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (uint32_t)mid << (rsh + 2), 0);
-#pragma unroll
-        for (int mid = 0; mid < 16; ++mid) xb[mid] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + (4u << (LT - 1)), (uint32_t)mid << (rsh + 2), 0);
-        tw_load_pair<4, true, 0>(tw, tn, a.tw_pair, 0, LT - 1, tid, nt);
-        step_compute_fused<4, true, 0, true>(xa, tw, tn);
-        b2_lds_put<4, LT>(xa, s, 0, 0u, tid, nt);
-        __builtin_amdgcn_sched_barrier(0);  // keep the two units apart: interleaving them doubles the live 64-bit temporaries
-        step_compute_fused<4, true, 0, true>(xb, tw, tn);
-        b2_lds_put<4, LT>(xb, s, 0, 1u, tid, nt);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int si = 1; si < NS - 1; ++si) {  // full middle steps; a step rewrites the words its own thread read
-        const int s0 = 4 * si;
-        tw_load_pair<4, false, 0>(tw, tn, a.tw_pair, s0, LT - 1, tid, nt);
-        b2_lds_get<4, LT>(xa, s, s0, 0u, tid, nt);  // one unit at a time: 16 data registers next to the 30 twiddles
-        step_compute_fused<4, false, 0, false>(xa, tw, tn);
-        b2_lds_put<4, LT>(xa, s, s0, 0u, tid, nt);
-        __builtin_amdgcn_sched_barrier(0);
-        b2_lds_get<4, LT>(xa, s, s0, 1u, tid, nt);
-        step_compute_fused<4, false, 0, false>(xa, tw, tn);
-        b2_lds_put<4, LT>(xa, s, s0, 1u, tid, nt);
-        __syncthreads();
-    }
-    {   // last step: KL stages, reduce, store
-        constexpr int s0 = 4 * (NS - 1);
-        constexpr int U = 16 >> KL, E = 1 << KL;
-        tw_load_pair<KL, false, 0>(tw, tn, a.tw_pair, s0, LT - 1, tid, nt);
-        const __amdgpu_buffer_rsrc_t rd = col_rsrc(a.out + (size_t)col * a.out_col_stride + tile_off, (uint32_t)((a.out_col_stride - tile_off) * 4));
-#pragma unroll
-        for (uint32_t h = 0; h < 2; ++h) {
-            b2_lds_get<KL, LT>(xa, s, s0, h, tid, nt);
-            step_compute_fused<KL, false, 0, false>(xa, tw, tn);
-#pragma unroll
-            for (int w = 0; w < U; ++w) {
-                uint32_t base_row, tl;
-                b2_coords<KL>(w, s0, LT - 1, tid, nt, base_row, tl);
-                const uint32_t vo = (((base_row << rsh) + tl) << 2) + h * (4u << (LT - 1));
-#pragma unroll
-                for (int mid = 0; mid < E; ++mid) __builtin_amdgcn_raw_buffer_store_b32(reduce_any(xa[w * E + mid]), rd, vo, (uint32_t)mid << (rsh + s0 + 2), 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

@@ -6,6 +6,8 @@
 // All of these stream each input word once; they are HBM-bound except batch_evaluate_any and
 // poly_divide, whose Fp4 products make them VALU-bound.
 #define BX_PLAIN_MAD 1  // the signed multiply-adds of lazy_ext.hpp are left to the compiler here (no loop-carried cell state)
+#include <algorithm>
+
 #include "ctx.hpp"
 #include "lazy_ext.hpp"
 
@@ -382,6 +384,14 @@ __global__ void gather_sample_kernel(uint32_t* __restrict__ dst, const uint32_t*
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < size) dst[i] = src[idx + i * stride];
 }
+// the queued form (bx_ctx::gq): one workgroup per descriptor {dst, src + idx, size, stride}
+__global__ __launch_bounds__(64) void gather_batch_kernel(const uint4* __restrict__ descs) {
+    const uint4 a = descs[2 * blockIdx.x], b = descs[2 * blockIdx.x + 1];
+    uint32_t* __restrict__ dst = (uint32_t*)(((unsigned long long)a.y << 32) | a.x);
+    const uint32_t* __restrict__ src = (const uint32_t*)(((unsigned long long)a.w << 32) | a.z);
+    const uint32_t size = b.x, stride = b.y;
+    for (uint32_t i = threadIdx.x; i < size; i += 64u) dst[i] = src[(size_t)i * stride];
+}
 
 // The chunk walks below are chains of dependent Fp4 products; their loads are independent, so they are issued eight at a
 // time (SCAN_B elements = 128 bytes per lane in flight) instead of one per product.
@@ -614,7 +624,7 @@ static inline unsigned grid1d(size_t n, unsigned bs = 256, size_t cap = 65536) {
 extern "C" const char* bx_fri_fold(bx_ctx* c, bx_buf out, bx_buf in, const uint32_t mix[4]) try {
     if (!c) return "bx_fri_fold: null ctx";
     BX_REQUIRE(c, out.len % 4 == 0 && in.len == out.len * BX_FRI_FOLD, "fri_fold: input.len must be 16 * output.len");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t count = out.len / 4;
     OpScope op(c, "fri_fold", 4.0 * (double)(in.len + out.len));
     if (!count) return nullptr;
@@ -627,7 +637,7 @@ extern "C" const char* bx_fri_fold_dev(bx_ctx* c, bx_buf out, bx_buf in, bx_buf 
     if (!c) return "bx_fri_fold_dev: null ctx";
     BX_REQUIRE(c, out.len % 4 == 0 && in.len == out.len * BX_FRI_FOLD, "fri_fold_dev: input.len must be 16 * output.len");
     BX_REQUIRE(c, mix_ext.dptr != nullptr && mix_ext.len >= 4, "fri_fold_dev: mix is one ext element in device memory");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t count = out.len / 4;
     OpScope op(c, "fri_fold", 4.0 * (double)(in.len + out.len));
     if (!count) return nullptr;
@@ -642,7 +652,7 @@ extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t 
     if (!c) return "bx_mix_poly_coeffs: null ctx";
     BX_REQUIRE(c, in.len >= input_size * count && combos.len >= input_size, "mix_poly_coeffs: input/combos too small");
     BX_REQUIRE(c, count > 0 && out.len % (4 * count) == 0, "mix_poly_coeffs: out.len not a multiple of 4*count");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (!input_size) return nullptr;
     size_t n_combos = out.len / (4 * count);
     OpScope op(c, "mix_poly_coeffs", 4.0 * (double)(input_size * count) + 32.0 * (double)out.len / 4.0);
@@ -668,7 +678,7 @@ static const char* evaluate_any_impl(bx_ctx* c, bx_buf coeffs, size_t poly_count
     BX_REQUIRE(c, poly_count > 0 && coeffs.len % poly_count == 0, "batch_evaluate_any: coeffs.len not a multiple of poly_count");
     size_t evals = which.len;
     BX_REQUIRE(c, xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_any: xs/out must hold one ext elem per eval");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t poly_size = coeffs.len / poly_count;
     size_t seg_elems = (size_t)EV_T * EV_K;
     int brev_log = 0;
@@ -720,7 +730,7 @@ extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_bu
     BX_REQUIRE(c, poly_ptrs.len == 2 * evals && xs.len == 4 * evals && out.len == 4 * evals, "batch_evaluate_ptrs: one pointer (two words), one flag, one point and one result per evaluation");
     BX_REQUIRE(c, is_pow2(poly_size) && poly_size >= seg_elems && poly_size / seg_elems <= 512, "batch_evaluate_ptrs: polynomial size must be a power of two in [2^15, 2^24]");
     BX_REQUIRE(c, evals <= 65535 && ((uintptr_t)poly_ptrs.dptr & 7u) == 0, "batch_evaluate_ptrs: at most 65535 evaluations, pointers 8-byte aligned");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "batch_evaluate_any", 4.0 * (double)(poly_size * evals));
     if (!evals) return nullptr;
     const size_t segs = poly_size / seg_elems;
@@ -743,7 +753,7 @@ extern "C" const char* bx_batch_evaluate_ptrs(bx_ctx* c, bx_buf poly_ptrs, bx_bu
 extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_buf b) try {
     if (!c) return "bx_eltwise_add_elem: null ctx";
     BX_REQUIRE(c, out.len == a.len && a.len == b.len, "eltwise_add_elem: length mismatch");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "eltwise_add_elem", 12.0 * (double)out.len);
     hipLaunchKernelGGL(eltwise_add_kernel, dim3(grid1d(out.len)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
                        (const uint32_t*)a.dptr, (const uint32_t*)b.dptr, out.len);
@@ -753,7 +763,7 @@ extern "C" const char* bx_eltwise_add_elem(bx_ctx* c, bx_buf out, bx_buf a, bx_b
 extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t factor_mont) try {
     if (!c) return "bx_eltwise_mul_factor: null ctx";
     BX_REQUIRE(c, factor_mont < P, "eltwise_mul_factor: factor is not a canonical Montgomery word");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (!io.len) return nullptr;
     OpScope op(c, "eltwise_mul_factor", 8.0 * (double)io.len);
     hipLaunchKernelGGL(eltwise_mul_factor_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, factor_mont, io.len);
@@ -763,14 +773,14 @@ extern "C" const char* bx_eltwise_mul_factor(bx_ctx* c, bx_buf io, uint32_t fact
 extern "C" const char* bx_eltwise_copy_elem(bx_ctx* c, bx_buf out, bx_buf in) try {
     if (!c) return "bx_eltwise_copy_elem: null ctx";
     BX_REQUIRE(c, out.len == in.len, "eltwise_copy_elem: length mismatch");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "eltwise_copy_elem", 8.0 * (double)out.len);
     BX_HIP(c, hipMemcpyAsync(out.dptr, in.dptr, out.len * 4, hipMemcpyDeviceToDevice, c->stream));
     return nullptr;
 } BX_ABI_CATCH(c, "bx_eltwise_copy_elem")
 extern "C" const char* bx_eltwise_zeroize_elem(bx_ctx* c, bx_buf io) try {
     if (!c) return "bx_eltwise_zeroize_elem: null ctx";
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "eltwise_zeroize_elem", 8.0 * (double)io.len);
     hipLaunchKernelGGL(eltwise_zeroize_kernel, dim3(grid1d(io.len)), dim3(256), 0, c->stream, (uint32_t*)io.dptr, io.len);
     BX_LAUNCH_CHECK(c);
@@ -779,7 +789,7 @@ extern "C" const char* bx_eltwise_zeroize_elem(bx_ctx* c, bx_buf io) try {
 extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) try {
     if (!c) return "bx_eltwise_sum_extelem: null ctx";
     BX_REQUIRE(c, out.len % 4 == 0 && out.len > 0 && in.len % out.len == 0, "eltwise_sum_extelem: in.len not a multiple of out.len");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t count = out.len / 4, to_add = in.len / out.len;
     OpScope op(c, "eltwise_sum_extelem", 4.0 * (double)(in.len + out.len));
     hipLaunchKernelGGL(eltwise_sum_ext_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
@@ -791,13 +801,51 @@ extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_
     if (!c) return "bx_gather_sample: null ctx";
     BX_REQUIRE(c, dst.len >= size, "gather_sample: dst too small");
     BX_REQUIRE(c, size == 0 || idx + (size - 1) * stride < src.len, "gather_sample: source index out of range");
-    BX_HIP(c, hipSetDevice(c->device));
     if (!size) return nullptr;
+    // Small gathers are queued and launched together by the next call that touches the ctx (ctx.hpp, "Deferred ... gather_sample"):
+    // the openings of a proof are ~5 000 of them.  Stream order as the caller sees it is kept: anything that could observe the
+    // difference flushes the queue first, and so does a gather that touches memory a queued one writes.
+    if (c->gather_defer && !c->profile && trace_level() == 0 && size <= 4096 && stride <= 0xffffffffu) {
+        const uintptr_t d0 = (uintptr_t)dst.dptr, d1 = d0 + 4 * size;
+        const uintptr_t s0 = (uintptr_t)((const uint32_t*)src.dptr + idx), s1 = s0 + 4 * ((size - 1) * stride + 1);
+        if (c->gq_n && ((s0 < c->gq_dst_hi && c->gq_dst_lo < s1) || (d0 < c->gq_dst_hi && c->gq_dst_lo < d1) || (d0 < c->gq_src_hi && c->gq_src_lo < d1)))
+            BX_TRY(gather_flush(c));  // reads or overwrites what a queued gather writes, or overwrites what one reads
+        if (c->gq_n == bx_ctx::GQ_MAX) BX_TRY(gather_flush(c));
+        if (!c->gq_n) c->gq_dst_lo = c->gq_src_lo = ~(uintptr_t)0, c->gq_dst_hi = c->gq_src_hi = 0;
+        const uint32_t w[8] = {(uint32_t)d0, (uint32_t)((unsigned long long)d0 >> 32), (uint32_t)s0, (uint32_t)((unsigned long long)s0 >> 32),
+                               (uint32_t)size, (uint32_t)stride, 0u, 0u};
+        c->gq.insert(c->gq.end(), w, w + 8);
+        c->gq_n += 1;
+        c->gq_dst_lo = std::min(c->gq_dst_lo, d0), c->gq_dst_hi = std::max(c->gq_dst_hi, d1);
+        c->gq_src_lo = std::min(c->gq_src_lo, s0), c->gq_src_hi = std::max(c->gq_src_hi, s1);
+        return nullptr;
+    }
+    BX_ENTER(c);
     hipLaunchKernelGGL(gather_sample_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)dst.dptr,
                        (const uint32_t*)src.dptr, idx, size, stride);
     BX_LAUNCH_CHECK(c);
     return nullptr;
 } BX_ABI_CATCH(c, "bx_gather_sample")
+
+namespace bx {
+// Launch the queued gathers: the descriptors go up through the pinned ring (h2d_staged: no wait) into d_gq, one workgroup each.
+// The queue is emptied FIRST: everything called from here (h2d_staged, and stream_wait when the ring wraps) checks it too.
+const char* gather_flush(bx_ctx* c) {
+    const size_t n = c->gq_n;
+    if (!n) return nullptr;
+    std::vector<uint32_t> q;
+    q.swap(c->gq);
+    c->gq_n = 0;
+    BX_HIP(c, hipSetDevice(c->device));
+    if (!c->d_gq) BX_HIP(c, hipMalloc((void**)&c->d_gq, bx_ctx::GQ_MAX * 32));
+    BX_TRY(h2d_staged(c, bx_buf{c->d_gq, 8 * bx_ctx::GQ_MAX}, q.data(), 8 * n));
+    hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)n), dim3(64), 0, c->stream, (const uint4*)c->d_gq);
+    BX_LAUNCH_CHECK(c);
+    q.clear();
+    c->gq.swap(q);  // keep the capacity
+    return nullptr;
+}
+}  // namespace bx
 
 // in-place division of the AoS ext array `arr` (n entries) by (x - z); `scratch` has room for every level's chunk values
 static const char* divide_rec(bx_ctx* c, uint32_t* arr, size_t n, Fp4 z, uint32_t* scratch, uint32_t* rem) {
@@ -830,7 +878,7 @@ static size_t scan_scratch_words(size_t n, size_t L, size_t direct, size_t count
 extern "C" const char* bx_poly_divide(bx_ctx* c, bx_buf poly, const uint32_t z[4], bx_buf rem_out) try {
     if (!c) return "bx_poly_divide: null ctx";
     BX_REQUIRE(c, poly.len % 4 == 0 && rem_out.len >= 4, "poly_divide: poly must be AoS ext, remainder buffer >= 4 words");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t size = poly.len / 4;
     if (!size) return nullptr;
     OpScope op(c, "poly_divide", 8.0 * (double)poly.len);
@@ -864,7 +912,7 @@ extern "C" const char* bx_batch_prefix_products(bx_ctx* c, bx_buf io, size_t cou
     BX_REQUIRE(c, io.len % 4 == 0, "prefix_products: buffer must hold AoS ext elements");
     BX_REQUIRE(c, count >= 1 && (io.len / 4) % count == 0, "prefix_products: the buffer does not split into `count` equal sequences");
     BX_REQUIRE(c, count <= 65535, "prefix_products: too many sequences");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     size_t n = io.len / 4 / count;
     if (n < 2) return nullptr;
     OpScope op(c, "prefix_products", 8.0 * (double)io.len);
@@ -889,7 +937,7 @@ extern "C" const char* bx_prefix_products(bx_ctx* c, bx_buf io) try {
 extern "C" const char* bx_scatter(bx_ctx* c, bx_buf into, bx_buf index, bx_buf offsets, bx_buf values) try {
     if (!c) return "bx_scatter: null ctx";
     BX_REQUIRE(c, offsets.len == values.len, "scatter: offsets and values must have the same length");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (index.len < 2 || offsets.len == 0) return nullptr;
     // asynchronous like every other entry point: range errors are raised on the device and reported by the next
     // blocking call on this ctx (bx_d2h / bx_sync)

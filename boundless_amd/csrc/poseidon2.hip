@@ -515,7 +515,7 @@ extern "C" const char* bx_poseidon2_set_params(bx_ctx* c, const uint32_t* rc213,
     // a prover snapshots the table for its host transcript at create time and bx_verify_segment uses the compiled-in one:
     // changing the device table under a live prover would make its trees and its transcript disagree
     BX_REQUIRE(c, c->live_provers == 0, "poseidon2_set_params: destroy the provers of this ctx first (their transcripts hold the old table)");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     for (int i = 0; i < 213; ++i) c->h_rc[i] = rc213[i] % P;
     for (int i = 0; i < 24; ++i) c->h_diag[i] = diag24[i] % P;
     return poseidon2_upload_params(c);
@@ -534,7 +534,7 @@ extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) try {
     BX_REQUIRE(c, rows > 0 && matrix.len % rows == 0, "hash_rows: matrix.len not a multiple of rows");
     BX_REQUIRE(c, rows <= 0xffffffffu, "hash_rows: too many rows");
     size_t cols = matrix.len / rows;
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
     return launch_hash_rows(c, (uint32_t*)out.dptr, (const uint32_t*)matrix.dptr, rows, cols);
 } BX_ABI_CATCH(c, "bx_hash_rows")
@@ -543,7 +543,7 @@ extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, siz
     if (!c) return "bx_hash_fold: null ctx";
     BX_REQUIRE(c, input_size == 2 * output_size, "hash_fold: input_size must be 2*output_size");
     BX_REQUIRE(c, io.len >= (input_size + 2 * output_size) * 8, "hash_fold: digest buffer too small");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "hash_fold", 96.0 * (double)output_size);
     return launch_hash_fold(c, (uint32_t*)io.dptr, input_size, output_size);
 } BX_ABI_CATCH(c, "bx_hash_fold")
@@ -554,7 +554,7 @@ extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx
     BX_REQUIRE(c, count <= 0xffffffffu && in.len / 8 <= 0xffffffffu, "hash_fold_indexed: too many digests");
     if (count == 0) return nullptr;
     BX_REQUIRE(c, out.dptr && in.dptr && sel.dptr && in.len >= 8, "hash_fold_indexed: null or empty buffer");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "hash_fold_indexed", 104.0 * (double)count);
     hipLaunchKernelGGL(hash_fold_indexed_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
                        (const uint32_t*)in.dptr, (const uint32_t*)sel.dptr, c->d_p2, (uint32_t)count, (uint32_t)(in.len / 8));
@@ -603,7 +603,7 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
     if (!c) return "bx_merkle_build: null ctx";
     BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
     BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     uint32_t* n = (uint32_t*)nodes.dptr;
     {
         OpScope op(c, "hash_rows", 4.0 * (double)matrix.len + 32.0 * (double)rows);
@@ -616,7 +616,7 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
 extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) try {
     if (!c) return "bx_merkle_fold: null ctx";
     BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_fold: nodes must hold 2*rows digests, rows a power of two");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
     return merkle_fold_layers(c, (uint32_t*)nodes.dptr, rows);
 } BX_ABI_CATCH(c, "bx_merkle_fold")
@@ -626,7 +626,7 @@ extern "C" const char* bx_transcript_step(bx_ctx* c, bx_buf state, bx_buf digest
     BX_REQUIRE(c, state.dptr != nullptr && state.len >= 25, "transcript_step: the state is 24 cells and the pool counter");
     BX_REQUIRE(c, digests.len >= 8 * n_commit && out_ext.len >= 4 * n_ext, "transcript_step: digests / out too small");
     BX_REQUIRE(c, n_commit <= 64 && n_ext <= 64, "transcript_step: at most 64 commits and 64 challenges per step");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (!n_commit && !n_ext) return nullptr;
     OpScope op(c, "transcript_step", 4.0 * (double)(50 + 8 * n_commit + 4 * n_ext));
     hipLaunchKernelGGL(transcript_step_kernel, dim3(1), dim3(64), 0, c->stream, (uint32_t*)state.dptr, (const uint32_t*)digests.dptr, (uint32_t)n_commit,

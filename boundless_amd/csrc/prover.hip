@@ -246,7 +246,7 @@ extern "C" const char* bx_merkle_query_gather(bx_ctx* c, bx_buf out, bx_buf matr
     BX_REQUIRE(c, matrix.len == rows * cols && nodes.len == 16 * rows, "merkle_query_gather: matrix/nodes size mismatch");
     unsigned depth = (unsigned)(ilog2(rows) - ilog2(top_size));
     BX_REQUIRE(c, out.len >= n_queries * (cols + 8 * depth) && positions.len >= n_queries, "merkle_query_gather: out/positions too small");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     if (!n_queries) return nullptr;
     OpScope op(c, "merkle_query_gather", 4.0 * (double)(n_queries * (cols + 8 * depth)) * 2.0);
     hipLaunchKernelGGL(merkle_query_gather_kernel, dim3((unsigned)n_queries), dim3(256), 0, c->stream, (uint32_t*)out.dptr,
@@ -269,7 +269,7 @@ extern "C" const char* bx_prover_create_with_circuit(bx_ctx* c, const bx_segment
     BX_REQUIRE(c, shape->w_code >= 1 && shape->w_data >= 1 && shape->w_accum >= 1, "bx_prover_create: every group needs at least one column");
     BX_REQUIRE(c, shape->w_code < 65536 && shape->w_data < 65536 && shape->w_accum < 65536, "bx_prover_create: group width out of range");
 
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     std::unique_ptr<bx_prover> p(new (std::nothrow) bx_prover());
     BX_REQUIRE(c, p != nullptr, "bx_prover_create: out of host memory");
     p->c = c;
@@ -482,7 +482,8 @@ extern "C" const char* bx_prove_submitted(bx_prover* p, uint32_t* seal_out, size
     // the code group's commitment is enqueued first (bx_prove_segment_bytes did that before it even staged the bytes); everything from
     // witgen on waits for the upload's event — on the stream, not on the host
     if (hipSetDevice(p->c->device) != hipSuccess) r = perr(p, "bx_prove_segment: hipSetDevice failed");
-    else if (!p->prologue_done && (r = prove_prologue(p)) != nullptr) {
+    else if (p->c->gq_n && (r = gather_flush(p->c)) != nullptr) {
+    } else if (!p->prologue_done && (r = prove_prologue(p)) != nullptr) {
     } else if (hipStreamWaitEvent(p->c->stream, sl->up, 0) != hipSuccess) r = perr(p, "bx_prove_segment: could not order the proof behind the segment's upload");
     else r = prove_segment_impl(p, *sl, seal_out, seal_cap, seal_words);
     p->prologue_done = false;

@@ -375,7 +375,7 @@ extern "C" const char* bx_poly_divide_batch(bx_ctx* c, bx_buf polys, size_t coun
     BX_REQUIRE(c, count >= 1 && count <= 65535 && polys.len % (4 * count) == 0, "poly_divide_batch: the buffer does not split into `count` AoS ext polynomials");
     BX_REQUIRE(c, zs != nullptr && rems_out.len >= 4 * count, "poly_divide_batch: one point and one remainder slot per polynomial");
     BX_REQUIRE(c, ((uintptr_t)polys.dptr & 15u) == 0 && ((uintptr_t)rems_out.dptr & 15u) == 0, "poly_divide_batch: buffers must be 16-byte aligned");
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     const size_t size = polys.len / 4 / count;
     if (!size) return nullptr;
     OpScope op(c, "poly_divide", 8.0 * (double)polys.len);
@@ -393,7 +393,7 @@ extern "C" const char* bx_poly_divide_batch_indexed(bx_ctx* c, bx_buf polys, siz
         std::sort(seen.begin(), seen.end());
         BX_REQUIRE(c, std::adjacent_find(seen.begin(), seen.end()) == seen.end(), "poly_divide_batch_indexed: a polynomial may be divided once per call");
     }
-    BX_HIP(c, hipSetDevice(c->device));
+    BX_ENTER(c);
     const size_t size = polys.len / 4 / n_polys;
     if (!size || !count) return nullptr;
     OpScope op(c, "poly_divide", 32.0 * (double)size * (double)count);

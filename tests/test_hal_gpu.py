@@ -205,32 +205,6 @@ def test_lde_columns_per_workgroup(hal, oracle, cpw, count):
         hal.set_tunable("ntt_cols_per_wg", 8)
 
 
-@pytest.mark.parametrize("fused", [1, 2, 3])
-@pytest.mark.parametrize("bits,count", [(14, 3), (16, 5), (18, 9), (19, 2), (20, 3), (21, 2), (22, 1)])
-def test_lde_fused_reduction_kernels_are_bit_exact(hal, oracle, fused, bits, count):
-    """Tunable ntt_fused (off by default, ntt_r16.hpp): the forward passes with fused-reduction butterflies — registers hold arbitrary
-    u32 residues, memory holds canonical words — give the oracle's words for every pass-B geometry they cover (2^8 ... 2^12 rows),
-    with either pass or both in that form, for the expanding LDE and for the in-place evaluate; extreme inputs (0, P - 1) included."""
-    hal.set_tunable("ntt_fused", fused)
-    try:
-        n = 1 << bits
-        x = rnd(bits * 10 + fused, n * count)
-        x[:n] = 0
-        x[n:2 * n] = oracle_P - 1
-        out = hal.alloc(4 * n * count)
-        hal.batch_expand_into_evaluate_ntt(out, hal.copy_from(x), count, 2)
-        ref = np.zeros(4 * n * count, np.uint32)
-        oracle.bxo_batch_expand_into_evaluate_ntt(ref, x, count, n, 2)
-        assert np.array_equal(out.view(), ref)
-        io = hal.copy_from(x)
-        hal.batch_evaluate_ntt(io, count, 0)
-        ref2 = x.copy()
-        oracle.bxo_batch_evaluate_ntt(ref2, count, n, 0)
-        assert np.array_equal(io.view(), ref2)
-    finally:
-        hal.set_tunable("ntt_fused", 0)
-
-
 def test_ntt_linearity_full_size(hal):
     n = 1 << 20
     a, b = rnd(1, n), rnd(2, n)
@@ -818,3 +792,50 @@ def test_batch_evaluate_ptrs_over_several_buffers_matches_per_buffer_calls(hal, 
         ref = np.zeros(4, np.uint32)
         oracle.bxo_batch_evaluate_any(np.ascontiguousarray(bufs[k].reshape(-1, size)[col]), size, np.zeros(1, np.uint32), c(xs[4 * e:4 * e + 4]), ref, 1)
         assert np.array_equal(got[e], ref), e
+
+
+@pytest.mark.parametrize("defer", [1, 0])
+def test_gather_sample_queue_keeps_the_stream_order_the_caller_sees(hal, defer):
+    """bx_gather_sample queues small gathers and launches them together (ctx.hpp: ~5 000 openings per proof driven through the plain
+    trait calls).  Whatever could observe the difference must not: chains of gathers through the same memory, a source overwritten
+    after it was gathered from, a destination read back at once, more gathers than the queue holds, and the un-queued path."""
+    hal.set_tunable("gather_defer", defer)
+    try:
+        rows, cols = 1 << 10, 24
+        m = rnd(910, rows * cols)
+        mat = hal.copy_from(m)
+        # 1. many independent gathers (rows of a column-major matrix), one read-back
+        out = hal.alloc(cols * 300)
+        pos = np.random.default_rng(5).integers(0, rows, 300)
+        for q, r in enumerate(pos):
+            hal.gather_sample(out.slice(q * cols, cols), mat, int(r), cols, rows)
+        assert np.array_equal(out.view().reshape(300, cols), m.reshape(cols, rows)[:, pos].T)
+        # 2. a chain: B <- gather(A), C <- gather(B), A <- gather(C)   (each reads what the previous one wrote)
+        a = hal.copy_from(np.arange(64, dtype=np.uint32))
+        b, c2 = hal.alloc_zeroed(32), hal.alloc_zeroed(16)
+        hal.gather_sample(b, a, 1, 32, 2)      # b[i] = a[1 + 2i] = 1 + 2i
+        hal.gather_sample(c2, b, 0, 16, 2)     # c[i] = b[2i] = 1 + 4i
+        hal.gather_sample(a.slice(0, 16), c2, 0, 16, 1)  # a[0..16) = c
+        assert np.array_equal(a.view()[:16], 1 + 4 * np.arange(16, dtype=np.uint32))
+        assert np.array_equal(b.view(), 1 + 2 * np.arange(32, dtype=np.uint32))
+        # 3. the source is overwritten AFTER the gather was issued: the gather saw the old words
+        src = hal.copy_from(np.full(128, 7, np.uint32))
+        dst = hal.alloc_zeroed(128)
+        hal.gather_sample(dst, src, 0, 128, 1)
+        src.copy_from(np.full(128, 9, np.uint32))
+        assert np.all(dst.view() == 7) and np.all(src.view() == 9)
+        # 4. a destination that a later NON-gather call reads: eltwise_copy of the gathered words
+        g1, g2 = hal.alloc_zeroed(cols), hal.alloc_zeroed(cols)
+        hal.gather_sample(g1, mat, 3, cols, rows)
+        hal.eltwise_copy_elem(g2, g1)
+        assert np.array_equal(g2.view(), m.reshape(cols, rows)[:, 3])
+        # 5. more gathers than the queue holds (8192), 8 words each like the path digests of an opening
+        nodes = rnd(911, 8 * 4096)
+        nb = hal.copy_from(nodes)
+        big = hal.alloc(8 * 9000)
+        idx = np.random.default_rng(6).integers(0, 4096, 9000)
+        for q, i in enumerate(idx):
+            hal.gather_sample(big.slice(8 * q, 8), nb, 8 * int(i), 8, 1)
+        assert np.array_equal(big.view().reshape(9000, 8), nodes.reshape(4096, 8)[idx])
+    finally:
+        hal.set_tunable("gather_defer", 1)

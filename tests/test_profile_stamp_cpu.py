@@ -29,7 +29,7 @@ def test_device_code_stamp_ignores_host_only_edits(tmp_path):
     base = _compile(tree, obj)
     assert base == _compile(tree, obj), "the device code object is not reproducible"
 
-    # 0. the same sources in another directory give the same code object (hipcc's path-derived cuid is switched off in build.FLAGS)
+    # 0. the same sources in another directory give the same code object (hipcc's path-derived cuid is replaced by -cuid=<file name>, passed per translation unit by build.cuid_flag)
     tree2 = str(tmp_path / "elsewhere" / "deeper" / "tree")
     shutil.copytree(tree, tree2)
     assert _compile(tree2, str(tmp_path / "circuit2.o")) == base, "the device-code stamp depends on the build directory"
