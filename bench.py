@@ -61,7 +61,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r05"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
+PROFILE_ROUND = "r06"  # committed PMC summaries this line refers to (profiles/<round>_*.json); falls back to r01's
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU issue model used throughout (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 units; measured in profiles/r01_microbench2_instr_cost.jsonl):
 # a wave64 instruction of the cheap integer class issues in 2 cycles per SIMD, one of the multiply class (v_mul_lo/hi_u32, v_mad_u64_u32,
@@ -74,7 +74,7 @@ _replayed = {}  # profile file -> device-code stamp it was collected on (None wh
 
 def _profile(name):
     """profiles/<PROFILE_ROUND>_<name>, or an earlier round's file while this round's has not been collected yet"""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(p):
             return p
@@ -176,6 +176,32 @@ def plain_hal_probe(args, sv, product_ms):
         ext[name] = r
     out["with_one_extension"] = ext
     out["with_all_extensions"] = timed(plain_hal.EXT_ALL)
+    # throughput of the trait-level path with three provers in flight (three drivers, three ctxs, three host threads — what a Rust
+    # process holding three `HipHal` objects could do; the reference's agent holds one, bento/crates/workflow/src/lib.rs:192)
+    import threading
+
+    lanes, per_lane = 3, 4
+    pps = [plain_hal.PlainHalProver(sv.hal.device, po2=args.po2, widths=tuple(int(x) for x in args.widths.split(",")), terms=args.terms,
+                                    degree=args.degree, flags=0) for _ in range(lanes)]
+    try:
+        for pp in pps:
+            pp.prove(seg.seed)  # warm
+        ok = [True] * lanes
+
+        def work(k):
+            for j in range(per_lane):
+                seal, _ = pps[k].prove(seg.seed)
+                ok[k] = ok[k] and bool(np.array_equal(seal, want))
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+        t0 = time.perf_counter()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        out["three_in_flight"] = {"proofs_per_s": round(lanes * per_lane / dt, 3), "proofs": lanes * per_lane, "seals_equal": all(ok)}
+    finally:
+        for pp in pps:
+            pp.close()
     out["note"] = ("one lone proof through the section-8(b2) entry points only, sequenced outside the library with its own host transcript; "
                    "with_one_extension = the same with that extension entry point replacing its plain call sequence; every device buffer but "
                    "`combos` (bx_alloc_zeroed per proof) is allocated up front, which risc0-zkp's prover does not do")
@@ -950,6 +976,14 @@ def main():
             return r
 
         roofline_in_region = ntt_roofline(kernels, "timed region, %d segments in flight" % len(servers))
+        if len(servers) > 1:
+            # HIP-event wall times of ONE lane while the other lanes share the GPU: a kernel's events also span the other lanes' kernels
+            # that the hardware ran in between, so these are not kernel durations and GB/s figures derived from them mean nothing
+            # (VERDICT r05 weak #10).  The kernel's own figures are `roofline` / `kernels_isolated`.
+            for k_ in ("achieved", "frac", "avg_ms_per_launch", "achieved_bytes_per_launch", "traffic_over_algorithmic"):
+                roofline_in_region[k_ + "_under_time_slicing"] = roofline_in_region.pop(k_)
+            kernels = {name: {"calls_per_step": v["calls_per_step"], "wall_ms_under_time_slicing": v["avg_ms"],
+                              "wall_ms_per_segment_under_time_slicing": v["ms_per_segment"]} for name, v in kernels.items()}
         roofline = ntt_valu_view(ntt_roofline(iso_k, "isolated probe: one extra segment proved alone after the timed region")) if iso_k else roofline_in_region
         # dominance is judged on the isolated durations (in-region ones are stretched by stream sharing)
         dom_src = iso_k if iso_k else kernels
@@ -1040,11 +1074,12 @@ def main():
             "roofline_in_region": roofline_in_region,
             "roofline_dominant": dominant,
             "roofline_job": job_valu_view(proved_total / elapsed / max(world, 1)),
+            "kernels_isolated": iso_k,
             "kernels": kernels,
             "live_profile": {"lanes_with_hip_events": len(live), "lanes": len(servers), "segments_profiled": proved_live,
                              "note": "per-entry-point HIP events bracket ONE lane per rank in the timed region (every lane: -0.9 % on the rate, "
-                                     "profiles/r03_ab_live_profile.jsonl); `kernels` and `roofline_in_region` are that lane's figures"},
-            "kernels_isolated": iso_k,
+                                     "profiles/r03_ab_live_profile.jsonl); `kernels` and `roofline_in_region` are that lane's WALL times while the "
+                                     "other lanes share the GPU (not kernel durations); `kernels_isolated` / `roofline` are one segment alone"},
             "replayed_profiles": replayed_profiles(),
         }
         if world == 1 and not args.no_pcie_extra and not args.segment_bytes and args.po2 >= 18:
