@@ -1879,6 +1879,17 @@ const char* bx_agent_create(const bx_agent_config* cfg, const bx_hot_store_ops* 
             delete a;
             return "bx_agent_create: po2_min / po2_max must satisfy 9 <= po2_min <= po2_max <= 24";
         }
+        // widths x the largest accepted size, checked here instead of at the first oversized task: bx_prover_create takes widths below
+        // 65536 (16-bit tap bookkeeping), and ONE buffer set of a lane — (w + 16) columns x 2^po2_max rows x (1 coefficient + 4
+        // evaluation words) — must at least fit the 288 GB of one MI355X
+        if (!prover && !a->cfg.no_prover && (a->cfg.w_code >= 65536 || a->cfg.w_data >= 65536 || a->cfg.w_accum >= 65536)) {
+            delete a;
+            return "bx_agent_create: group widths must be below 65536";
+        }
+        if (!prover && !a->cfg.no_prover && (((uint64_t)a->cfg.w_code + a->cfg.w_data + a->cfg.w_accum + 16u) * 20u << a->cfg.po2_max) > (288ull << 30)) {
+            delete a;
+            return "bx_agent_create: the group widths at po2_max need more than the 288 GB of one GPU for a single buffer set: lower po2_max or the widths";
+        }
         if (!a->cfg.max_shapes) a->cfg.max_shapes = 2;
         if (a->cfg.lift_po2 && (a->cfg.lift_po2 < 9 || a->cfg.lift_po2 > 24)) {
             delete a;

@@ -114,3 +114,14 @@ def test_native_agent_fails_loudly_without_gpu(libpath):
 
     with pytest.raises(HalError, match="bx_agent_create"):
         ag.Agent(prover=None)
+
+
+def test_native_agent_validates_widths_against_po2_max_at_create(libpath):
+    """a configuration whose buffers cannot exist is refused by bx_agent_create, not by the first oversized task."""
+    from boundless_amd import agent as ag
+    from boundless_amd.hal import HalError
+
+    with pytest.raises(HalError, match="group widths must be below 65536"):
+        ag.Agent(prover=None, widths=(16, 70000, 64))
+    with pytest.raises(HalError, match="more than the 288 GB of one GPU"):
+        ag.Agent(prover=None, widths=(16, 4096, 64), po2_range=(9, 24))

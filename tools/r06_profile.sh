@@ -5,7 +5,7 @@
 set -u
 O=gpurun_out/r6p; mkdir -p $O
 export TMPDIR=/tmp
-B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra"
+B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra --no-plain-hal"
 # 1. per-kernel time: the default command (3 segments in flight) and one segment in flight
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -o kt -- $B --no-live-profile > $O/bench_kt3.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -o kt -- $B --inflight 1 --no-live-profile > $O/bench_kt1.json 2>/dev/null
@@ -20,7 +20,7 @@ done
 python tools/pmc_traffic.py "$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $O/r06_bench_pmc_traffic.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # 3. VALU instructions of the whole job, per segment (the tool counts the proofs of the run by their eval_check launches)
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra --no-plain-hal > /dev/null 2>&1
 python tools/job_valu.py "$(find $O/pmc_valu -name '*counter_collection.csv' | head -1)" auto $O/r06_job_valu_insts.json
 rm -rf $O/pmc_valu
 # 4. the stall side of the two LDE kernels, bench.py with one segment in flight (VERDICT r04 item 2 ii): separate passes of <= 8 SQ counters
@@ -42,14 +42,15 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1 --master-port 29652 bench.py --gpus 8 --dist-backend gloo --device 0 --inflight 1 --job 64 2>/dev/null | grep '^{' | tail -1 > $O/r06_ws8_gloo_1gpu_job64.json
 # 6. the trait-level proof (tests/plain_hal_prover.c) beside bx_prove_segment, one extension at a time, three in flight
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-agent-mode --no-pcie-extra 2>/dev/null | tail -1 > $O/b_plain.json
-python - <<PY
-import json
-j = json.load(open("$O/b_plain.json"))
-out = {"what": "single_proof_ms of `python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-agent-mode --no-pcie-extra` (untimed extra, rank 0): one lone 2^20 / 16-256-64 "
+O=$O python - <<'PY'
+import json, os
+O = os.environ["O"]
+j = json.load(open(O + "/b_plain.json"))
+out = {"what": "single_proof_ms of python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-agent-mode --no-pcie-extra (untimed extra, rank 0): one lone 2^20 / 16-256-64 "
                "proof by bx_prove_segment (min/median/spin_wait) and by tests/plain_hal_prover.c - the plain Hal entry points of SURVEY 8(b2) only, sequenced "
                "outside the library - then with ONE extension entry point swapped in at a time, and three such drivers in flight",
        "device_code_sha": j["replayed_profiles"]["device_code_sha"], "value_proofs_per_s": j["value"], "single_proof_ms": j["single_proof_ms"]}
-json.dump(out, open("$O/r06_plain_hal.json", "w"), indent=1)
+json.dump(out, open(O + "/r06_plain_hal.json", "w"), indent=1)
 PY
 BX_TUNABLES=gather_defer=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra 2>/dev/null | tail -1 | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); p=j['single_proof_ms']['plain_hal']; print(json.dumps({'gather_defer': 0, 'plain_hal_min_ms': p['min'], 'calls': p['calls'], 'three_in_flight': p.get('three_in_flight'), 'bx_prove_segment_min_ms': j['single_proof_ms']['min']}))" > $O/r06_plain_hal_gather_defer0.json
