@@ -125,3 +125,29 @@ def test_native_agent_validates_widths_against_po2_max_at_create(libpath):
         ag.Agent(prover=None, widths=(16, 70000, 64))
     with pytest.raises(HalError, match="more than the 288 GB of one GPU"):
         ag.Agent(prover=None, widths=(16, 4096, 64), po2_range=(9, 24))
+
+
+def test_plain_hal_driver_is_plain_c_on_the_declared_abi(libpath):
+    """tests/plain_hal_prover.c (the trait-level driver of tests/test_plain_hal_gpu.py and of bench.py's single_proof_ms.plain_hal)
+    compiles as pedantic C99 against include/*.h alone, links against the library, exports its six entry points, and references
+    nothing of the library but declared bx_* symbols — in particular not bx_prove_segment, the in-library prover it is compared with,
+    and nothing of oracle/."""
+    import subprocess
+    import sys
+
+    src = os.path.join(ROOT, "tests", "plain_hal_prover.c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", f"-I{os.path.join(ROOT, 'include')}", src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import plain_hal
+
+    so = plain_hal.build()
+    out = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert {"ph_create", "ph_prove", "ph_destroy", "ph_seal_words", "ph_last_calls", "ph_error"} <= defined
+    used = {ln.split()[-1] for ln in out.splitlines() if " U " in ln and ln.split()[-1].startswith("bx")}
+    assert used and used <= set(declared_symbols())
+    assert not any(s.startswith("bx_prove") or s.startswith("bx_prover_") or s.startswith("bxo_") for s in used), used
+    text = open(src).read()
+    assert "oracle" not in text.split("*/", 1)[1]  # the header comment says it does not use oracle/; the code must not either
