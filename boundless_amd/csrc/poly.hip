@@ -805,7 +805,8 @@ extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_
     // Small gathers are queued and launched together by the next call that touches the ctx (ctx.hpp, "Deferred ... gather_sample"):
     // the openings of a proof are ~5 000 of them.  Stream order as the caller sees it is kept: anything that could observe the
     // difference flushes the queue first, and so does a gather that touches memory a queued one writes.
-    if (c->gather_defer && !c->profile && trace_level() == 0 && size <= 4096 && stride <= 0xffffffffu) {
+    // (not on an adopted stream, bx_set_stream: its owner enqueues work of its own there without going through this library)
+    if (c->gather_defer && c->stream == c->own_stream && !c->profile && trace_level() == 0 && size <= 4096 && stride <= 0xffffffffu) {
         const uintptr_t d0 = (uintptr_t)dst.dptr, d1 = d0 + 4 * size;
         const uintptr_t s0 = (uintptr_t)((const uint32_t*)src.dptr + idx), s1 = s0 + 4 * ((size - 1) * stride + 1);
         if (c->gq_n && ((s0 < c->gq_dst_hi && c->gq_dst_lo < s1) || (d0 < c->gq_dst_hi && c->gq_dst_lo < d1) || (d0 < c->gq_src_hi && c->gq_src_lo < d1)))

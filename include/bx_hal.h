@@ -162,7 +162,9 @@ const char* bx_eltwise_mul_factor(bx_ctx* ctx, bx_buf io, uint32_t factor_mont);
 /* Hal::gather_sample(dst, src, idx, size, stride): dst[i] = src[idx + i*stride].  MerkleTreeProver::prove issues thousands of these
  * per proof (one per opened row, one per path digest), so a small gather is QUEUED and the queue is launched as one kernel by the
  * next call of any kind on the ctx (or bx_get_stream): stream order as the caller observes it is unchanged, the ~3.7 us of launch
- * cost per gather is paid once per batch.  Tunable "gather_defer" = 0 launches each gather at once. */
+ * cost per gather is paid once per batch.  Tunable "gather_defer" = 0 launches each gather at once; so does a ctx that runs on
+ * an adopted stream (bx_set_stream), whose owner enqueues work there that this library does not see.  Work a caller enqueues
+ * directly on the ctx's OWN stream must fetch it with bx_get_stream each time (which flushes), not from an earlier call. */
 const char* bx_gather_sample(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride);
 /* Hal::prefix_products(io): io[i] = io[i] * io[i-1] over AoS ext elements (inclusive running product; the circuit's
  * accumulate step uses it for its grand products). */

@@ -660,6 +660,11 @@ def test_torch_memory_and_stream_interop(hal, oracle):
             hal.batch_interpolate_ntt(a, cols)
             hal.zk_shift(a, cols)
             hal.batch_expand_into_evaluate_ntt(b, a, cols, 2)
+            # a gather followed by torch's own work on the adopted stream: the library must not hold the gather back in its queue
+            # (it cannot see what the stream's owner enqueues), so torch reads the gathered words
+            t_row = torch.zeros(cols, dtype=torch.int32, device="cuda")
+            hal.gather_sample(hal.wrap(t_row.data_ptr(), cols), b, 5, cols, 4 * n)
+            t_copy = t_row.clone()  # enqueued by torch on the same stream, without passing through the library
         finally:
             stream.synchronize()
             hal.set_stream(None)
@@ -669,6 +674,7 @@ def test_torch_memory_and_stream_interop(hal, oracle):
     ref_out = np.zeros(4 * n * cols, np.uint32)
     oracle.bxo_batch_expand_into_evaluate_ntt(ref_out, ref, cols, n, 2)
     assert np.array_equal(t_out.cpu().numpy().view(np.uint32), ref_out)
+    assert np.array_equal(t_copy.cpu().numpy().view(np.uint32), ref_out.reshape(cols, 4 * n)[:, 5])
 
 
 # ------------------------------------------------------------------ degenerate inputs
