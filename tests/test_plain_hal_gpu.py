@@ -114,3 +114,31 @@ def test_plain_hal_seal_at_the_baseline_config():
     bad = np.nonzero(seal != want)[0]
     assert bad.size == 0, f"{bad.size} differing seal words vs the oracle, first at {bad[:5]}"
     print(f"plain-Hal proof at 2^20: {ms:.1f} ms cold, {ms2:.1f} ms warm, {calls} entry-point calls")
+
+
+def test_three_plain_hal_drivers_in_flight_stay_bit_exact():
+    """Three trait-level drivers (three ctxs, three host threads — what a process holding three `HipHal` objects does) prove
+    different segments concurrently, each with its own queue of deferred gathers: every seal is the oracle's."""
+    import threading
+
+    import plain_hal
+
+    po2, widths = 12, (4, 12, 4)
+    drivers = [plain_hal.PlainHalProver(0, po2=po2, widths=widths) for _ in range(3)]
+    got = {}
+
+    def work(k):
+        for j in range(4):
+            seed = 1000 + 4 * k + j
+            got[seed] = drivers[k].prove(seed)[0]
+
+    try:
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    finally:
+        for d in drivers:
+            d.close()
+    assert sorted(got) == list(range(1000, 1012))
+    for seed, seal in got.items():
+        assert np.array_equal(seal, ol.prove_segment(po2, *widths, seed)[0]), seed
