@@ -54,6 +54,13 @@ json.dump(out, open(O + "/r06_plain_hal.json", "w"), indent=1)
 PY
 BX_TUNABLES=gather_defer=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-agent-mode --no-pcie-extra 2>/dev/null | tail -1 | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); p=j['single_proof_ms']['plain_hal']; print(json.dumps({'gather_defer': 0, 'plain_hal_min_ms': p['min'], 'calls': p['calls'], 'three_in_flight': p.get('three_in_flight'), 'bx_prove_segment_min_ms': j['single_proof_ms']['min']}))" > $O/r06_plain_hal_gather_defer0.json
+# 6b. rocprofv3 per-kernel summary of the trait-level proof, gather_sample queue on / off (7 gather_batch_kernel launches per proof against 5 100 gather_sample_kernel launches)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -o kt -- python tools/plain_hal_run.py 5 > $O/run_defer1.txt 2>/dev/null
+BX_TUNABLES=gather_defer=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -o kt -- python tools/plain_hal_run.py 5 > $O/run_defer0.txt 2>/dev/null
+cp "$(find $O/kt1 -name '*kernel_stats.csv' | head -1)" $O/r06_plain_hal_kernel_stats.csv
+cp "$(find $O/kt0 -name '*kernel_stats.csv' | head -1)" $O/r06_plain_hal_kernel_stats_gather_defer0.csv
+rm -rf $O/kt1 $O/kt0
+cat $O/run_defer1.txt $O/run_defer0.txt; grep -i "gather" $O/r06_plain_hal_kernel_stats.csv $O/r06_plain_hal_kernel_stats_gather_defer0.csv | cut -c1-220
 # inflight sweep
 for l in 1 2 3 4; do python bench.py --steps 8 --warmup 3 --inflight $l --no-cpu-baseline --no-agent-mode --no-pcie-extra --no-plain-hal 2>/dev/null | tail -1 | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); print(json.dumps({'inflight': $l, 'value': round(j['value'],3), 'ms_per_step': j['ms_per_step'], 'single_proof_ms': j['single_proof_ms']['min']}))"; done > $O/r06_inflight_sweep.jsonl
