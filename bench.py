@@ -155,9 +155,23 @@ def plain_hal_probe(args, sv, product_ms):
     seg = Segment.synthetic(index=4 * 10**6, po2=args.po2)
     want = sv.prove_segment(seg).seal
 
-    def timed(flags):
-        pp = plain_hal.PlainHalProver(sv.hal.device, po2=args.po2, widths=tuple(int(x) for x in args.widths.split(",")),
-                                      terms=args.terms, degree=args.degree, flags=flags)
+    def make(flags, tunables=None):
+        """a driver (its own ctx); `tunables` = BX_TUNABLES for that ctx alone (read by bx_init)"""
+        old = os.environ.get("BX_TUNABLES")
+        if tunables:
+            os.environ["BX_TUNABLES"] = (old + "," if old else "") + tunables
+        try:
+            return plain_hal.PlainHalProver(sv.hal.device, po2=args.po2, widths=tuple(int(x) for x in args.widths.split(",")),
+                                            terms=args.terms, degree=args.degree, flags=flags)
+        finally:
+            if tunables:
+                if old is None:
+                    del os.environ["BX_TUNABLES"]
+                else:
+                    os.environ["BX_TUNABLES"] = old
+
+    def timed(flags, tunables=None):
+        pp = make(flags, tunables)
         try:
             ts, equal = [], True
             for _ in range(4):
@@ -182,27 +196,37 @@ def plain_hal_probe(args, sv, product_ms):
     import threading
 
     lanes, per_lane = 3, 4
-    pps = [plain_hal.PlainHalProver(sv.hal.device, po2=args.po2, widths=tuple(int(x) for x in args.widths.split(",")), terms=args.terms,
-                                    degree=args.degree, flags=0) for _ in range(lanes)]
-    try:
-        for pp in pps:
-            pp.prove(seg.seed)  # warm
-        ok = [True] * lanes
 
-        def work(k):
-            for j in range(per_lane):
-                seal, _ = pps[k].prove(seg.seed)
-                ok[k] = ok[k] and bool(np.array_equal(seal, want))
+    def in_flight(flags, tunables=None):
+        pps = [make(flags, tunables) for _ in range(lanes)]
+        try:
+            for pp in pps:
+                pp.prove(seg.seed)  # warm
+            ok = [True] * lanes
 
-        ts = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
-        t0 = time.perf_counter()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        dt = time.perf_counter() - t0
-        out["three_in_flight"] = {"proofs_per_s": round(lanes * per_lane / dt, 3), "proofs": lanes * per_lane, "seals_equal": all(ok)}
-    finally:
-        for pp in pps:
-            pp.close()
+            def work(k):
+                for j in range(per_lane):
+                    seal, _ = pps[k].prove(seg.seed)
+                    ok[k] = ok[k] and bool(np.array_equal(seal, want))
+
+            ts = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+            t0 = time.perf_counter()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            dt = time.perf_counter() - t0
+            return {"proofs_per_s": round(lanes * per_lane / dt, 3), "proofs": lanes * per_lane, "seals_equal": all(ok)}
+        finally:
+            for pp in pps:
+                pp.close()
+
+    out["three_in_flight"] = in_flight(0)
+    # risc0-zkp's prover allocates its buffers inside every proof (hal.alloc_* in commit_group / finalize / fri_prove) and drops them
+    # at its end: the same proof with the ~9 GB of big buffers allocated and released inside the timed call — through the library's
+    # per-ctx pool (default), and with the pool off (alloc_cache_mb = 0: hipMalloc / stream wait + hipFree, and hipFree drains the
+    # whole device, the other lanes' streams included)
+    app = plain_hal.ALLOC_PER_PROOF
+    out["alloc_per_proof"] = {"pooled": timed(app), "hipMalloc_hipFree": timed(app, "alloc_cache_mb=0"),
+                              "three_in_flight_pooled": in_flight(app), "three_in_flight_hipMalloc_hipFree": in_flight(app, "alloc_cache_mb=0")}
     out["note"] = ("one lone proof through the section-8(b2) entry points only, sequenced outside the library with its own host transcript; "
                    "with_one_extension = the same with that extension entry point replacing its plain call sequence; every device buffer but "
                    "`combos` (bx_alloc_zeroed per proof) is allocated up front, which risc0-zkp's prover does not do")

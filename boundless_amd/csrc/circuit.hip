@@ -383,12 +383,12 @@ const char* synth_create(void*, bx_ctx* c, const bx_segment_params* shape, void*
     const Circuit& cc = st->cc;
     const size_t n = (size_t)1 << cc.po2;
     const char* e = nullptr;
-    if (!e) e = bx_alloc(c, 8 * (cc.constraints() + 1), &st->mixpows);  // canonical table + centred copy
-    if (!e) e = bx_alloc(c, n * (cc.pairs ? cc.pairs : 1), &st->perm_offsets);
-    if (!e) e = bx_alloc(c, n + 1, &st->perm_index);
-    if (!e) e = bx_alloc(c, n * (cc.E ? cc.E : 1), &st->acc_src);
-    if (!e) e = bx_alloc(c, 4 * n * (cc.E ? cc.E : 1), &st->acc_run);
-    if (!e) e = bx_alloc(c, 4 * (cc.E ? cc.E : 1), &st->betas);
+    if (!e) e = raw_alloc(c, 8 * (cc.constraints() + 1), &st->mixpows);  // canonical table + centred copy
+    if (!e) e = raw_alloc(c, n * (cc.pairs ? cc.pairs : 1), &st->perm_offsets);
+    if (!e) e = raw_alloc(c, n + 1, &st->perm_index);
+    if (!e) e = raw_alloc(c, n * (cc.E ? cc.E : 1), &st->acc_src);
+    if (!e) e = raw_alloc(c, 4 * n * (cc.E ? cc.E : 1), &st->acc_run);
+    if (!e) e = raw_alloc(c, 4 * (cc.E ? cc.E : 1), &st->betas);
     if (!e) e = circuit_perm_tables(c, cc, st->perm_offsets, st->perm_index);
     if (e) {
         synth_destroy(nullptr, st);

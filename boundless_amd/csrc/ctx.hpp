@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,17 @@ struct bx_ctx {
     uintptr_t gq_dst_lo = 0, gq_dst_hi = 0, gq_src_lo = 0, gq_src_hi = 0;  // bounding intervals of what the queue writes / reads
     long gather_defer = 1;
     static constexpr size_t GQ_MAX = 8192;
+
+    // bx_alloc / bx_release pool (hal.hip).  risc0-zkp's prover allocates every buffer inside a proof (hal.alloc_* in commit_group,
+    // finalize, fri_prove: ~9 GB in ~45 buffers at 2^20 / 16-256-64) and drops them at its end; raw hipMalloc / hipFree cost
+    // milliseconds per GB-sized block and hipFree drains the WHOLE device, every other lane's stream included.  A released block
+    // therefore goes to a per-ctx free list and the next request of about that size takes it back: no driver call, no wait —
+    // every use of the memory, old and new, is ordered on the ctx's one stream.  Capped by the tunable alloc_cache_mb (0 = off:
+    // hipMalloc / stream wait + hipFree as before); an allocation that fails empties the list and retries.
+    std::multimap<size_t, void*> pool_free;        // capacity in bytes -> block
+    std::unordered_map<void*, size_t> pool_live;   // blocks handed out by bx_alloc, with their capacity
+    size_t pool_cached = 0;
+    long alloc_cache_mb = 16384;
 
     // scratch (grown on demand)
     uint32_t* d_scratch = nullptr;
@@ -239,6 +251,7 @@ struct OpScope {
 
 // internal launchers shared between translation units (each returns NULL or an error string)
 const char* ensure_scratch(bx_ctx* c, size_t words);
+const char* raw_alloc(bx_ctx* c, size_t words, bx_buf* out);  // hal.hip: plain hipMalloc for the library's own long-lived buffers (not pooled)
 const char* gather_flush(bx_ctx* c);  // poly.hip: launch the queued gather_sample descriptors (no-op when the queue is empty)
 constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
 constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;

@@ -308,6 +308,7 @@ extern "C" const char* bx_free(bx_ctx* c) try {
     if (c->d_p2) (void)hipFree(c->d_p2);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_gq) (void)hipFree(c->d_gq);
+    for (auto& kv : c->pool_free) (void)hipFree(kv.second);
     for (int b = 0; b < 2; ++b)
         if (c->d_scan[b]) (void)hipFree(c->d_scan[b]);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
@@ -346,12 +347,61 @@ extern "C" void* bx_get_stream(bx_ctx* c) {
     return c ? (void*)c->stream : nullptr;
 }
 
+namespace bx {
+// the library's own long-lived buffers (a prover's buffer set, the circuit's tables): straight from the driver, freed with hipFree
+const char* raw_alloc(bx_ctx* c, size_t words, bx_buf* out) {
+    BX_REQUIRE(c, out != nullptr, "raw_alloc: null out");
+    BX_HIP(c, hipSetDevice(c->device));
+    void* p = nullptr;
+    BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
+    out->dptr = p;
+    out->len = words;
+    return nullptr;
+}
+// ---- bx_alloc / bx_release pool (ctx.hpp) ----
+static size_t pool_round(size_t bytes) {  // 256 B granules for small blocks, 2 MiB for large ones (so that nearby sizes match)
+    const size_t g = bytes <= ((size_t)1 << 20) ? 256 : ((size_t)2 << 20);
+    return (bytes + g - 1) / g * g;
+}
+static void pool_trim(bx_ctx* c) {  // give every cached block back to the driver (the stream is drained first: hipFree would do it anyway)
+    if (c->pool_free.empty()) return;
+    (void)stream_wait(c);
+    for (auto& kv : c->pool_free) (void)hipFree(kv.second);
+    c->pool_free.clear();
+    c->pool_cached = 0;
+}
+static const char* pool_alloc(bx_ctx* c, size_t words, void** out) {
+    const size_t bytes = pool_round((words ? words : 1) * 4);
+    if (c->alloc_cache_mb > 0) {
+        auto it = c->pool_free.lower_bound(bytes);
+        if (it != c->pool_free.end() && it->first <= bytes + bytes / 8) {  // at most 12.5 % larger than asked for
+            *out = it->second;
+            c->pool_cached -= it->first;
+            c->pool_live[*out] = it->first;
+            c->pool_free.erase(it);
+            return nullptr;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && !c->pool_free.empty()) {  // out of memory with blocks idling in the list: release them and try again
+        (void)hipGetLastError();
+        pool_trim(c);
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) return set_err(c, "hipMalloc", e, __FILE__, __LINE__);
+    c->pool_live[p] = bytes;
+    *out = p;
+    return nullptr;
+}
+}  // namespace bx
+
 extern "C" const char* bx_alloc(bx_ctx* c, size_t words, bx_buf* out) try {
     if (!c) return "bx_alloc: null ctx";
     BX_REQUIRE(c, out != nullptr, "bx_alloc: null out");
     BX_ENTER(c);
     void* p = nullptr;
-    BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
+    BX_TRY(pool_alloc(c, words, &p));
     out->dptr = p;
     out->len = words;
     return nullptr;
@@ -361,19 +411,32 @@ extern "C" const char* bx_alloc_zeroed(bx_ctx* c, size_t words, bx_buf* out) try
     BX_REQUIRE(c, out != nullptr, "bx_alloc_zeroed: null out");
     BX_ENTER(c);
     void* p = nullptr;
-    BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
-    if (hipMemsetAsync(p, 0, (words ? words : 1) * 4, c->stream) != hipSuccess) {
-        (void)hipFree(p);
-        return set_msg(c, "bx_alloc_zeroed: clearing the allocation failed");
-    }
+    BX_TRY(pool_alloc(c, words, &p));
     out->dptr = p;
     out->len = words;
+    if (hipMemsetAsync(p, 0, (words ? words : 1) * 4, c->stream) != hipSuccess) {
+        (void)bx_release(c, *out);
+        out->dptr = nullptr;
+        return set_msg(c, "bx_alloc_zeroed: clearing the allocation failed");
+    }
     return nullptr;
 } BX_ABI_CATCH(c, "bx_alloc_zeroed")
 extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;
     BX_ENTER(c);
+    auto it = c->pool_live.find(b.dptr);
+    if (it != c->pool_live.end()) {
+        const size_t cap = it->second;
+        c->pool_live.erase(it);
+        // keep it for the next request of that size: whoever gets it uses it on this ctx's stream, behind everything enqueued so far.
+        // (Not on an adopted stream: its owner may still be using the memory in work this library has not seen.)
+        if (c->alloc_cache_mb > 0 && c->stream == c->own_stream && c->pool_cached + cap <= ((size_t)c->alloc_cache_mb << 20)) {
+            c->pool_free.emplace(cap, b.dptr);
+            c->pool_cached += cap;
+            return nullptr;
+        }
+    }
     BX_HIP(c, stream_wait(c));
     BX_HIP(c, hipFree(b.dptr));
     return nullptr;
@@ -486,6 +549,11 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
         c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
+    } else if (!strcmp(name, "alloc_cache_mb")) {
+        BX_REQUIRE(c, value >= 0 && value <= (288 << 10), "alloc_cache_mb out of range [0, 294912]");
+        BX_ENTER(c);
+        c->alloc_cache_mb = value;
+        while (!c->pool_free.empty() && c->pool_cached > ((size_t)value << 20)) pool_trim(c);  // a lower cap takes effect at once
     } else if (!strcmp(name, "gather_defer")) {
         BX_ENTER(c);
         c->gather_defer = value != 0;

@@ -60,7 +60,7 @@ struct DevBuf {  // owning device allocation; movable, not copyable
     }
     const char* alloc(bx_ctx* ctx, size_t words) {
         c = ctx;
-        return bx_alloc(ctx, words, &b);
+        return raw_alloc(ctx, words, &b);  // long-lived (the prover's lifetime), freed with hipFree in the destructor: not pooled
     }
     ~DevBuf() {
         if (b.dptr) (void)hipFree(b.dptr);

@@ -65,12 +65,20 @@ const char* bx_free(bx_ctx* ctx);
 const char* bx_device_name(bx_ctx* ctx, char* out, size_t cap);
 const char* bx_set_stream(bx_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (NULL = own stream) */
 void* bx_get_stream(bx_ctx* ctx);
-const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out); /* contents undefined */
+/* Hal::alloc_*: contents undefined.  bx_alloc / bx_release go through a per-ctx POOL: a released block is kept (up to the tunable
+ * "alloc_cache_mb", default 16384; 0 = off) and handed to the next request of about its size — no driver call and no wait, every use
+ * of the memory being ordered on the ctx's one stream.  risc0-zkp's prover allocates every buffer inside a proof and drops it at
+ * the end; with raw hipMalloc / hipFree that costs 8 ms per lone 2^20 proof and, because hipFree drains the WHOLE device, takes
+ * three provers in flight from 23.6 to 2.5 proofs/s (profiles/r06_plain_hal.json, `alloc_per_proof`).  Memory obtained here must be
+ * returned with bx_release (not hipFree); bx_free returns the pool to the driver. */
+const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
 /* Hal::alloc_extelem_zeroed / alloc_elem_init(.., 0): an allocation whose words are 0, cleared on the ctx's stream (enqueued, like
  * every other call).  risc0-zkp's prover relies on it where it accumulates into a fresh buffer — `combos` in Prover::finalize is
  * filled by mix_poly_coeffs' `+=` — and Hal::eltwise_zeroize_elem is NOT a clear (it maps the INVALID marker 0xffffffff to 0 and
  * leaves every other word alone), so a trait-level caller has no other way to get zeros (tests/plain_hal_prover.c found this). */
 const char* bx_alloc_zeroed(bx_ctx* ctx, size_t words, bx_buf* out);
+/* Enqueue-only for pooled blocks (the block is reused behind everything already on the stream); blocks the pool does not keep, and
+ * pointers it never handed out, are freed after a stream wait as before. */
 const char* bx_release(bx_ctx* ctx, bx_buf buf);
 const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
 const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */

@@ -15,6 +15,7 @@ OUT = os.path.join(HERE, "_build", "libplain_hal.so")
 
 EXT_INTERPOLATE_ZK, EXT_MERKLE_BUILD, EXT_COEFFS_BITREV, EXT_DIVIDE_BATCH, EXT_QUERY_GATHER, EXT_EVAL_PTRS = 1, 2, 4, 8, 16, 32
 EXT_ALL = 63
+ALLOC_PER_PROOF = 64  # not an extension: the big buffers are allocated and released inside every proof, as risc0-zkp's prover does
 EXT_NAMES = {EXT_INTERPOLATE_ZK: "bx_batch_interpolate_zk", EXT_MERKLE_BUILD: "bx_merkle_build",
              EXT_COEFFS_BITREV: "bx_batch_evaluate_any_bitrev+bx_batch_bit_reverse_ext", EXT_DIVIDE_BATCH: "bx_poly_divide_batch_indexed",
              EXT_QUERY_GATHER: "bx_merkle_query_gather", EXT_EVAL_PTRS: "bx_batch_evaluate_ptrs"}

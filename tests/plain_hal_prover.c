@@ -44,6 +44,10 @@
 #define PH_EXT_QUERY_GATHER 16u  /* bx_merkle_query_gather             for gather_sample per row / per digest             */
 #define PH_EXT_EVAL_PTRS 32u     /* bx_batch_evaluate_ptrs (one call)  for batch_evaluate_any per group (N >= 2^15)       */
 #define PH_EXT_ALL 63u
+#define PH_ALLOC_PER_PROOF 64u   /* not an extension: the big buffers (coefficients, evaluations, Merkle nodes, FRI rounds, query buffer:
+                                    ~9 GB at 2^20 / 16-256-64) are allocated at the start of every proof and released at its end, as
+                                    risc0-zkp's prover does (hal.alloc_* inside commit_group / finalize / fri_prove) — what bx_alloc /
+                                    bx_release cost a trait-level caller.  Default: everything is allocated once in ph_create. */
 
 #define P BX_P
 #define MONT_ONE 268435454u
@@ -222,6 +226,8 @@ typedef struct ph_prover {
     bx_buf code_w, combos, final_poly, which, xs, evals, rems, final_coeffs, seg_dev, qout, positions, tap_ptrs, tap_flags;
     fri_round rounds[MAX_ROUNDS];
     size_t n_rounds, final_size, seal_cap;
+    size_t qwords;
+    int big;      /* the big buffers are allocated */
     size_t calls; /* entry-point calls of the last proof */
     char err[512];
 } ph_prover;
@@ -252,8 +258,45 @@ static const char* tree_init(ph_prover* p, tree* t, size_t rows, size_t cols) {
     }
     t->top = (size_t)1 << top;
     t->depth = t->layers - top;
-    PH(bx_alloc(p->c, 16 * rows, &t->nodes));
+    (void)p;
     return NULL;
+}
+/* the big per-proof buffers (what risc0-zkp's prover allocates inside a proof) */
+static const char* big_alloc(ph_prover* p) {
+    bx_ctx* c = p->c;
+    const size_t N = p->N, D = 4 * N;
+    for (int g = 0; g < 4; ++g) {
+        group* G = &p->g[g];
+        PH(bx_alloc(c, (size_t)G->width * N, &G->coeffs));
+        PH(bx_alloc(c, (size_t)G->width * D, &G->evaluated));
+        PH(bx_alloc(c, 16 * G->tr.rows, &G->tr.nodes));
+    }
+    PH(bx_alloc(c, (size_t)p->shape.w_code * N, &p->code_w));
+    PH(bx_alloc(c, 4 * N, &p->final_poly));
+    for (size_t r = 0; r < p->n_rounds; ++r) {
+        fri_round* R = &p->rounds[r];
+        PH(bx_alloc(c, 16 * R->size, &R->evaluated));
+        PH(bx_alloc(c, 4 * R->size / BX_FRI_FOLD, &R->out_coeffs));
+        PH(bx_alloc(c, 16 * R->tr.rows, &R->tr.nodes));
+    }
+    PH(bx_alloc(c, 4 * p->final_size, &p->final_coeffs));
+    PH(bx_alloc(c, p->qwords * BX_QUERIES, &p->qout));
+    p->big = 1;
+    return NULL;
+}
+static void big_release(ph_prover* p) {
+    bx_buf* bufs[4 * 3 + 4 + 3 * MAX_ROUNDS];
+    size_t n = 0;
+    for (int g = 0; g < 4; ++g) bufs[n++] = &p->g[g].coeffs, bufs[n++] = &p->g[g].evaluated, bufs[n++] = &p->g[g].tr.nodes;
+    bufs[n++] = &p->code_w, bufs[n++] = &p->final_poly, bufs[n++] = &p->final_coeffs, bufs[n++] = &p->qout;
+    for (size_t r = 0; r < p->n_rounds; ++r) bufs[n++] = &p->rounds[r].evaluated, bufs[n++] = &p->rounds[r].out_coeffs, bufs[n++] = &p->rounds[r].tr.nodes;
+    for (size_t i = 0; i < n; ++i) {
+        if (bufs[i]->dptr) (void)bx_release(p->c, *bufs[i]), p->calls += 1;
+        bufs[i]->dptr = NULL;
+    }
+    if (p->combos.dptr) (void)bx_release(p->c, p->combos), p->calls += 1;
+    p->combos.dptr = NULL;
+    p->big = 0;
 }
 
 const char* ph_error(const ph_prover* p) { return p ? p->err : "null"; }
@@ -264,22 +307,14 @@ const char* ph_destroy(ph_prover* p) {
     if (!p) return NULL;
     if (p->c) (void)bx_sync(p->c);
     if (p->circ && p->circ_state && p->circ->destroy) p->circ->destroy(p->circ->user, p->circ_state);
-    bx_buf* bufs[] = {&p->code_w, &p->combos, &p->final_poly, &p->which, &p->xs, &p->evals, &p->rems, &p->final_coeffs, &p->seg_dev, &p->qout,
-                      &p->positions, &p->tap_ptrs, &p->tap_flags};
+    if (p->c) big_release(p);
+    bx_buf* bufs[] = {&p->which, &p->xs, &p->evals, &p->rems, &p->seg_dev, &p->positions, &p->tap_ptrs, &p->tap_flags};
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; ++i)
         if (bufs[i]->dptr) (void)bx_release(p->c, *bufs[i]);
     for (int g = 0; g < 4; ++g) {
         group* G = &p->g[g];
-        if (G->coeffs.dptr) (void)bx_release(p->c, G->coeffs);
-        if (G->evaluated.dptr) (void)bx_release(p->c, G->evaluated);
         if (G->combo_ids.dptr) (void)bx_release(p->c, G->combo_ids);
-        if (G->tr.nodes.dptr) (void)bx_release(p->c, G->tr.nodes);
         free(G->n_backs), free(G->backs), free(G->combo);
-    }
-    for (size_t r = 0; r < p->n_rounds; ++r) {
-        if (p->rounds[r].evaluated.dptr) (void)bx_release(p->c, p->rounds[r].evaluated);
-        if (p->rounds[r].out_coeffs.dptr) (void)bx_release(p->c, p->rounds[r].out_coeffs);
-        if (p->rounds[r].tr.nodes.dptr) (void)bx_release(p->c, p->rounds[r].tr.nodes);
     }
     if (p->own_ctx && p->c) (void)bx_free(p->c);
     free(p);
@@ -322,8 +357,6 @@ const char* ph_create(bx_ctx* ctx, int device, const bx_segment_params* shape, u
     for (int g = 0; g < 4; ++g) {
         group* G = &p->g[g];
         G->width = widths[g];
-        CR(bx_alloc(ctx, (size_t)G->width * N, &G->coeffs));
-        CR(bx_alloc(ctx, (size_t)G->width * D, &G->evaluated));
         CR(tree_init(p, &G->tr, D, G->width));
         G->n_backs = (uint32_t*)calloc(G->width, 4);
         G->backs = (uint32_t(*)[BX_MAX_TAPS])calloc(G->width, sizeof *G->backs);
@@ -360,9 +393,7 @@ const char* ph_create(bx_ctx* ctx, int device, const bx_segment_params* shape, u
     for (size_t id = 0; id < p->n_trace_combos; ++id) p->n_div += p->combo_n[id];
     if (p->circ->create) CR(p->circ->create(p->circ->user, ctx, &p->shape, &p->circ_state));
     p->n_globals = p->circ->n_globals ? p->circ->n_globals(p->circ->user, &p->shape) : 0;
-    CR(bx_alloc(ctx, (size_t)p->shape.w_code * N, &p->code_w));
     /* `combos` is allocated per proof (alloc_extelem_zeroed in Prover::finalize): mix_poly_coeffs accumulates into it */
-    CR(bx_alloc(ctx, 4 * N, &p->final_poly));
     CR(bx_alloc(ctx, p->total_taps, &p->which));
     CR(bx_alloc(ctx, 4 * p->total_taps, &p->xs));
     CR(bx_alloc(ctx, 4 * p->total_taps, &p->evals));
@@ -370,47 +401,51 @@ const char* ph_create(bx_ctx* ctx, int device, const bx_segment_params* shape, u
     CR(bx_alloc(ctx, (BX_SEGMENT_WIRE_BYTES + 3) / 4, &p->seg_dev));
     {   /* `which` of batch_evaluate_any: the polynomial (column) of every tap evaluation, group by group */
         uint32_t* w = (uint32_t*)malloc(4 * p->total_taps);
-        uint32_t* ptrs = (uint32_t*)malloc(8 * p->total_taps);
-        uint32_t* fl = (uint32_t*)malloc(4 * p->total_taps);
         size_t e = 0;
-        if (!w || !ptrs || !fl) CR("ph_create: out of memory");
+        if (!w) CR("ph_create: out of memory");
         for (int g = 0; g < 4; ++g)
             for (uint32_t col = 0; col < p->g[g].width; ++col)
-                for (uint32_t t = 0; t < p->g[g].n_backs[col]; ++t, ++e) {
-                    const unsigned long long a = (unsigned long long)(uintptr_t)((uint32_t*)p->g[g].coeffs.dptr + (size_t)col * N);
-                    w[e] = col;
-                    ptrs[2 * e] = (uint32_t)a, ptrs[2 * e + 1] = (uint32_t)(a >> 32);
-                    fl[e] = ((p->flags & PH_EXT_COEFFS_BITREV) && g < 3) ? 1u : 0u;
-                }
+                for (uint32_t t = 0; t < p->g[g].n_backs[col]; ++t, ++e) w[e] = col;
         const char* m = bx_h2d(ctx, p->which, w, p->total_taps);
-        if (!m && (p->flags & PH_EXT_EVAL_PTRS)) {
-            m = bx_alloc(ctx, 2 * p->total_taps, &p->tap_ptrs);
-            if (!m) m = bx_alloc(ctx, p->total_taps, &p->tap_flags);
-            if (!m) m = bx_h2d(ctx, p->tap_ptrs, ptrs, 2 * p->total_taps);
-            if (!m) m = bx_h2d(ctx, p->tap_flags, fl, p->total_taps);
-        }
-        if (!m) m = bx_sync(ctx);
-        free(w), free(ptrs), free(fl);
+        free(w);
         CR(m);
     }
     size_t size = N, qwords = 0;
     while (size > BX_FRI_MIN_DEGREE) {
         fri_round* R = &p->rounds[p->n_rounds++];
         R->size = size;
-        CR(bx_alloc(ctx, 16 * size, &R->evaluated));
-        CR(bx_alloc(ctx, 4 * size / BX_FRI_FOLD, &R->out_coeffs));
         CR(tree_init(p, &R->tr, 4 * size / BX_FRI_FOLD, 4 * BX_FRI_FOLD));
         qwords += R->tr.cols + 8 * R->tr.depth;
         size /= BX_FRI_FOLD;
     }
     p->final_size = size;
-    CR(bx_alloc(ctx, 4 * size, &p->final_coeffs));
     for (int g = 0; g < 4; ++g) qwords += p->g[g].tr.cols + 8 * p->g[g].tr.depth;
-    CR(bx_alloc(ctx, qwords * BX_QUERIES, &p->qout));
+    p->qwords = qwords;
     CR(bx_alloc(ctx, BX_QUERIES * MAX_TREES, &p->positions));
     p->seal_cap = BX_SEAL_HEADER_WORDS + p->n_globals + 4 * p->total_taps + 4 * size + BX_QUERIES * qwords;
     for (int g = 0; g < 4; ++g) p->seal_cap += 8 * p->g[g].tr.top;
     for (size_t r = 0; r < p->n_rounds; ++r) p->seal_cap += 8 * p->rounds[r].tr.top;
+    if (p->flags & PH_ALLOC_PER_PROOF) p->flags &= ~PH_EXT_EVAL_PTRS; /* that entry point takes column ADDRESSES, fixed per shape */
+    if (!(p->flags & PH_ALLOC_PER_PROOF)) CR(big_alloc(p));
+    if (p->flags & PH_EXT_EVAL_PTRS) { /* bx_batch_evaluate_ptrs: the device address and storage order of every tap's column */
+        uint32_t* ptrs = (uint32_t*)malloc(8 * p->total_taps);
+        uint32_t* fl = (uint32_t*)malloc(4 * p->total_taps);
+        size_t e = 0;
+        const char* m = (!ptrs || !fl) ? "ph_create: out of memory" : NULL;
+        for (int g = 0; g < 4 && !m; ++g)
+            for (uint32_t col = 0; col < p->g[g].width; ++col)
+                for (uint32_t t = 0; t < p->g[g].n_backs[col]; ++t, ++e) {
+                    const unsigned long long a = (unsigned long long)(uintptr_t)((uint32_t*)p->g[g].coeffs.dptr + (size_t)col * N);
+                    ptrs[2 * e] = (uint32_t)a, ptrs[2 * e + 1] = (uint32_t)(a >> 32);
+                    fl[e] = ((p->flags & PH_EXT_COEFFS_BITREV) && g < 3) ? 1u : 0u;
+                }
+        if (!m) m = bx_alloc(ctx, 2 * p->total_taps, &p->tap_ptrs);
+        if (!m) m = bx_alloc(ctx, p->total_taps, &p->tap_flags);
+        if (!m) m = bx_h2d(ctx, p->tap_ptrs, ptrs, 2 * p->total_taps);
+        if (!m) m = bx_h2d(ctx, p->tap_flags, fl, p->total_taps);
+        free(ptrs), free(fl);
+        CR(m);
+    }
     CR(bx_sync(ctx));
     *out = p;
     return NULL;
@@ -466,6 +501,11 @@ const char* ph_prove(ph_prover* p, uint64_t seed, uint32_t* seal_out, size_t sea
     T.h = &p->h, T.seal = seal_out, T.cap = seal_cap;
     p->calls = 0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (p->flags & PH_ALLOC_PER_PROOF) {
+        if (p->big) big_release(p); /* an earlier proof failed half-way */
+        const char* e = big_alloc(p);
+        if (e) { big_release(p); return e; }
+    }
 
     /* header */
     {
@@ -730,6 +770,7 @@ const char* ph_prove(ph_prover* p, uint64_t seed, uint32_t* seal_out, size_t sea
     }
 done:
     free(coeff_u), free(hostbuf);
+    if (p->flags & PH_ALLOC_PER_PROOF) big_release(p);
     if (err) return err;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (wall_ms) *wall_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;

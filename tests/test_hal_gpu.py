@@ -845,3 +845,66 @@ def test_gather_sample_queue_keeps_the_stream_order_the_caller_sees(hal, defer):
         assert np.array_equal(big.view().reshape(9000, 8), nodes.reshape(4096, 8)[idx])
     finally:
         hal.set_tunable("gather_defer", 1)
+
+
+def test_alloc_pool_recycles_blocks_without_changing_what_callers_see():
+    """bx_alloc / bx_release go through a per-ctx pool (ctx.hpp): a released block serves the next request of about its size.  What a
+    caller can observe must not change: alloc_zeroed is zero on recycled (dirty) memory, work enqueued before a release still sees its
+    data, sizes that do not match get their own block, the cap and the off switch hold, and closing the ctx returns everything."""
+    import torch
+
+    from boundless_amd.hal import HipHal
+
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
+    h = HipHal(0)
+    try:
+        n = 1 << 22
+        a = h.copy_from(np.full(n, 0xDEADBEEF, np.uint32))
+        ptr = a.raw.dptr
+        out = h.alloc(n)
+        h.eltwise_copy_elem(out, a)  # enqueued, reads `a` ...
+        a.free()                     # ... released right behind it: no wait, the block goes to the pool
+        z = h.alloc_zeroed(n)        # the same block comes back (same size), cleared on the stream behind the copy
+        assert z.raw.dptr == ptr
+        assert not z.view().any() and np.all(out.view() == 0xDEADBEEF)
+        z.free()
+        small = h.alloc(n // 2)      # a block twice as large as asked for is not handed out
+        assert small.raw.dptr != ptr
+        close = h.alloc(n - 1000)    # one within 12.5 % is
+        assert close.raw.dptr == ptr
+        small.free(), close.free(), out.free()
+        # many sizes, interleaved lifetimes, contents checked: nothing aliases while live
+        rng = np.random.default_rng(9)
+        live = []
+        for it in range(200):
+            if live and rng.random() < 0.45:
+                buf, val = live.pop(int(rng.integers(len(live))))
+                assert np.all(buf.view() == val)
+                buf.free()
+            else:
+                words = int(rng.integers(1, 1 << 18))
+                buf = h.alloc(words)
+                buf.copy_from(np.full(words, it, np.uint32))
+                live.append((buf, it))
+        ptrs = sorted((b.raw.dptr, b.raw.len) for b, _ in live)
+        assert all(p0 + 4 * l0 <= p1 for (p0, l0), (p1, _) in zip(ptrs, ptrs[1:]))
+        for buf, val in live:
+            assert np.all(buf.view() == val)
+            buf.free()
+        # off switch: the cached blocks go back to the driver at once, releases free again
+        h.set_tunable("alloc_cache_mb", 0)
+        b1 = h.alloc(n)
+        p1 = b1.raw.dptr
+        b1.free()
+        torch.cuda.synchronize()
+        held = free_before - torch.cuda.mem_get_info(0)[0]
+        assert held < (256 << 20), held  # only the ctx's own tables are left
+        h.set_tunable("alloc_cache_mb", 1)  # a 1 MiB cap: a 16 MiB block is not kept
+        b2 = h.alloc(n)
+        b2.free()
+        assert h.alloc(n).raw.dptr is not None
+    finally:
+        h.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] >= free_before - (64 << 20)

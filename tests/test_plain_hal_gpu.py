@@ -142,3 +142,26 @@ def test_three_plain_hal_drivers_in_flight_stay_bit_exact():
     assert sorted(got) == list(range(1000, 1012))
     for seed, seal in got.items():
         assert np.array_equal(seal, ol.prove_segment(po2, *widths, seed)[0]), seed
+
+
+@pytest.mark.parametrize("po2,widths,cache_mb", [(12, (4, 16, 8), None), (16, (16, 32, 8), None), (16, (16, 32, 8), 0)])
+def test_plain_hal_with_every_buffer_allocated_inside_the_proof(po2, widths, cache_mb, monkeypatch):
+    """risc0-zkp's prover allocates its buffers inside a proof and drops them at its end.  The driver does the same with
+    ALLOC_PER_PROOF: bx_alloc / bx_release are then on the proof's path — served by the library's per-ctx pool (a released block is
+    handed to the next request of its size, no driver call, no device-wide wait), or by hipMalloc / hipFree with alloc_cache_mb = 0.
+    Recycled memory is dirty, so this is also the test that nothing in the sequence relies on fresh zeros: three proofs, same seal."""
+    import plain_hal
+
+    if cache_mb is not None:
+        monkeypatch.setenv("BX_TUNABLES", f"alloc_cache_mb={cache_mb}")
+    seed = 4242 + po2
+    pp = plain_hal.PlainHalProver(0, po2=po2, widths=widths, flags=plain_hal.ALLOC_PER_PROOF)
+    try:
+        seals = [pp.prove(seed)[0] for _ in range(3)]
+        other = pp.prove(seed + 1)[0]
+    finally:
+        pp.close()
+    want = ol.prove_segment(po2, *widths, seed)[0]
+    for s in seals:
+        assert np.array_equal(s, want)
+    assert np.array_equal(other, ol.prove_segment(po2, *widths, seed + 1)[0])
