@@ -77,8 +77,9 @@ const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
  * filled by mix_poly_coeffs' `+=` — and Hal::eltwise_zeroize_elem is NOT a clear (it maps the INVALID marker 0xffffffff to 0 and
  * leaves every other word alone), so a trait-level caller has no other way to get zeros (tests/plain_hal_prover.c found this). */
 const char* bx_alloc_zeroed(bx_ctx* ctx, size_t words, bx_buf* out);
-/* Enqueue-only for pooled blocks (the block is reused behind everything already on the stream); blocks the pool does not keep, and
- * pointers it never handed out, are freed after a stream wait as before. */
+/* Enqueue-only for pooled blocks (the block is reused behind everything already on THIS ctx's stream — work of another ctx or stream
+ * that still uses the memory must have been waited for by the caller; hipFree's device-wide wait no longer hides that); blocks the
+ * pool does not keep, and pointers it never handed out, are freed after a stream wait as before. */
 const char* bx_release(bx_ctx* ctx, bx_buf buf);
 const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
 const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */
