@@ -1,6 +1,7 @@
 """Round-6 soak at the metric's size (`PYTHONPATH=. python tools/soak_r06.py SECONDS [out.json]`): two in-library provers
 (bx_prove_segment) and two trait-level drivers (tests/plain_hal_prover.c: plain Hal entry points only, gather_sample queue on) prove
-segments 0, 1, 2, ... of 2^20 cycles side by side for SECONDS.  Every seal is verified on the CPU; every segment a plain driver proved
+segments 0, 1, 2, ... of 2^20 cycles side by side for SECONDS (one of the two drivers allocates and releases its big buffers inside every
+proof: bx_alloc / bx_release pool).  Every seal is verified on the CPU; every segment a plain driver proved
 is proved again by an in-library prover and the two seals compared word for word.  Then 20 x create / prove / destroy of a plain driver
 (its own ctx each time): free HBM before == after."""
 import json
@@ -21,7 +22,8 @@ from boundless_amd.prover import HipProverServer, Segment, verify_seal  # noqa: 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 out = sys.argv[2] if len(sys.argv) > 2 else None
 servers = [HipProverServer(0) for _ in range(3)]  # two lanes + the re-prover
-drivers = [plain_hal.PlainHalProver(0) for _ in range(2)]
+drivers = [plain_hal.PlainHalProver(0), plain_hal.PlainHalProver(0, flags=plain_hal.ALLOC_PER_PROOF)]  # the second allocates its ~9 GB of
+# buffers inside every proof, through the library's per-ctx pool (as risc0-zkp's prover would)
 todo, again = queue.Queue(), queue.Queue()
 stats = {"proved_in_library": 0, "proved_plain_hal": 0, "verified": 0, "recompared": 0, "mismatches": 0, "verify_failures": 0}
 lock = threading.Lock()
