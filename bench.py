@@ -32,6 +32,11 @@ rank 0 joins them: the job's only collective);
 The JSON line also carries
   single_proof_ms   wall clock of a lone proof (the reference's agent proves one segment at a time per process), no HIP events around it;
                     .spin_wait = the same with the host thread busy-waiting on its stream (the one-proof-at-a-time latency mode);
+                    .plain_hal = the same segment proved from OUTSIDE the library through the plain Hal-trait entry points of SURVEY 8(b2)
+                    only (tests/plain_hal_prover.c: what a Rust `impl Hal for HipHal` shim driven by risc0-zkp's prover gets; seal compared with
+                    bx_prove_segment's), then with each extension entry point swapped in alone, with three such drivers in flight, and with
+                    the ~9 GB of buffers allocated inside every proof as upstream does (`alloc_per_proof`: through the library's bx_alloc pool,
+                    and on raw hipMalloc / hipFree);
   pcie_inclusive    untimed extra at N=1: the same workload with 80 MB per segment over PCIe, two deep (`value` stays inputs-resident);
   per_rank, backend one row per rank (rank, device, proofs, seconds) and the backend's world size: whether RCCL saw N ranks, and balance;
   roofline      the NTT/LDE entry point named by BASELINE's metric (`roofline.dominant` = the job's dominant kernel, hash_rows, against
