@@ -142,6 +142,7 @@ struct bx_ctx {
     // seal verifiers, so 2 is the default; BX_WAIT=spin|block|poll overrides it at bx_init.
     long wait_blocking = 2;
     long wait_poll_us = 50;
+    long wait_spin_us = 60;  // policy 2: poll without sleeping for this long before the first usleep (short read-backs end within it)
     bool wait_poll = false;  // blocking requested but the device flag could not be set: sleep-poll an event instead
     hipEvent_t wait_ev = nullptr;
     long eval_x4 = 1;                // batch_evaluate_any: 16-byte loads for whole 2^15-coefficient segments (0 = the dword kernel)

@@ -14,6 +14,7 @@
 #include <string>
 
 #include <sys/prctl.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "ctx.hpp"
@@ -248,6 +249,19 @@ hipError_t stream_wait(bx_ctx* c) {
     if (!slack_set) {
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
         slack_set = true;
+    }
+    // Short waits first: a read-back of a few words on an idle stream is over in 10-20 us, and usleep() cannot wake up earlier than
+    // ~60 us after it was called.  A trait-level caller makes ~30 such waits per proof (one per Buffer::view), which cost it 1.5 ms of
+    // a 48 ms proof.  So the event is polled without sleeping for the first wait_spin_us (bounded: at most that much CPU per wait), then
+    // with the sleep as before.
+    if (c->wait_spin_us > 0) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            if ((e = hipEventQuery(c->wait_ev)) != hipErrorNotReady) return e;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L >= c->wait_spin_us) break;
+        }
     }
     while ((e = hipEventQuery(c->wait_ev)) == hipErrorNotReady) usleep((useconds_t)c->wait_poll_us);
     return e;
@@ -549,6 +563,9 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
         c->ntt_group_cols = value;
     } else if (!strcmp(name, "ntt_tile_b_wide")) {
         c->ntt_tile_b_wide = value != 0;
+    } else if (!strcmp(name, "wait_spin_us")) {
+        BX_REQUIRE(c, value >= 0 && value <= 10000, "wait_spin_us out of range [0, 10000]");
+        c->wait_spin_us = value;
     } else if (!strcmp(name, "alloc_cache_mb")) {
         BX_REQUIRE(c, value >= 0 && value <= (288 << 10), "alloc_cache_mb out of range [0, 294912]");
         BX_ENTER(c);

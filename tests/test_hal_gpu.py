@@ -908,3 +908,30 @@ def test_alloc_pool_recycles_blocks_without_changing_what_callers_see():
         h.close()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info(0)[0] >= free_before - (64 << 20)
+
+
+def test_wait_policies_return_the_same_words(hal):
+    """How a host thread waits for its stream (ctx.hpp: busy-poll, interrupt, event poll with a bounded spin first — wait_spin_us) is
+    not observable in results: a read-back right behind a long kernel and a run of tiny read-backs give the same words under each."""
+    from boundless_amd.hal import HalError
+
+    n = 1 << 22
+    src = rnd(920, n)
+    try:
+        for blocking, spin in [(2, 60), (2, 0), (2, 5000), (0, 60), (1, 60)]:
+            hal.set_tunable("wait_blocking", blocking)
+            hal.set_tunable("wait_spin_us", spin)
+            a, out = hal.copy_from(src), hal.alloc(n)
+            for _ in range(8):  # a few ms of device work in front of the read-back
+                hal.eltwise_copy_elem(out, a)
+                hal.batch_bit_reverse(out, 1)
+                hal.batch_bit_reverse(out, 1)
+            assert np.array_equal(out.view(), src), (blocking, spin)
+            for i in range(0, 4096, 97):  # short waits: 8 words each on an idle stream
+                assert np.array_equal(out.slice(i, 8).view(), src[i:i + 8]), (blocking, spin, i)
+            a.free(), out.free()
+        with pytest.raises(HalError, match="wait_spin_us out of range"):
+            hal.set_tunable("wait_spin_us", -1)
+    finally:
+        hal.set_tunable("wait_blocking", 2)
+        hal.set_tunable("wait_spin_us", 60)
