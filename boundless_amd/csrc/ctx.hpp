@@ -134,7 +134,8 @@ struct bx_ctx {
     //   1 block  hipSetDeviceFlags(hipDeviceScheduleBlockingSync) before the stream is created (a stream keeps the mode the
     //            device had at its creation): waits sleep on the completion interrupt, but the runtime's event thread then
     //            handles one interrupt per kernel: 0.52 CPUs busy, 0.021 CPU-s per proof (flag is per device and process; if
-    //            the runtime refuses it, falls back to 2);
+    //            the runtime refuses it, falls back to 2).  Only BX_WAIT=block at bx_init sets the flag; asked for at run time
+    //            (bx_set_tunable) it IS policy 2 — flipping the mode under live streams deadlocks a later hipFree (hal.hip);
     //   2 poll   record an event and hipEventQuery it every wait_poll_us (usleep in between; the waiting thread's timer slack is
     //            lowered to 1 us so that the period is real): no interrupts, no spinning: 0.13 CPUs busy, 0.0055 CPU-s per
     //            proof, 24.90 against 24.95 proofs/s busy-polling (a 20 us period doubles the CPU for +0.0).
@@ -257,7 +258,7 @@ const char* gather_flush(bx_ctx* c);  // poly.hip: launch the queued gather_samp
 constexpr uint32_t FLAG_SLOT_SCATTER_RANGE = 0u;  // words of bx_ctx::h_flag
 constexpr uint32_t FLAG_SLOT_SCATTER_INDEX = 1u;
 constexpr uint32_t FLAG_SLOTS = 4u;
-void apply_wait_policy(bx_ctx* c);         // set the device's schedule flag from bx_ctx::wait_blocking
+void apply_wait_policy(bx_ctx* c, bool at_init);  // bx_ctx::wait_blocking -> the device's schedule flag (at bx_init only) or the event poll
 hipError_t stream_wait(bx_ctx* c);           // wait for the ctx's stream under the ctx's wait policy (bx_ctx::wait_blocking)
 const char* sync_and_check_flag(bx_ctx* c);  // stream_wait + deferred device errors
 // h2d without a wait (words <= UP_WORDS): through the pinned ring; when the ring wraps, the stream is drained first

@@ -174,7 +174,7 @@ extern "C" const char* bx_init(int device, bx_ctx** out) try {
     }
     // before the stream exists: a stream keeps the wait mode the device had when it was created (measured: the first ctx of a
     // process, whose stream predated the flag, kept busy-polling while later ones slept)
-    apply_wait_policy(c);
+    apply_wait_policy(c, true);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return "bx_init: hipStreamCreate failed";
@@ -269,12 +269,17 @@ hipError_t stream_wait(bx_ctx* c) {
 // Apply bx_ctx::wait_blocking (see ctx.hpp).  The schedule flag is per DEVICE AND PROCESS, not per ctx: it is touched only for the one
 // policy that needs it ("block"); "poll" (the default) and "spin" leave the process's setting alone — a ctx in the default mode must
 // not force Spin on torch's, RCCL's or another ctx's streams, nor undo a Blocking flag an earlier ctx asked for.
-void apply_wait_policy(bx_ctx* c) {
+// The flag is only ever set from bx_init (BX_WAIT=block), i.e. before this ctx's stream exists.  Asked for at RUN TIME
+// (bx_set_tunable "wait_blocking" 1) the ctx sleep-polls its event instead and the device flag is left alone: flipping the schedule
+// mode of a process whose streams were created under the other mode is accepted by this runtime and then deadlocks a later hipFree —
+// hip::Device::SyncAllStreams waits on a condition variable for streams whose completions are never signalled that way (found by the
+// GPU suite, round 6: an agent destroyed after such a flip hung in synth_destroy -> hipFree -> amd::Event::awaitCompletion).
+void apply_wait_policy(bx_ctx* c, bool at_init) {
     c->wait_poll = false;
     if (c->wait_blocking != 1) return;
-    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) {
-        (void)hipGetLastError();
-        c->wait_poll = true;  // the runtime refused (streams already exist): sleep-poll an event instead
+    if (!at_init || hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) {
+        if (at_init) (void)hipGetLastError();
+        c->wait_poll = true;  // not at init, or the runtime refused: sleep-poll an event instead
     }
 }
 const char* h2d_staged(bx_ctx* c, bx_buf dst, const uint32_t* src, size_t words) {
@@ -599,7 +604,7 @@ extern "C" const char* bx_set_tunable(bx_ctx* c, const char* name, long value) t
         BX_REQUIRE(c, value >= 0 && value <= 2, "wait_blocking must be 0 (busy-poll), 1 (sleep until the completion interrupt) or 2 (sleep-poll an event)");
         c->wait_blocking = value;
         BX_ENTER(c);
-        apply_wait_policy(c);
+        apply_wait_policy(c, false);
     } else if (!strcmp(name, "wait_poll_us")) {
         BX_REQUIRE(c, value >= 1 && value <= 10000, "wait_poll_us out of range [1, 10000]");
         c->wait_poll_us = value;
