@@ -323,6 +323,39 @@ OPS = [op_interpolate, op_expand, op_evaluate, op_hash_rows, op_hash_fold, op_me
        op_sum_ext, op_gather, op_poly_divide, op_prefix, op_scatter]
 
 
+def run(iters=300, seed=1, only="", verbose=False):
+    from boundless_amd.hal import HalError, HipHal
+
+    ol.build()
+    O = ol.lib()
+    hal = HipHal(0)
+    rng = np.random.default_rng(seed)
+    ops = [f for f in OPS if not only or only in f.__name__]
+    ran, refused, failures = {}, {}, []
+    t0 = time.time()
+    try:
+        for it in range(iters):
+            f = ops[int(rng.integers(0, len(ops)))]
+            sub = np.random.default_rng(int(rng.integers(0, 1 << 62)))
+            try:
+                what = f(hal, O, sub)
+                ran[f.__name__] = ran.get(f.__name__, 0) + 1
+                if verbose:
+                    print(it, what, flush=True)
+            except HalError as e:  # a refusal is loud: allowed, but counted and shown
+                refused.setdefault(f.__name__, []).append(str(e))
+                try:
+                    hal.sync()
+                except HalError:
+                    pass
+            except AssertionError as e:
+                failures.append({"iter": it, "op": f.__name__, "error": str(e)})
+    finally:
+        hal.close()
+    return {"tool": "fuzz_hal", "seed": seed, "iters": iters, "seconds": round(time.time() - t0, 1), "ran": ran,
+            "refused": {k: {"count": len(v), "first": v[0]} for k, v in refused.items()}, "failures": failures[:20], "n_failures": len(failures)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=300)
@@ -330,36 +363,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
-    from boundless_amd.hal import HalError, HipHal
-
-    ol.build()
-    O = ol.lib()
-    hal = HipHal(0)
-    rng = np.random.default_rng(args.seed)
-    ops = [f for f in OPS if not args.only or args.only in f.__name__]
-    ran, refused, failures = {}, {}, []
-    t0 = time.time()
-    for it in range(args.iters):
-        f = ops[int(rng.integers(0, len(ops)))]
-        sub = np.random.default_rng(int(rng.integers(0, 1 << 62)))
-        try:
-            what = f(hal, O, sub)
-            ran[f.__name__] = ran.get(f.__name__, 0) + 1
-            if args.verbose:
-                print(it, what, flush=True)
-        except HalError as e:  # a refusal is loud: allowed, but counted and shown
-            refused.setdefault(f.__name__, []).append(str(e))
-            try:
-                hal.sync()
-            except HalError:
-                pass
-        except AssertionError as e:
-            failures.append({"iter": it, "op": f.__name__, "error": str(e)})
-    hal.close()
-    out = {"tool": "fuzz_hal", "seed": args.seed, "iters": args.iters, "seconds": round(time.time() - t0, 1), "ran": ran,
-           "refused": {k: {"count": len(v), "first": v[0]} for k, v in refused.items()}, "failures": failures[:20], "n_failures": len(failures)}
+    out = run(args.iters, args.seed, args.only, args.verbose)
     print(json.dumps(out))
-    return 1 if failures else 0
+    return 1 if out["n_failures"] else 0
 
 
 if __name__ == "__main__":

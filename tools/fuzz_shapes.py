@@ -24,15 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle_lib as ol  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--min-po2", type=int, default=9)
-    ap.add_argument("--max-po2", type=int, default=15)
-    ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0 = run all iterations)")
-    ap.add_argument("--verbose", action="store_true")
-    args = ap.parse_args()
+def run(args):
     import plain_hal
     from boundless_amd.hal import HalError
     from boundless_amd.prover import HipProverServer, Segment
@@ -83,8 +75,20 @@ def main():
             failures.append({"iter": it, **what, "error": f"{type(e).__name__}: {e}"[:400]})
     out = {"tool": "fuzz_shapes", "seed": args.seed, "shapes_proved_and_verified": done, "of_which_also_through_the_plain_driver": plain_done,
            "seconds": round(time.time() - t0, 1), "failures": failures[:20], "n_failures": len(failures)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--min-po2", type=int, default=9)
+    ap.add_argument("--max-po2", type=int, default=15)
+    ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0 = run all iterations)")
+    ap.add_argument("--verbose", action="store_true")
+    out = run(ap.parse_args())
     print(json.dumps(out))
-    return 1 if failures else 0
+    return 1 if out["n_failures"] else 0
 
 
 if __name__ == "__main__":
