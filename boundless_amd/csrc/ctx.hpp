@@ -198,6 +198,12 @@ const char* abi_caught(bx_ctx* c, const char* fn) noexcept;
     } while (0)
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+// a * b <= limit without wrapping: the scalars of an entry point come from the caller, and a product that wraps must not pass a bound
+// check (a wrapped `4 * count` is also a division by zero)
+inline bool mul_le(size_t a, size_t b, size_t limit) {
+    size_t p;
+    return !__builtin_mul_overflow(a, b, &p) && p <= limit;
+}
 inline int ilog2(size_t n) {
     int k = 0;
     while (((size_t)1 << k) < n) k++;

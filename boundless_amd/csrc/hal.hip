@@ -370,6 +370,7 @@ namespace bx {
 // the library's own long-lived buffers (a prover's buffer set, the circuit's tables): straight from the driver, freed with hipFree
 const char* raw_alloc(bx_ctx* c, size_t words, bx_buf* out) {
     BX_REQUIRE(c, out != nullptr, "raw_alloc: null out");
+    BX_REQUIRE(c, words <= ((size_t)1 << 40), "raw_alloc: more than 2^40 words asked for");
     BX_HIP(c, hipSetDevice(c->device));
     void* p = nullptr;
     BX_HIP(c, hipMalloc(&p, (words ? words : 1) * 4));
@@ -390,6 +391,7 @@ static void pool_trim(bx_ctx* c) {  // give every cached block back to the drive
     c->pool_cached = 0;
 }
 static const char* pool_alloc(bx_ctx* c, size_t words, void** out) {
+    BX_REQUIRE(c, words <= ((size_t)1 << 40), "bx_alloc: more than 2^40 words asked for");  // and words * 4 cannot wrap below
     const size_t bytes = pool_round((words ? words : 1) * 4);
     if (c->alloc_cache_mb > 0) {
         auto it = c->pool_free.lower_bound(bytes);

@@ -583,7 +583,7 @@ extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count,
     if (!c) return "bx_batch_evaluate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && io.len % count == 0 && is_pow2(io.len / count), "batch_evaluate_ntt: io.len/count must be a power of two");
     int m = ilog2(io.len / count);
-    BX_REQUIRE(c, (int)expand_bits <= m, "batch_evaluate_ntt: expand_bits > log2(size)");
+    BX_REQUIRE(c, expand_bits <= (size_t)m, "batch_evaluate_ntt: expand_bits > log2(size)");
     BX_ENTER(c);
     OpScope op(c, "batch_evaluate_ntt", 8.0 * (double)io.len);
     return forward(c, (uint32_t*)io.dptr, (const uint32_t*)io.dptr, count, m, 0, (int)expand_bits);
@@ -592,7 +592,7 @@ extern "C" const char* bx_batch_evaluate_ntt(bx_ctx* c, bx_buf io, size_t count,
 extern "C" const char* bx_batch_expand_into_evaluate_ntt(bx_ctx* c, bx_buf out, bx_buf in, size_t count, size_t expand_bits) try {
     if (!c) return "bx_batch_expand_into_evaluate_ntt: null ctx";
     BX_REQUIRE(c, count > 0 && in.len % count == 0 && is_pow2(in.len / count), "batch_expand_into_evaluate_ntt: in.len/count must be a power of two");
-    BX_REQUIRE(c, out.len == (in.len << expand_bits), "batch_expand_into_evaluate_ntt: out.len != in.len << expand_bits");
+    BX_REQUIRE(c, expand_bits < 32 && out.len >> expand_bits == in.len && out.len == (in.len << expand_bits), "batch_expand_into_evaluate_ntt: out.len != in.len << expand_bits");
     BX_REQUIRE(c, out.dptr != in.dptr || expand_bits == 0, "batch_expand_into_evaluate_ntt: in-place expansion");
     BX_ENTER(c);
     OpScope op(c, "batch_expand_into_evaluate_ntt", 4.0 * (double)in.len + 4.0 * (double)out.len);
@@ -635,7 +635,7 @@ __global__ void bit_reverse_ext_kernel(uint4* __restrict__ io, int n, size_t tot
 }
 extern "C" const char* bx_batch_bit_reverse_ext(bx_ctx* c, bx_buf io_ext, size_t count) try {
     if (!c) return "bx_batch_bit_reverse_ext: null ctx";
-    BX_REQUIRE(c, count > 0 && io_ext.len % (4 * count) == 0 && is_pow2(io_ext.len / (4 * count)),
+    BX_REQUIRE(c, count > 0 && count <= io_ext.len / 4 && io_ext.len % (4 * count) == 0 && is_pow2(io_ext.len / (4 * count)),
                "batch_bit_reverse_ext: io.len/(4*count) must be a power of two");
     BX_REQUIRE(c, ((uintptr_t)io_ext.dptr & 15) == 0, "batch_bit_reverse_ext: buffer must be 16-byte aligned");
     BX_ENTER(c);

@@ -650,8 +650,8 @@ extern "C" const char* bx_fri_fold_dev(bx_ctx* c, bx_buf out, bx_buf in, bx_buf 
 extern "C" const char* bx_mix_poly_coeffs(bx_ctx* c, bx_buf out, const uint32_t mix_start[4], const uint32_t mix[4], bx_buf in,
                                           bx_buf combos, size_t input_size, size_t count) try {
     if (!c) return "bx_mix_poly_coeffs: null ctx";
-    BX_REQUIRE(c, in.len >= input_size * count && combos.len >= input_size, "mix_poly_coeffs: input/combos too small");
-    BX_REQUIRE(c, count > 0 && out.len % (4 * count) == 0, "mix_poly_coeffs: out.len not a multiple of 4*count");
+    BX_REQUIRE(c, mul_le(input_size, count, in.len) && combos.len >= input_size, "mix_poly_coeffs: input/combos too small");
+    BX_REQUIRE(c, count > 0 && mul_le(4, count, out.len) && out.len % (4 * count) == 0, "mix_poly_coeffs: out.len not a multiple of 4*count");
     BX_ENTER(c);
     if (!input_size) return nullptr;
     size_t n_combos = out.len / (4 * count);
@@ -800,7 +800,7 @@ extern "C" const char* bx_eltwise_sum_extelem(bx_ctx* c, bx_buf out, bx_buf in) 
 extern "C" const char* bx_gather_sample(bx_ctx* c, bx_buf dst, bx_buf src, size_t idx, size_t size, size_t stride) try {
     if (!c) return "bx_gather_sample: null ctx";
     BX_REQUIRE(c, dst.len >= size, "gather_sample: dst too small");
-    BX_REQUIRE(c, size == 0 || idx + (size - 1) * stride < src.len, "gather_sample: source index out of range");
+    BX_REQUIRE(c, size == 0 || (idx < src.len && mul_le(size - 1, stride, src.len - 1 - idx)), "gather_sample: source index out of range");
     if (!size) return nullptr;
     // Small gathers are queued and launched together by the next call that touches the ctx (ctx.hpp, "Deferred ... gather_sample"):
     // the openings of a proof are ~5 000 of them.  Stream order as the caller sees it is kept: anything that could observe the

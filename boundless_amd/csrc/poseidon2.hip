@@ -541,8 +541,7 @@ extern "C" const char* bx_hash_rows(bx_ctx* c, bx_buf out, bx_buf matrix) try {
 
 extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, size_t output_size) try {
     if (!c) return "bx_hash_fold: null ctx";
-    BX_REQUIRE(c, input_size == 2 * output_size, "hash_fold: input_size must be 2*output_size");
-    BX_REQUIRE(c, io.len >= (input_size + 2 * output_size) * 8, "hash_fold: digest buffer too small");
+    BX_REQUIRE(c, output_size <= io.len / 32 && input_size == 2 * output_size, "hash_fold: input_size must be 2*output_size, and the buffer hold 2*input_size digests");
     BX_ENTER(c);
     OpScope op(c, "hash_fold", 96.0 * (double)output_size);
     return launch_hash_fold(c, (uint32_t*)io.dptr, input_size, output_size);
@@ -550,7 +549,7 @@ extern "C" const char* bx_hash_fold(bx_ctx* c, bx_buf io, size_t input_size, siz
 
 extern "C" const char* bx_hash_fold_indexed(bx_ctx* c, bx_buf out, bx_buf in, bx_buf sel, size_t count) try {
     if (!c) return "bx_hash_fold_indexed: null ctx";
-    BX_REQUIRE(c, out.len >= 8 * count && sel.len >= 2 * count, "hash_fold_indexed: out or sel too small");
+    BX_REQUIRE(c, count <= out.len / 8 && count <= sel.len / 2, "hash_fold_indexed: out or sel too small");
     BX_REQUIRE(c, count <= 0xffffffffu && in.len / 8 <= 0xffffffffu, "hash_fold_indexed: too many digests");
     if (count == 0) return nullptr;
     BX_REQUIRE(c, out.dptr && in.dptr && sel.dptr && in.len >= 8, "hash_fold_indexed: null or empty buffer");
@@ -601,7 +600,7 @@ static const char* merkle_fold_layers(bx_ctx* c, uint32_t* n, size_t rows) {
 
 extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, size_t rows) try {
     if (!c) return "bx_merkle_build: null ctx";
-    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
+    BX_REQUIRE(c, is_pow2(rows) && rows <= nodes.len / 16 && nodes.len == 16 * rows, "merkle_build: nodes must hold 2*rows digests, rows a power of two");
     BX_REQUIRE(c, matrix.len % rows == 0, "merkle_build: matrix.len not a multiple of rows");
     BX_ENTER(c);
     uint32_t* n = (uint32_t*)nodes.dptr;
@@ -615,7 +614,7 @@ extern "C" const char* bx_merkle_build(bx_ctx* c, bx_buf nodes, bx_buf matrix, s
 // Extension: the fold half of bx_merkle_build alone — the leaves are already in nodes[rows .. 2 rows).
 extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) try {
     if (!c) return "bx_merkle_fold: null ctx";
-    BX_REQUIRE(c, is_pow2(rows) && nodes.len == 16 * rows, "merkle_fold: nodes must hold 2*rows digests, rows a power of two");
+    BX_REQUIRE(c, is_pow2(rows) && rows <= nodes.len / 16 && nodes.len == 16 * rows, "merkle_fold: nodes must hold 2*rows digests, rows a power of two");
     BX_ENTER(c);
     OpScope op(c, "hash_fold", 96.0 * (double)(rows - 1));
     return merkle_fold_layers(c, (uint32_t*)nodes.dptr, rows);
@@ -624,8 +623,8 @@ extern "C" const char* bx_merkle_fold(bx_ctx* c, bx_buf nodes, size_t rows) try 
 extern "C" const char* bx_transcript_step(bx_ctx* c, bx_buf state, bx_buf digests, size_t n_commit, bx_buf out_ext, size_t n_ext) try {
     if (!c) return "bx_transcript_step: null ctx";
     BX_REQUIRE(c, state.dptr != nullptr && state.len >= 25, "transcript_step: the state is 24 cells and the pool counter");
-    BX_REQUIRE(c, digests.len >= 8 * n_commit && out_ext.len >= 4 * n_ext, "transcript_step: digests / out too small");
     BX_REQUIRE(c, n_commit <= 64 && n_ext <= 64, "transcript_step: at most 64 commits and 64 challenges per step");
+    BX_REQUIRE(c, digests.len >= 8 * n_commit && out_ext.len >= 4 * n_ext, "transcript_step: digests / out too small");
     BX_ENTER(c);
     if (!n_commit && !n_ext) return nullptr;
     OpScope op(c, "transcript_step", 4.0 * (double)(50 + 8 * n_commit + 4 * n_ext));

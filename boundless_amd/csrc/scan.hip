@@ -384,7 +384,7 @@ extern "C" const char* bx_poly_divide_batch(bx_ctx* c, bx_buf polys, size_t coun
 extern "C" const char* bx_poly_divide_batch_indexed(bx_ctx* c, bx_buf polys, size_t n_polys, size_t count, const uint32_t* which, const uint32_t* zs,
                                                     bx_buf rems_out) try {
     if (!c) return "bx_poly_divide_batch_indexed: null ctx";
-    BX_REQUIRE(c, n_polys >= 1 && polys.len % (4 * n_polys) == 0, "poly_divide_batch_indexed: the buffer does not split into n_polys AoS ext polynomials");
+    BX_REQUIRE(c, n_polys >= 1 && n_polys <= polys.len / 4 && polys.len % (4 * n_polys) == 0, "poly_divide_batch_indexed: the buffer does not split into n_polys AoS ext polynomials");
     BX_REQUIRE(c, count <= 65535 && which != nullptr && zs != nullptr && rems_out.len >= 4 * count, "poly_divide_batch_indexed: one index, one point and one remainder slot per division");
     BX_REQUIRE(c, ((uintptr_t)polys.dptr & 15u) == 0 && ((uintptr_t)rems_out.dptr & 15u) == 0, "poly_divide_batch_indexed: buffers must be 16-byte aligned");
     for (size_t q = 0; q < count; ++q) BX_REQUIRE(c, which[q] < n_polys, "poly_divide_batch_indexed: polynomial index out of range");

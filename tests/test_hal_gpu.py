@@ -935,3 +935,39 @@ def test_wait_policies_return_the_same_words(hal):
     finally:
         hal.set_tunable("wait_blocking", 2)
         hal.set_tunable("wait_spin_us", 60)
+
+
+def test_scalars_whose_products_wrap_are_refused(hal):
+    """The scalars of an entry point come from the caller.  A count / size / stride so large that `4 * count` or `(size - 1) * stride`
+    wraps around 2^64 must fail the bound check like any other out-of-range value — not pass it (and then divide by zero on the host or
+    read far outside the buffer on the device).  Every call returns an error string; the buffers are untouched; the ctx keeps working."""
+    from boundless_amd.hal import HalError
+
+    x = rnd(930, 1 << 12)
+    buf, out = hal.copy_from(x), hal.alloc_zeroed(1 << 14)
+    mix = rnd(931, 4)
+    combos = hal.copy_from(np.zeros(4, np.uint32))
+    hostile = [
+        lambda: hal.mix_poly_coeffs(out, mix, mix, buf, combos, 4, 1 << 62),              # 4 * count wraps to 0: was a division by zero
+        lambda: hal.mix_poly_coeffs(out, mix, mix, buf, combos, 1 << 63, 2),              # input_size * count wraps to 0
+        lambda: hal.gather_sample(out, buf, 2, 9, 1 << 61),                               # (size - 1) * stride wraps to 0
+        lambda: hal.gather_sample(out, buf, 3, 3, (1 << 64) - 1),
+        lambda: hal.gather_sample(out, buf, 1 << 63, 1, 1),
+        lambda: hal.hash_fold(out, 0, 1 << 63),                                           # 2 * output_size wraps to 0 == input_size
+        lambda: hal.merkle_build(out.slice(0, 0), buf, 1 << 60),                          # 16 * rows wraps to 0 == nodes.len
+        lambda: hal.batch_expand_into_evaluate_ntt(out, buf, 1, 66),                      # a shift by more than the word
+        lambda: hal.batch_expand_into_evaluate_ntt(out, buf, 1, 64),
+        lambda: hal.batch_evaluate_ntt(buf, 1, (1 << 32) + 1),                            # truncated to int it was 1
+        lambda: hal.batch_bit_reverse_ext(buf, 1 << 62),
+        lambda: hal.batch_interpolate_ntt(buf, 1 << 63),
+        lambda: hal.fri_fold(out.slice(0, 4), buf.slice(0, 63), mix),
+        lambda: hal.alloc(1 << 62),                                                       # words * 4 wraps to 0 bytes
+        lambda: hal.alloc_zeroed((1 << 62) + 1),
+    ]
+    for k, call in enumerate(hostile):
+        with pytest.raises(HalError):
+            call()
+            pytest.fail(f"hostile call {k} was accepted")
+    assert np.array_equal(buf.view(), x) and not out.view().any()
+    hal.gather_sample(out, buf, 5, 7, 100)  # the largest in-range stride pattern still works
+    assert np.array_equal(out.view()[:7], x[5:5 + 700:100])

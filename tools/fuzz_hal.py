@@ -48,6 +48,8 @@ class Placed:
         got = self.whole.view()
         exp = self.host.copy()
         exp[self.off:self.off + self.n] = want
+        if os.environ.get("FUZZ_SELFTEST") == "1" and self.n:  # the checker checked: one wrong word must be reported
+            exp[self.off + self.n - 1] ^= 1
         if not np.array_equal(got[:self.off], exp[:self.off]) or not np.array_equal(got[self.off + self.n:], exp[self.off + self.n:]):
             raise AssertionError(f"{what}: words outside the operand were written (offset {self.off - PAD})")
         bad = np.nonzero(got != exp)[0]
@@ -67,8 +69,14 @@ def elems(rng, n):
 
 
 # ---- one function per entry point: build operands, call, compare.  Each returns a short description of what it drew. ----
+def big(rng, lo, mid, hi):
+    """mostly [lo, mid), one time in six [mid, hi]: the large sizes take the multi-pass kernels"""
+    return int(rng.integers(mid, hi + 1)) if rng.random() < 1 / 6 else int(rng.integers(lo, mid))
+
+
 def op_interpolate(hal, O, rng):
-    bits, count = int(rng.integers(1, 17)), int(rng.integers(1, 7))
+    bits = big(rng, 1, 17, 22)
+    count = int(rng.integers(1, 7 if bits < 17 else 3))
     n = 1 << bits
     x = elems(rng, n * count)
     io = Placed(hal, rng, x)
@@ -87,7 +95,8 @@ def op_interpolate(hal, O, rng):
 
 
 def op_expand(hal, O, rng):
-    bits, count, eb = int(rng.integers(1, 15)), int(rng.integers(1, 7)), int(rng.integers(1, 4))
+    bits, eb = big(rng, 1, 15, 20), int(rng.integers(1, 4))
+    count = int(rng.integers(1, 7 if bits < 15 else 3))
     n = 1 << bits
     x = elems(rng, n * count)
     inp = Placed(hal, rng, x)
@@ -102,7 +111,8 @@ def op_expand(hal, O, rng):
 
 
 def op_evaluate(hal, O, rng):
-    bits, count = int(rng.integers(1, 16)), int(rng.integers(1, 6))
+    bits = big(rng, 1, 16, 22)
+    count = int(rng.integers(1, 6 if bits < 16 else 3))
     eb = int(rng.integers(0, min(bits, 3) + 1))
     n = 1 << bits
     x = elems(rng, n * count)
@@ -116,8 +126,8 @@ def op_evaluate(hal, O, rng):
 
 
 def op_hash_rows(hal, O, rng):
-    rows = int(rng.integers(1, 3000)) if rng.random() < 0.5 else 1 << int(rng.integers(0, 13))
-    cols = int(rng.integers(1, 70))
+    rows = int(rng.integers(1, 3000)) if rng.random() < 0.5 else 1 << big(rng, 0, 13, 18)
+    cols = int(rng.integers(1, 70 if rows <= 4096 else 20))
     x = elems(rng, rows * cols)
     m = Placed(hal, rng, x)
     out = Placed(hal, rng, np.zeros(8 * rows, np.uint32), granule=8)
@@ -130,7 +140,7 @@ def op_hash_rows(hal, O, rng):
 
 
 def op_hash_fold(hal, O, rng):
-    out_size = 1 << int(rng.integers(0, 12))
+    out_size = 1 << big(rng, 0, 12, 19)
     nodes = elems(rng, 8 * 4 * out_size)  # digests [0, 4 out): inputs at [2 out, 4 out), outputs at [out, 2 out)
     io = Placed(hal, rng, nodes, granule=8)
     hal.hash_fold(io.buf, 2 * out_size, out_size)
@@ -142,8 +152,8 @@ def op_hash_fold(hal, O, rng):
 
 
 def op_merkle(hal, O, rng):
-    rows = 1 << int(rng.integers(0, 13))
-    cols = int(rng.integers(1, 40))
+    rows = 1 << big(rng, 0, 13, 19)
+    cols = int(rng.integers(1, 40 if rows <= 4096 else 12))
     x = elems(rng, rows * cols)
     m = Placed(hal, rng, x)
     nodes = Placed(hal, rng, np.zeros(16 * rows, np.uint32), granule=8)
