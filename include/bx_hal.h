@@ -216,7 +216,8 @@ const char* bx_profile_report(bx_ctx* ctx, char* json_out, size_t cap); /* block
  * an error is returned if none is installed.  The environment variable BX_TRACE=1|2 switches it on at the first bx_init. */
 const char* bx_trace_enable(int level);
 int bx_trace_level(void);
-/* Tunables (NTT pass split, tile sizes); name/value pairs documented in DESIGN.md.  Unknown names error. */
+/* Tunables (NTT pass split, tile sizes, Merkle layer launches, wait policy, allocation pool ...): name/value pairs in DESIGN.md
+ * section 9.  Unknown names and out-of-range values are errors; every combination gives the same words. */
 const char* bx_set_tunable(bx_ctx* ctx, const char* name, long value);
 
 #if defined(__GNUC__)
