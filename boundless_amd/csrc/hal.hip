@@ -447,6 +447,10 @@ extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!b.dptr) return nullptr;
     BX_ENTER(c);
     auto it = c->pool_live.find(b.dptr);
+    if (it == c->pool_live.end() && !c->pool_free.empty()) {  // not handed out by bx_alloc (a raw_alloc / foreign block) — or released TWICE:
+        for (auto& kv : c->pool_free)                         // a block that idles in the pool must not reach hipFree behind the pool's back
+            BX_REQUIRE(c, kv.second != b.dptr, "bx_release: this buffer was already released");
+    }
     if (it != c->pool_live.end()) {
         const size_t cap = it->second;
         c->pool_live.erase(it);

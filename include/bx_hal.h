@@ -79,7 +79,8 @@ const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
 const char* bx_alloc_zeroed(bx_ctx* ctx, size_t words, bx_buf* out);
 /* Enqueue-only for pooled blocks (the block is reused behind everything already on THIS ctx's stream — work of another ctx or stream
  * that still uses the memory must have been waited for by the caller; hipFree's device-wide wait no longer hides that); blocks the
- * pool does not keep, and pointers it never handed out, are freed after a stream wait as before. */
+ * pool does not keep, and pointers it never handed out, are freed after a stream wait as before.  Releasing a block that already
+ * idles in the pool (a double release) is an error, not a hipFree. */
 const char* bx_release(bx_ctx* ctx, bx_buf buf);
 const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
 const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */

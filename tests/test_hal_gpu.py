@@ -892,6 +892,17 @@ def test_alloc_pool_recycles_blocks_without_changing_what_callers_see():
         for buf, val in live:
             assert np.all(buf.view() == val)
             buf.free()
+        # a block released twice is refused (it idles in the pool: a second release must not hipFree it behind the pool's back)
+        from boundless_amd.hal import BxBuf
+
+        dbl = h.alloc(n)
+        raw = BxBuf(dbl.raw.dptr, dbl.raw.len)
+        dbl.free()
+        msg = h.lib.bx_release(h.ctx, raw)
+        assert msg and b"already released" in msg
+        again = h.alloc(n)
+        assert again.raw.dptr == raw.dptr  # still in the pool, still usable
+        again.free()
         # off switch: the cached blocks go back to the driver at once, releases free again
         h.set_tunable("alloc_cache_mb", 0)
         b1 = h.alloc(n)
