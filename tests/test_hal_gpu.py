@@ -855,6 +855,7 @@ def test_alloc_pool_recycles_blocks_without_changing_what_callers_see():
 
     from boundless_amd.hal import HipHal
 
+    HipHal(0).close()  # the first ctx of a process loads the code objects (~150 MB that stay with the runtime): not part of what is measured
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info(0)[0]
     h = HipHal(0)
