@@ -69,7 +69,8 @@ void* bx_get_stream(bx_ctx* ctx);
  * "alloc_cache_mb", default 16384; 0 = off) and handed to the next request of about its size — no driver call and no wait, every use
  * of the memory being ordered on the ctx's one stream.  risc0-zkp's prover allocates every buffer inside a proof and drops it at
  * the end; with raw hipMalloc / hipFree that costs 6 ms per lone 2^20 proof and, because hipFree drains the WHOLE device, takes
- * three provers in flight from 23.5 to 2.9 proofs/s (profiles/r06_plain_hal.json, `alloc_per_proof`).  Memory obtained here must be
+ * three provers in flight from 23.7 to 2.5-3.1 proofs/s in four runs of seven (20-21 in the other three: profiles/
+ * r06_alloc_per_proof_bimodal.json).  Memory obtained here must be
  * returned with bx_release (not hipFree); bx_free returns the pool to the driver. */
 const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
 /* Hal::alloc_extelem_zeroed / alloc_elem_init(.., 0): an allocation whose words are 0, cleared on the ctx's stream (enqueued, like
