@@ -495,6 +495,36 @@ extern "C" const char* bx_d2d(bx_ctx* c, bx_buf dst, bx_buf src, size_t words) t
     BX_HIP(c, hipMemcpyAsync(dst.dptr, src.dptr, words * 4, hipMemcpyDeviceToDevice, c->stream));
     return nullptr;
 } BX_ABI_CATCH(c, "bx_d2d")
+extern "C" const char* bx_eltwise_copy_elem_slice(bx_ctx* c, bx_buf into, const uint32_t* from, size_t from_len, size_t from_rows, size_t from_cols,
+                                                  size_t from_offset, size_t from_stride, size_t into_offset, size_t into_stride) try {
+    if (!c) return "bx_eltwise_copy_elem_slice: null ctx";
+    if (!from_rows || !from_cols) return nullptr;
+    BX_REQUIRE(c, from != nullptr && into.dptr != nullptr, "eltwise_copy_elem_slice: null buffer");
+    // last word touched on each side, without wrapping: offset + (rows - 1) * stride + cols <= len
+    BX_REQUIRE(c, from_cols <= from_len && from_offset <= from_len - from_cols && mul_le(from_rows - 1, from_stride, from_len - from_cols - from_offset),
+               "eltwise_copy_elem_slice: the region leaves the source slice");
+    BX_REQUIRE(c, from_cols <= into.len && into_offset <= into.len - from_cols && mul_le(from_rows - 1, into_stride, into.len - from_cols - into_offset),
+               "eltwise_copy_elem_slice: the region leaves the destination buffer");
+    BX_REQUIRE(c, from_rows == 1 || into_stride >= from_cols, "eltwise_copy_elem_slice: destination rows overlap (into_stride < from_cols)");
+    BX_REQUIRE(c, from_stride <= (SIZE_MAX >> 2) && into_stride <= (SIZE_MAX >> 2), "eltwise_copy_elem_slice: stride too large");
+    BX_ENTER(c);
+    OpScope op(c, "eltwise_copy_elem_slice", 8.0 * (double)from_rows * (double)from_cols);
+    if (from_rows == 1 || (from_stride == from_cols && into_stride == from_cols)) {  // one contiguous run
+        BX_HIP(c, hipMemcpyAsync((uint32_t*)into.dptr + into_offset, from + from_offset, from_rows * from_cols * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // the pitches of a 2-D copy must be at least its width: a source whose rows overlap (from_stride < from_cols) goes row by row
+        if (from_stride >= from_cols) {
+            BX_HIP(c, hipMemcpy2DAsync((uint32_t*)into.dptr + into_offset, into_stride * 4, from + from_offset, from_stride * 4, from_cols * 4, from_rows,
+                                       hipMemcpyHostToDevice, c->stream));
+        } else {
+            for (size_t r = 0; r < from_rows; ++r)
+                BX_HIP(c, hipMemcpyAsync((uint32_t*)into.dptr + into_offset + r * into_stride, from + from_offset + r * from_stride, from_cols * 4,
+                                         hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    BX_HIP(c, stream_wait(c));  // `from` may be pageable and freed by the caller right after
+    return nullptr;
+} BX_ABI_CATCH(c, "bx_eltwise_copy_elem_slice")
 extern "C" const char* bx_sync(bx_ctx* c) try {
     if (!c) return "bx_sync: null ctx";
     BX_ENTER(c);

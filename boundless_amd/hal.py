@@ -67,6 +67,7 @@ def load_library():
         "bx_h2d": [ctx, BxBuf, C.c_void_p, sz],
         "bx_d2h": [ctx, C.c_void_p, BxBuf, sz],
         "bx_d2d": [ctx, BxBuf, BxBuf, sz],
+        "bx_eltwise_copy_elem_slice": [ctx, BxBuf, C.c_void_p, sz, sz, sz, sz, sz, sz, sz],
         "bx_sync": [ctx],
         "bx_batch_interpolate_ntt": [ctx, BxBuf, sz],
         "bx_batch_evaluate_ntt": [ctx, BxBuf, sz, sz],
@@ -323,6 +324,12 @@ class HipHal:
 
     def eltwise_copy_elem(self, output, inp):
         self._check(self.lib.bx_eltwise_copy_elem(self.ctx, output.raw, inp.raw))
+
+    def eltwise_copy_elem_slice(self, into, from_host, from_rows, from_cols, from_offset, from_stride, into_offset, into_stride):
+        """Hal::eltwise_copy_elem_slice: strided 2-D copy of a HOST slice into a device buffer (into[io + r*is + c] = from[fo + r*fs + c])."""
+        a, _ = _words(from_host)
+        self._check(self.lib.bx_eltwise_copy_elem_slice(self.ctx, into.raw, a.ctypes.data, a.size, from_rows, from_cols, from_offset, from_stride,
+                                                        into_offset, into_stride))
 
     def eltwise_zeroize_elem(self, io):
         self._check(self.lib.bx_eltwise_zeroize_elem(self.ctx, io.raw))

@@ -86,6 +86,14 @@ const char* bx_release(bx_ctx* ctx, bx_buf buf);
 const char* bx_h2d(bx_ctx* ctx, bx_buf dst, const uint32_t* src, size_t words);
 const char* bx_d2h(bx_ctx* ctx, uint32_t* dst, bx_buf src, size_t words); /* blocks */
 const char* bx_d2d(bx_ctx* ctx, bx_buf dst, bx_buf src, size_t words);
+/* Hal::eltwise_copy_elem_slice(into, from: &[Elem], from_rows, from_cols, from_offset, from_stride, into_offset, into_stride)
+ * ([EXT] risc0-zkp; the CUDA HAL uploads `from` and runs its `eltwise_copy_fp_region` kernel): a strided 2-D copy of a HOST slice
+ * into a device buffer,   into[into_offset + r * into_stride + c] = from[from_offset + r * from_stride + c],   r < from_rows,
+ * c < from_cols — how the prover places a witness of `steps` rows per column into buffers of 2^po2 rows per column.  One
+ * hipMemcpy2DAsync on the ctx's stream; blocks like bx_h2d (`from` may be pageable and freed by the caller right after).
+ * `from_len` = the slice's length in words.  Rows that would overlap in `into` (into_stride < from_cols) are refused. */
+const char* bx_eltwise_copy_elem_slice(bx_ctx* ctx, bx_buf into, const uint32_t* from, size_t from_len, size_t from_rows, size_t from_cols,
+                                       size_t from_offset, size_t from_stride, size_t into_offset, size_t into_stride);
 const char* bx_sync(bx_ctx* ctx);
 /* Hal::get_hash_suite (its name: "poseidon2", the reference's default hashfn) and Hal::has_unified_memory (0). */
 const char* bx_hash_suite_name(void);

@@ -984,3 +984,37 @@ def test_scalars_whose_products_wrap_are_refused(hal):
     assert np.array_equal(buf.view(), x) and not out.view().any()
     hal.gather_sample(out, buf, 5, 7, 100)  # the largest in-range stride pattern still works
     assert np.array_equal(out.view()[:7], x[5:5 + 700:100])
+
+
+def test_eltwise_copy_elem_slice_places_a_host_region_with_strides(hal):
+    """Hal::eltwise_copy_elem_slice: into[io + r*is + c] = from[fo + r*fs + c] from a HOST slice — how the prover places a witness of
+    `steps` rows per column into buffers of 2^po2 rows per column.  Against numpy, words outside the region untouched, every run
+    shape (one contiguous run, a 2-D copy, overlapping source rows), and the regions that leave either side refused."""
+    from boundless_amd.hal import HalError
+
+    rng = np.random.default_rng(940)
+    for rows, cols, fs, is_, fo, io in [(1, 17, 0, 0, 3, 5), (7, 100, 100, 100, 0, 0), (5, 33, 40, 64, 11, 9), (256, 1000, 1000, 1024, 0, 0),
+                                        (4, 16, 8, 16, 2, 1), (3, 1, 1, 1, 0, 0), (1 << 10, 3, 5, 7, 4, 4)]:
+        src = rnd(rows * 31 + cols, fo + (rows - 1) * fs + cols + 13)
+        init = rnd(cols, io + (rows - 1) * is_ + cols + 29)
+        dst = hal.copy_from(init)
+        hal.eltwise_copy_elem_slice(dst, src, rows, cols, fo, fs, io, is_)
+        want = init.copy()
+        for r in range(rows):
+            want[io + r * is_: io + r * is_ + cols] = src[fo + r * fs: fo + r * fs + cols]
+        assert np.array_equal(dst.view(), want), (rows, cols, fs, is_, fo, io)
+    # the witness shape: 24 columns of 1000 steps into columns of 1024 rows (column-major on both sides)
+    steps, n, w = 1000, 1024, 24
+    wit = rnd(941, steps * w)
+    data = hal.alloc_zeroed(n * w)
+    hal.eltwise_copy_elem_slice(data, wit, w, steps, 0, steps, 0, n)
+    got = data.view().reshape(w, n)
+    assert np.array_equal(got[:, :steps], wit.reshape(w, steps)) and not got[:, steps:].any()
+    dst = hal.alloc_zeroed(100)
+    src = rnd(942, 100)
+    for bad in [(2, 60, 0, 60, 0, 60), (2, 10, 95, 1, 0, 10), (2, 10, 0, 10, 85, 10), (3, 10, 0, 10, 0, 5), (2, 1, 0, 1 << 63, 0, 1),
+                (1 << 62, 4, 0, 4, 0, 4), (1, 101, 0, 0, 0, 0)]:
+        with pytest.raises(HalError):
+            hal.eltwise_copy_elem_slice(dst, src, *bad)
+    assert not dst.view().any()
+    hal.eltwise_copy_elem_slice(dst, src, 0, 5, 0, 0, 0, 0)  # nothing to copy: not an error

@@ -329,7 +329,24 @@ def op_scatter(hal, O, rng):
     return f"scatter {total} into {into_len}"
 
 
-OPS = [op_interpolate, op_expand, op_evaluate, op_hash_rows, op_hash_fold, op_merkle, op_fri_fold, op_mix_poly, op_evaluate_any, op_eltwise,
+def op_copy_slice(hal, O, rng):
+    rows, cols = int(rng.integers(1, 200)), int(rng.integers(1, 3000))
+    fs = int(rng.integers(0 if rows == 1 else 1, cols + 50))
+    is_ = int(rng.integers(cols, cols + 100))
+    fo, io = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+    src = elems(rng, fo + (rows - 1) * fs + cols + int(rng.integers(0, 9)))
+    init = elems(rng, io + (rows - 1) * is_ + cols + int(rng.integers(0, 9)))
+    dst = Placed(hal, rng, init)
+    hal.eltwise_copy_elem_slice(dst.buf, src, rows, cols, fo, fs, io, is_)
+    want = init.copy()
+    for r in range(rows):
+        want[io + r * is_: io + r * is_ + cols] = src[fo + r * fs: fo + r * fs + cols]
+    dst.check(want, f"eltwise_copy_elem_slice rows={rows} cols={cols} fs={fs} is={is_} fo={fo} io={io}")
+    dst.free()
+    return f"eltwise_copy_elem_slice {rows} x {cols}"
+
+
+OPS = [op_copy_slice, op_interpolate, op_expand, op_evaluate, op_hash_rows, op_hash_fold, op_merkle, op_fri_fold, op_mix_poly, op_evaluate_any, op_eltwise,
        op_sum_ext, op_gather, op_poly_divide, op_prefix, op_scatter]
 
 
