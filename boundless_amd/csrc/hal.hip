@@ -442,6 +442,21 @@ extern "C" const char* bx_alloc_zeroed(bx_ctx* c, size_t words, bx_buf* out) try
     }
     return nullptr;
 } BX_ABI_CATCH(c, "bx_alloc_zeroed")
+extern "C" const char* bx_alloc_init(bx_ctx* c, size_t words, uint32_t value, bx_buf* out) try {
+    if (!c) return "bx_alloc_init: null ctx";
+    BX_REQUIRE(c, out != nullptr, "bx_alloc_init: null out");
+    BX_ENTER(c);
+    void* p = nullptr;
+    BX_TRY(pool_alloc(c, words, &p));
+    out->dptr = p;
+    out->len = words;
+    if (words && hipMemsetD32Async((hipDeviceptr_t)p, (int)value, words, c->stream) != hipSuccess) {
+        (void)bx_release(c, *out);
+        out->dptr = nullptr;
+        return set_msg(c, "bx_alloc_init: filling the allocation failed");
+    }
+    return nullptr;
+} BX_ABI_CATCH(c, "bx_alloc_init")
 extern "C" const char* bx_release(bx_ctx* c, bx_buf b) try {
     if (!c) return "bx_release: null ctx";
     if (!b.dptr) return nullptr;

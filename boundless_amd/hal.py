@@ -63,6 +63,7 @@ def load_library():
         "bx_set_stream": [ctx, C.c_void_p],
         "bx_alloc": [ctx, sz, C.POINTER(BxBuf)],
         "bx_alloc_zeroed": [ctx, sz, C.POINTER(BxBuf)],
+        "bx_alloc_init": [ctx, sz, C.c_uint32, C.POINTER(BxBuf)],
         "bx_release": [ctx, BxBuf],
         "bx_h2d": [ctx, BxBuf, C.c_void_p, sz],
         "bx_d2h": [ctx, C.c_void_p, BxBuf, sz],
@@ -222,6 +223,12 @@ class HipHal:
         """Hal::alloc_extelem_zeroed / alloc_elem_init(.., 0): cleared on the ctx's stream (eltwise_zeroize_elem is not a clear)."""
         raw = BxBuf()
         self._check(self.lib.bx_alloc_zeroed(self.ctx, words, C.byref(raw)))
+        return Buffer(self, raw)
+
+    def alloc_elem_init(self, words, value):
+        """Hal::alloc_elem_init: every word holds `value` (e.g. the INVALID marker 0xffffffff), filled on the ctx's stream."""
+        raw = BxBuf()
+        self._check(self.lib.bx_alloc_init(self.ctx, words, int(value) & 0xFFFFFFFF, C.byref(raw)))
         return Buffer(self, raw)
 
     def alloc_extelem(self, n):

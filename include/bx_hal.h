@@ -78,6 +78,10 @@ const char* bx_alloc(bx_ctx* ctx, size_t words, bx_buf* out);
  * filled by mix_poly_coeffs' `+=` — and Hal::eltwise_zeroize_elem is NOT a clear (it maps the INVALID marker 0xffffffff to 0 and
  * leaves every other word alone), so a trait-level caller has no other way to get zeros (tests/plain_hal_prover.c found this). */
 const char* bx_alloc_zeroed(bx_ctx* ctx, size_t words, bx_buf* out);
+/* Hal::alloc_elem_init(name, size, value): an allocation whose words all hold `value` (any 32-bit pattern: rv32im's witness generator
+ * fills its buffers with the INVALID marker 0xffffffff and lets eltwise_zeroize_elem clear what was never written).  Filled on the
+ * ctx's stream (hipMemsetD32Async), enqueued like every other call. */
+const char* bx_alloc_init(bx_ctx* ctx, size_t words, uint32_t value, bx_buf* out);
 /* Enqueue-only for pooled blocks (the block is reused behind everything already on THIS ctx's stream — work of another ctx or stream
  * that still uses the memory must have been waited for by the caller; hipFree's device-wide wait no longer hides that); blocks the
  * pool does not keep, and pointers it never handed out, are freed after a stream wait as before.  Releasing a block that already

@@ -539,6 +539,15 @@ def test_eltwise_and_gather(hal, oracle):
     hal.eltwise_zeroize_elem(zb)
     oracle.bxo_eltwise_zeroize(z, n)
     assert np.array_equal(zb.view(), z)
+    # alloc_elem_init (rv32im's witness generator: every cell INVALID, then eltwise_zeroize_elem clears what was never written)
+    inv = hal.alloc_elem_init(100003, 0xFFFFFFFF)
+    assert np.all(inv.view() == 0xFFFFFFFF)
+    inv.slice(10, 50).copy_from(a[:50])
+    hal.eltwise_zeroize_elem(inv)
+    v = inv.view()
+    assert np.array_equal(v[10:60], a[:50]) and not v[:10].any() and not v[60:].any()
+    inv.free()
+    assert np.all(hal.alloc_elem_init(77, 12345).view() == 12345) and hal.alloc_elem_init(0, 5).view().size == 0
     # alloc_zeroed (Hal::alloc_extelem_zeroed): zeros even when the allocator hands back memory that was just dirtied and freed
     for _ in range(3):
         d = hal.copy_from(np.full(1 << 20, 0xDEADBEEF, np.uint32))
